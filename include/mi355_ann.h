@@ -1,0 +1,252 @@
+/*
+ * mi355_ann.h — C ABI of the MI355X (gfx950) ANN scan engine.
+ *
+ * This is the drop-in boundary for LanceDB's vector-search hot path.  In the
+ * reference there is no FFI on this path: `lancedb::query::VectorQuery` holds an
+ * `Arc<dyn BaseTable>` (rust/lancedb/src/table.rs:549-576) and
+ * `table::query::create_plan` (rust/lancedb/src/table/query.rs:131-328) hands a
+ * `VectorQueryRequest` (rust/lancedb/src/query.rs:1066-1095) to
+ * `lance::dataset::scanner::Scanner::{nearest, minimum_nprobes, maximum_nprobes,
+ * refine, distance_metric, distance_range, use_index}` and then `create_plan()`
+ * (table/query.rs:231-327).  The entry points below are what a Rust shim that
+ * replaces the `ANNIvfPartitionExec` / `ANNIvfSubIndexExec` / `KNNVectorDistance`
+ * plan nodes (named at table/query.rs:1079, python/python/lancedb/query.py:1369)
+ * would bind with `extern "C"`.  See INTEGRATION.md for that shim.
+ *
+ * Conventions
+ *   - every function returns an int32 status (0 = ok); no exception or abort
+ *     crosses the ABI.  Codes map onto lancedb::Error variants
+ *     (rust/lancedb/src/error.rs): 1 InvalidInput, 2 Runtime, 3 Timeout,
+ *     4 NotSupported.
+ *   - the caller owns every buffer it passes in or receives results in; the
+ *     library copies index data to the device at open and never frees caller
+ *     memory.  Handles are opaque and released only by *_close.
+ *   - plain pointers and sizes only: no torch / Arrow types.
+ *   - result contract (python/python/lancedb/query.py:1365-1370): per query up to
+ *     k rows sorted by (_distance ASC, _rowid ASC), NaN distances dropped,
+ *     distances restricted to [lower_bound, upper_bound)
+ *     (rust/lancedb/src/query.rs:1282-1288).  `_distance` is f32, `_rowid` u64
+ *     (rust/lancedb/src/query/hybrid.rs:95-100).
+ */
+#ifndef MI355_ANN_H
+#define MI355_ANN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ANN_ABI_VERSION 1u
+
+/* ---- status codes (rust/lancedb/src/error.rs:55-145) -------------------- */
+enum {
+  MI355_OK = 0,
+  MI355_ERR_INVALID_INPUT = 1, /* lancedb::Error::InvalidInput */
+  MI355_ERR_RUNTIME = 2,       /* lancedb::Error::Runtime (HIP failure text) */
+  MI355_ERR_TIMEOUT = 3,       /* lancedb::Error::Timeout */
+  MI355_ERR_NOT_SUPPORTED = 4  /* lancedb::Error::NotSupported */
+};
+
+/* ---- DistanceType (rust/lancedb/src/lib.rs:233-260) ---------------------- */
+enum {
+  MI355_METRIC_L2 = 0,     /* squared euclidean, [0, inf) */
+  MI355_METRIC_COSINE = 1, /* 1 - cos, [0, 2] */
+  MI355_METRIC_DOT = 2,    /* 1 - dot (lance_linalg dot_distance) */
+  MI355_METRIC_DEFAULT = 255 /* "not set": use the metric the index was trained with
+                                (VectorQueryRequest.distance_type = None) */
+};
+
+/* where the buffers named by a descriptor / call live */
+enum {
+  MI355_MEM_HOST = 0,
+  MI355_MEM_DEVICE = 1 /* pointers are device pointers on `device` */
+};
+
+/* element type of raw vector columns (utils/mod.rs:289-298: any float type) */
+enum {
+  MI355_DTYPE_F32 = 0,
+  MI355_DTYPE_BF16 = 1,
+  MI355_DTYPE_F16 = 2
+};
+
+/* layout of the PQ code block handed to mi355_index_open */
+enum {
+  /* [n_rows, m] u8, rows ordered by partition (partition p = rows
+     part_offsets[p] .. part_offsets[p+1]) */
+  MI355_CODES_ROW_MAJOR = 0,
+  /* per partition a [m, len_p] u8 block (sub-quantiser major), partitions
+     concatenated at byte offset m * part_offsets[p]: the transposed storage
+     lance-index keeps per partition ([EXT]) */
+  MI355_CODES_PART_TRANSPOSED = 1
+};
+
+typedef struct mi355_index mi355_index; /* IVF-PQ index resident on one GPU */
+typedef struct mi355_flat mi355_flat;   /* raw vector column resident on one GPU */
+
+/*
+ * Describes a trained IVF-PQ index.  Field meanings follow
+ * IvfPqIndexBuilder -> IvfBuildParams / PQBuildParams
+ * (rust/lancedb/src/index/vector.rs:266-319, table/create_index.rs:68-102,
+ * :283-303).
+ */
+typedef struct mi355_index_desc {
+  uint32_t struct_size; /* sizeof(mi355_index_desc), ABI guard */
+  uint32_t dim;         /* vector dimension */
+  uint32_t nlist;       /* IVF partitions (num_partitions) */
+  uint32_t m;           /* PQ sub-vectors (num_sub_vectors); dim % m == 0 */
+  uint32_t nbits;       /* PQ bits; 8 supported (4 -> NOT_SUPPORTED) */
+  uint32_t metric;      /* MI355_METRIC_* the index was trained with */
+  uint64_t n_rows;      /* rows covered by the index */
+  uint32_t mem;         /* MI355_MEM_*: where the pointers below live */
+  uint32_t codes_layout;/* MI355_CODES_* */
+  const float *centroids;       /* [nlist, dim] f32 */
+  const float *codebook;        /* [m, 2^nbits, dim/m] f32 */
+  const uint64_t *part_offsets; /* [nlist+1] row offsets, ALWAYS host memory */
+  const uint8_t *codes;         /* see codes_layout */
+  const uint64_t *row_ids;      /* [n_rows] _rowid per indexed row, in index order;
+                                   NULL = identity (row i has _rowid i) */
+  const void *raw_vectors;      /* optional [n_rows, dim] raw vectors in index
+                                   order (refine stage, query.rs:1302-1332);
+                                   NULL = refine unavailable */
+  uint32_t raw_dtype;           /* MI355_DTYPE_* of raw_vectors */
+  int32_t device;               /* HIP device ordinal */
+  /* Partition sharding over the GPUs of one node.  This
+     handle keeps the partitions a greedy bytes-balanced bin-packing assigns to
+     `shard_rank`; all other partitions are empty on this handle.  1/0 = no
+     sharding. */
+  uint32_t shard_count;
+  uint32_t shard_rank;
+} mi355_index_desc;
+
+/*
+ * Per-search parameters: the numeric subset of VectorQueryRequest +
+ * QueryRequest (rust/lancedb/src/query.rs:1066-1114, :818-907).
+ */
+typedef struct mi355_search_params {
+  uint32_t struct_size;   /* sizeof(mi355_search_params) */
+  uint32_t k;             /* limit + offset (table/query.rs:231) */
+  uint32_t nprobe_min;    /* minimum_nprobes (default 20) */
+  uint32_t nprobe_max;    /* maximum_nprobes; 0 = None = all partitions */
+  uint32_t refine_factor; /* 0 = not set; n>=1 fetches k*n candidates and
+                             re-ranks by true distance (query.rs:1313-1317) */
+  uint32_t metric;        /* MI355_METRIC_DEFAULT or must equal the index metric */
+  uint32_t has_lower_bound;
+  uint32_t has_upper_bound;
+  float lower_bound;      /* inclusive */
+  float upper_bound;      /* exclusive */
+  uint32_t io_mem;        /* MI355_MEM_*: where queries / outputs live.  DEVICE
+                             = enqueue on the handle's stream and return
+                             without waiting (see mi355_*_set_stream) */
+  uint32_t timeout_ms;    /* 0 = none (QueryExecutionOptions.timeout, query.rs:641) */
+} mi355_search_params;
+
+typedef struct mi355_flat_desc {
+  uint32_t struct_size;
+  uint32_t dim;
+  uint64_t n_rows;
+  uint32_t dtype;          /* MI355_DTYPE_* */
+  uint32_t mem;            /* MI355_MEM_* */
+  const void *vectors;     /* [n_rows, dim] */
+  const uint64_t *row_ids; /* [n_rows] or NULL = identity */
+  int32_t device;
+  uint32_t reserved;
+} mi355_flat_desc;
+
+/* analyze_plan-style counters (table/query.rs:105-112) for the last search */
+typedef struct mi355_stats {
+  uint32_t struct_size;
+  uint32_t n_queries;
+  uint64_t partitions_probed;  /* sum over queries */
+  uint64_t vectors_scanned;    /* sum over (query, partition) pairs */
+  uint64_t code_bytes_scanned; /* algorithmic bytes: m*nbits/8 per vector per query */
+  uint64_t work_items;         /* scan work items launched */
+  float us_coarse;             /* per-stage device time; 0 unless profiling on */
+  float us_select;
+  float us_plan;
+  float us_scan;
+  float us_merge;
+  float us_refine;
+  float us_total;
+  uint32_t scan_variant;       /* which ADC kernel ran (MI355_SCAN_*) */
+} mi355_stats;
+
+enum {
+  MI355_SCAN_AUTO = 0,
+  MI355_SCAN_PAIR = 1,   /* one work item per (query, partition slice), f32 LUT */
+  MI355_SCAN_GROUP4 = 2  /* partition-major, 4 queries share one code stream */
+};
+
+/* ---- library ------------------------------------------------------------ */
+uint32_t mi355_abi_version(void);
+/* number of visible gfx950 devices; 0 when none / no HIP runtime */
+int32_t mi355_device_count(int32_t *out_count);
+/* message of the last failing call on THIS thread (handle may be NULL) */
+int32_t mi355_last_error(char *buf, size_t buf_len);
+
+/* ---- IVF-PQ index lifecycle (replaces the lance Session index cache,
+ *      python/src/session.rs:49-50: upload once, reuse across queries) ----- */
+int32_t mi355_index_open(const mi355_index_desc *desc, mi355_index **out);
+int32_t mi355_index_close(mi355_index *index);
+/* run all later work of this handle on `hip_stream` (a hipStream_t); NULL
+   restores the handle's own stream */
+int32_t mi355_index_set_stream(mi355_index *index, void *hip_stream);
+int32_t mi355_index_sync(mi355_index *index);
+/* tuning knobs: MI355_SCAN_* variant, slice length (rows per scan work item,
+   0 = default), profile!=0 records per-stage times into mi355_stats */
+int32_t mi355_index_configure(mi355_index *index, uint32_t scan_variant,
+                              uint32_t slice_rows, uint32_t profile);
+/* rows kept on this handle and how many partitions are non-empty here */
+int32_t mi355_index_info(const mi355_index *index, uint64_t *out_rows,
+                         uint32_t *out_partitions_owned);
+
+/*
+ * IVF-PQ search — replaces ANNIvfPartitionExec + ANNIvfSubIndexExec + TopK
+ * (+ refine Take/KNNVectorDistance).  `queries` is [n_queries, dim] f32
+ * (Query::nearest_to always casts to Float32, query.rs:1011-1021).
+ * Outputs: out_rowids/out_dist are [n_queries, k]; row q holds out_counts[q]
+ * valid entries sorted by (distance, rowid); the tail is filled with
+ * UINT64_MAX / +inf.
+ */
+int32_t mi355_search(mi355_index *index, const float *queries,
+                     uint32_t n_queries, const mi355_search_params *params,
+                     uint64_t *out_rowids, float *out_dist,
+                     uint32_t *out_counts);
+int32_t mi355_last_stats(const mi355_index *index, mi355_stats *out);
+
+/* ---- flat (no index / bypass_vector_index, query.rs:1360-1370) ---------- */
+int32_t mi355_flat_open(const mi355_flat_desc *desc, mi355_flat **out);
+int32_t mi355_flat_close(mi355_flat *flat);
+int32_t mi355_flat_set_stream(mi355_flat *flat, void *hip_stream);
+int32_t mi355_flat_sync(mi355_flat *flat);
+/* Replaces KNNVectorDistance + SortExec TopK.  params->metric selects the
+   metric (DEFAULT = L2, lib.rs:236-243); nprobe / refine fields are ignored. */
+int32_t mi355_flat_search(mi355_flat *flat, const float *queries,
+                          uint32_t n_queries,
+                          const mi355_search_params *params,
+                          uint64_t *out_rowids, float *out_dist,
+                          uint32_t *out_counts);
+
+/*
+ * Merge n_lists candidate lists per query into one top-k (the reducer after
+ * the multi-GPU all-gather).  Inputs are DEVICE pointers laid
+ * out [n_lists, n_queries, k] (+ counts [n_lists, n_queries]); outputs are
+ * DEVICE [n_queries, k] / [n_queries].  Runs on `hip_stream` of `device`.
+ */
+int32_t mi355_merge_topk(int32_t device, void *hip_stream,
+                         const uint64_t *in_rowids, const float *in_dist,
+                         const uint32_t *in_counts, uint32_t n_lists,
+                         uint32_t n_queries, uint32_t k, uint64_t *out_rowids,
+                         float *out_dist, uint32_t *out_counts);
+
+/* Deterministic partition -> shard assignment used by mi355_index_open
+   (greedy: partitions by descending length, each to the least loaded shard;
+   ties to the lower shard id).  out_owner is [nlist]. */
+int32_t mi355_shard_plan(const uint64_t *part_offsets, uint32_t nlist,
+                         uint32_t shard_count, uint32_t *out_owner);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_ANN_H */

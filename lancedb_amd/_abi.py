@@ -1,0 +1,156 @@
+"""ctypes mirror of include/mi355_ann.h (struct layouts and constants only).
+
+This is the Python-side analogue of the binding a maintainer would add on the
+Rust side: field order and widths must match the header
+exactly; `struct_size` guards against drift at run time.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+OK = 0
+ERR_INVALID_INPUT = 1
+ERR_RUNTIME = 2
+ERR_TIMEOUT = 3
+ERR_NOT_SUPPORTED = 4
+
+METRIC_L2 = 0
+METRIC_COSINE = 1
+METRIC_DOT = 2
+METRIC_DEFAULT = 255
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+DTYPE_F32 = 0
+DTYPE_BF16 = 1
+DTYPE_F16 = 2
+
+CODES_ROW_MAJOR = 0
+CODES_PART_TRANSPOSED = 1
+
+SCAN_AUTO = 0
+SCAN_PAIR = 1
+SCAN_GROUP4 = 2
+
+UINT64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("dim", C.c_uint32),
+        ("nlist", C.c_uint32),
+        ("m", C.c_uint32),
+        ("nbits", C.c_uint32),
+        ("metric", C.c_uint32),
+        ("n_rows", C.c_uint64),
+        ("mem", C.c_uint32),
+        ("codes_layout", C.c_uint32),
+        ("centroids", C.c_void_p),
+        ("codebook", C.c_void_p),
+        ("part_offsets", C.c_void_p),
+        ("codes", C.c_void_p),
+        ("row_ids", C.c_void_p),
+        ("raw_vectors", C.c_void_p),
+        ("raw_dtype", C.c_uint32),
+        ("device", C.c_int32),
+        ("shard_count", C.c_uint32),
+        ("shard_rank", C.c_uint32),
+    ]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("k", C.c_uint32),
+        ("nprobe_min", C.c_uint32),
+        ("nprobe_max", C.c_uint32),
+        ("refine_factor", C.c_uint32),
+        ("metric", C.c_uint32),
+        ("has_lower_bound", C.c_uint32),
+        ("has_upper_bound", C.c_uint32),
+        ("lower_bound", C.c_float),
+        ("upper_bound", C.c_float),
+        ("io_mem", C.c_uint32),
+        ("timeout_ms", C.c_uint32),
+    ]
+
+
+class FlatDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("dim", C.c_uint32),
+        ("n_rows", C.c_uint64),
+        ("dtype", C.c_uint32),
+        ("mem", C.c_uint32),
+        ("vectors", C.c_void_p),
+        ("row_ids", C.c_void_p),
+        ("device", C.c_int32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_queries", C.c_uint32),
+        ("partitions_probed", C.c_uint64),
+        ("vectors_scanned", C.c_uint64),
+        ("code_bytes_scanned", C.c_uint64),
+        ("work_items", C.c_uint64),
+        ("us_coarse", C.c_float),
+        ("us_select", C.c_float),
+        ("us_plan", C.c_float),
+        ("us_scan", C.c_float),
+        ("us_merge", C.c_float),
+        ("us_refine", C.c_float),
+        ("us_total", C.c_float),
+        ("scan_variant", C.c_uint32),
+    ]
+
+
+# every symbol include/mi355_ann.h declares (tests check the .so exports all)
+EXPORTED_SYMBOLS = (
+    "mi355_abi_version",
+    "mi355_device_count",
+    "mi355_last_error",
+    "mi355_index_open",
+    "mi355_index_close",
+    "mi355_index_set_stream",
+    "mi355_index_sync",
+    "mi355_index_configure",
+    "mi355_index_info",
+    "mi355_search",
+    "mi355_last_stats",
+    "mi355_flat_open",
+    "mi355_flat_close",
+    "mi355_flat_set_stream",
+    "mi355_flat_sync",
+    "mi355_flat_search",
+    "mi355_merge_topk",
+    "mi355_shard_plan",
+)
+
+METRIC_NAMES = {"l2": METRIC_L2, "cosine": METRIC_COSINE, "dot": METRIC_DOT}
+
+
+def make_params(k=10, nprobe_min=20, nprobe_max=20, refine_factor=0,
+                metric=METRIC_DEFAULT, lower_bound=None, upper_bound=None,
+                io_mem=MEM_HOST, timeout_ms=0):
+    """Fill a SearchParams with VectorQueryRequest defaults
+    (rust/lancedb/src/query.rs:1097-1114: nprobes 20/20, k 10, no refine)."""
+    p = SearchParams()
+    p.struct_size = C.sizeof(SearchParams)
+    p.k = k
+    p.nprobe_min = nprobe_min
+    p.nprobe_max = 0 if nprobe_max is None else nprobe_max
+    p.refine_factor = refine_factor or 0
+    p.metric = metric
+    p.has_lower_bound = 0 if lower_bound is None else 1
+    p.has_upper_bound = 0 if upper_bound is None else 1
+    p.lower_bound = 0.0 if lower_bound is None else float(lower_bound)
+    p.upper_bound = 0.0 if upper_bound is None else float(upper_bound)
+    p.io_mem = io_mem
+    p.timeout_ms = timeout_ms
+    return p

@@ -1,0 +1,204 @@
+"""numpy front-end of the CPU oracle (oracle/ann_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+the cpu_baseline leg of bench.py.  Nothing under lancedb_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from lancedb_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "ann_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "mi355_ann.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True,
+                   stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_chain_dot.restype = C.c_float
+        L.orc_chain_l2.restype = C.c_float
+        L.orc_exact_distance.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleIndex:
+    """IVF-PQ index on the host; arrays follow mi355_index_desc."""
+
+    def __init__(self, centroids, codebook, part_offsets, codes, row_ids=None,
+                 raw_vectors=None, metric="l2", codes_layout=_abi.CODES_ROW_MAJOR,
+                 raw_dtype=_abi.DTYPE_F32):
+        self.centroids = _f32(centroids)
+        self.codebook = _f32(codebook)
+        self.part_offsets = np.ascontiguousarray(part_offsets, dtype=np.uint64)
+        self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        self.row_ids = None if row_ids is None else np.ascontiguousarray(row_ids, dtype=np.uint64)
+        self.raw = None if raw_vectors is None else np.ascontiguousarray(raw_vectors)
+        self.nlist, self.dim = self.centroids.shape
+        self.m = self.codebook.shape[0]
+        self.metric = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else metric
+        d = _abi.IndexDesc()
+        d.struct_size = C.sizeof(_abi.IndexDesc)
+        d.dim, d.nlist, d.m, d.nbits = self.dim, self.nlist, self.m, 8
+        d.metric = self.metric
+        d.n_rows = int(self.part_offsets[-1])
+        d.mem = _abi.MEM_HOST
+        d.codes_layout = codes_layout
+        d.centroids = _ptr(self.centroids)
+        d.codebook = _ptr(self.codebook)
+        d.part_offsets = _ptr(self.part_offsets)
+        d.codes = _ptr(self.codes)
+        d.row_ids = _ptr(self.row_ids)
+        d.raw_vectors = _ptr(self.raw)
+        d.raw_dtype = raw_dtype
+        d.device = 0
+        d.shard_count, d.shard_rank = 1, 0
+        self.desc = d
+        self.n_rows = d.n_rows
+        h = C.c_void_p()
+        st = lib().orc_index_open(C.byref(d), C.byref(h))
+        if st != 0:
+            raise ValueError(f"orc_index_open failed with status {st}")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().orc_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, queries, params=None, nthreads=0, **kw):
+        """-> (rowids [nq,k] u64, dist [nq,k] f32, counts [nq] u32, status)."""
+        p = params if params is not None else _abi.make_params(**kw)
+        q = _f32(queries).reshape(-1, self.dim)
+        nq, k = q.shape[0], p.k
+        ids = np.empty((nq, k), dtype=np.uint64)
+        dist = np.empty((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        scanned = C.c_uint64(0)
+        st = lib().orc_search(self._h, _ptr(q), C.c_uint32(nq), C.byref(p), _ptr(ids),
+                              _ptr(dist), _ptr(cnt), C.c_int32(nthreads), C.byref(scanned))
+        self.last_vectors_scanned = scanned.value
+        return ids, dist, cnt, st
+
+    # stage-wise entry points for kernel-level parity tests ------------------
+    def preprocess(self, q):
+        q = _f32(q)
+        if self.metric == _abi.METRIC_COSINE:
+            nrm = np.float32(np.sqrt(np.float32(chain_dot(q, q))))
+            return (q / nrm).astype(np.float32)
+        return q
+
+    def coarse(self, q):
+        q = self.preprocess(q)
+        out = np.empty(self.nlist, dtype=np.float32)
+        lib().orc_coarse(self._h, _ptr(q), _ptr(out))
+        return out
+
+    def select_probes(self, coarse, nprobe):
+        coarse = _f32(coarse)
+        out = np.empty(nprobe, dtype=np.uint32)
+        lib().orc_select_probes(_ptr(coarse), C.c_uint32(self.nlist), C.c_uint32(nprobe), _ptr(out))
+        return out
+
+    def build_lut(self, q, part):
+        q = self.preprocess(q)
+        out = np.empty((self.m, 256), dtype=np.float32)
+        lib().orc_build_lut(self._h, _ptr(q), C.c_uint32(part), _ptr(out))
+        return out
+
+    def adc_partition(self, lut, part):
+        lut = _f32(lut)
+        n = int(self.part_offsets[part + 1] - self.part_offsets[part])
+        out = np.empty(max(n, 1), dtype=np.float32)
+        lib().orc_adc_partition(self._h, _ptr(lut), C.c_uint32(part), _ptr(out))
+        return out[:n]
+
+
+def chain_dot(a, b):
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc_chain_dot(_ptr(a), _ptr(b), C.c_uint32(a.size)))
+
+
+def chain_l2(a, b):
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc_chain_l2(_ptr(a), _ptr(b), C.c_uint32(a.size)))
+
+
+def flat_search(vectors, queries, params=None, row_ids=None, dtype=_abi.DTYPE_F32,
+                nthreads=0, **kw):
+    """Flat KNN.  `vectors` is [n, dim]: f32, or uint16 holding bf16/f16 bits."""
+    p = params if params is not None else _abi.make_params(**kw)
+    v = np.ascontiguousarray(vectors)
+    if dtype == _abi.DTYPE_F32:
+        v = _f32(v)
+    else:
+        assert v.dtype == np.uint16
+    n, dim = v.shape
+    rid = None if row_ids is None else np.ascontiguousarray(row_ids, dtype=np.uint64)
+    fd = _abi.FlatDesc()
+    fd.struct_size = C.sizeof(_abi.FlatDesc)
+    fd.dim, fd.n_rows, fd.dtype, fd.mem = dim, n, dtype, _abi.MEM_HOST
+    fd.vectors, fd.row_ids, fd.device = _ptr(v), _ptr(rid), 0
+    q = _f32(queries).reshape(-1, dim)
+    nq, k = q.shape[0], p.k
+    ids = np.empty((nq, k), dtype=np.uint64)
+    dist = np.empty((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    st = lib().orc_flat_search(C.byref(fd), _ptr(q), C.c_uint32(nq), C.byref(p), _ptr(ids),
+                               _ptr(dist), _ptr(cnt), C.c_int32(nthreads))
+    return ids, dist, cnt, st
+
+
+def merge_topk(in_ids, in_dist, in_counts, k):
+    in_ids = np.ascontiguousarray(in_ids, dtype=np.uint64)
+    in_dist = _f32(in_dist)
+    in_counts = np.ascontiguousarray(in_counts, dtype=np.uint32)
+    n_lists, nq = in_counts.shape
+    ids = np.empty((nq, k), dtype=np.uint64)
+    dist = np.empty((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    lib().orc_merge_topk(_ptr(in_ids), _ptr(in_dist), _ptr(in_counts), C.c_uint32(n_lists),
+                         C.c_uint32(nq), C.c_uint32(k), _ptr(ids), _ptr(dist), _ptr(cnt))
+    return ids, dist, cnt
+
+
+def shard_plan(part_offsets, shard_count):
+    po = np.ascontiguousarray(part_offsets, dtype=np.uint64)
+    nlist = po.size - 1
+    out = np.empty(nlist, dtype=np.uint32)
+    st = lib().orc_shard_plan(_ptr(po), C.c_uint32(nlist), C.c_uint32(shard_count), _ptr(out))
+    assert st == 0
+    return out

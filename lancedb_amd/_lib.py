@@ -1,0 +1,108 @@
+"""Loader / builder of the native engine (libmi355_ann.so).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is
+visible, every search call raises.  The library is built in-tree with hipcc
+(cross-compiles without a GPU) so it travels with the repository snapshot.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libmi355_ann.so")
+_SOURCES = [os.path.join(_PKG, "csrc", f) for f in
+            ("mi355_ann.hip", "kernels_ivfpq.h", "kernels_flat.h", "kernels_group.h", "device_common.h")]
+_HEADER = os.path.join(ROOT, "include", "mi355_ann.h")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+               "-shared", "-Wall", "-Wno-unused-function"]
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """Mirrors lancedb::Error variants (rust/lancedb/src/error.rs:55-145)."""
+
+    def __init__(self, status, message):
+        self.status = status
+        name = {1: "InvalidInput", 2: "Runtime", 3: "Timeout", 4: "NotSupported"}.get(status, str(status))
+        super().__init__(f"{name}: {message}")
+
+
+class InvalidInput(EngineError, ValueError):
+    pass
+
+
+class NotSupported(EngineError):
+    pass
+
+
+class QueryTimeout(EngineError, TimeoutError):
+    pass
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in _SOURCES + [_HEADER])
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 the C-ABI library in-tree."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + [_SOURCES[0], "-o", LIB_PATH]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed building libmi355_ann.so:\n" + r.stdout[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built (never falls
+    back to anything else)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  The MI355X engine has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.mi355_abi_version.restype = C.c_uint32
+        for name in _abi.EXPORTED_SYMBOLS:
+            if name != "mi355_abi_version":
+                getattr(L, name).restype = C.c_int32
+        if L.mi355_abi_version() != _abi.ABI_VERSION:
+            raise ImportError("libmi355_ann.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(1024)
+    lib().mi355_last_error(buf, C.c_size_t(1024))
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status):
+    if status == _abi.OK:
+        return
+    msg = last_error()
+    cls = {_abi.ERR_INVALID_INPUT: InvalidInput, _abi.ERR_NOT_SUPPORTED: NotSupported,
+           _abi.ERR_TIMEOUT: QueryTimeout}.get(status, EngineError)
+    raise cls(status, msg)
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(lib().mi355_device_count(C.byref(n)))
+    return n.value

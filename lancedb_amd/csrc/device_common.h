@@ -1,0 +1,258 @@
+// device_common.h — shared device helpers for the gfx950 ANN kernels.
+//
+// Arithmetic contract (oracle/ann_oracle.c header): every distance
+// is a d-ascending f32 fma chain; this TU is compiled with -ffp-contract=off so
+// only the explicit __fmaf_rn calls fuse.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi355_ann.h"
+
+#define MI355_WAVE 64
+
+struct Cand {  // 16 B candidate record kept between scan -> merge -> refine
+  float d;       // final (metric-adjusted) distance
+  uint32_t pos;  // local row position on this handle; 0xFFFFFFFF = empty slot
+  uint64_t id;   // _rowid
+};
+
+#define CAND_EMPTY_POS 0xFFFFFFFFu
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
+  _Float16 x;
+  __builtin_memcpy(&x, &h, 2);
+  return (float)x;  // exact widening
+}
+
+__device__ __forceinline__ float load_elem(const void* base, uint32_t dtype, uint64_t i) {
+  if (dtype == MI355_DTYPE_F32) return ((const float*)base)[i];
+  if (dtype == MI355_DTYPE_BF16) return bf16_bits_to_f32(((const uint16_t*)base)[i]);
+  return f16_bits_to_f32(((const uint16_t*)base)[i]);
+}
+
+// total order on (distance, rowid): python/python/lancedb/query.py:1368
+__device__ __forceinline__ bool key_less(float d1, uint32_t hi1, uint32_t lo1, float d2,
+                                         uint32_t hi2, uint32_t lo2) {
+  if (d1 < d2) return true;
+  if (d1 > d2) return false;
+  if (hi1 != hi2) return hi1 < hi2;
+  return lo1 < lo2;
+}
+
+// distance_range [lower, upper) (rust/lancedb/src/query.rs:1282-1288); NaN = NULL -> dropped
+struct RangeFilter {
+  uint32_t has_lower, has_upper;
+  float lower, upper;
+};
+
+__device__ __forceinline__ bool in_range(float d, const RangeFilter& r) {
+  if (d != d) return false;
+  if (r.has_lower && !(d >= r.lower)) return false;
+  if (r.has_upper && !(d < r.upper)) return false;
+  return true;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// ---------------------------------------------------------------------------
+// K4: wave-level top-kk reducer ("replace the worst").  The kk best keys seen
+// so far live unsorted in registers, KPL per lane (slot g = s*64 + lane < kk);
+// the current worst kept key is tracked wave-uniformly and is the admission
+// threshold.  A candidate is admitted iff key < worst, so the kept set is
+// always the exact kk smallest by (distance, rowid).  Expected admissions for n
+// random keys are ~kk*ln(n/kk): the hot loop only pays one compare per row.
+// ---------------------------------------------------------------------------
+template <int KPL>
+struct WaveTopK {
+  float d[KPL];
+  uint32_t pos[KPL], lo[KPL], hi[KPL];
+  float thr_d;  // worst kept key (wave-uniform)
+  uint32_t thr_lo, thr_hi;
+  int thr_lane, thr_slot;
+  uint32_t kk;
+
+  __device__ __forceinline__ void init(uint32_t kk_, int lane) {
+    kk = kk_;
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) {
+      d[s] = __builtin_huge_valf();
+      pos[s] = CAND_EMPTY_POS;
+      lo[s] = 0xFFFFFFFFu;
+      hi[s] = 0xFFFFFFFFu;
+    }
+    recompute(lane);
+  }
+
+  // find the worst enabled slot across the wave (ties: lowest lane, lowest slot)
+  __device__ __forceinline__ void recompute(int lane) {
+    float bd = 0.f;
+    uint32_t blo = 0, bhi = 0;
+    int bs = 0, bv = 0, bl = lane;
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) {
+      bool en = (uint32_t)(s * MI355_WAVE + lane) < kk;
+      if (en && (!bv || key_less(bd, bhi, blo, d[s], hi[s], lo[s]))) {
+        bd = d[s];
+        blo = lo[s];
+        bhi = hi[s];
+        bs = s;
+        bv = 1;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float od = __shfl_xor(bd, off);
+      uint32_t olo = __shfl_xor(blo, off), ohi = __shfl_xor(bhi, off);
+      int os = __shfl_xor(bs, off), ov = __shfl_xor(bv, off), ol = __shfl_xor(bl, off);
+      bool take;
+      if (!ov)
+        take = false;
+      else if (!bv)
+        take = true;
+      else if (key_less(bd, bhi, blo, od, ohi, olo))
+        take = true;
+      else if (key_less(od, ohi, olo, bd, bhi, blo))
+        take = false;
+      else
+        take = (ol < bl) || (ol == bl && os < bs);
+      if (take) {
+        bd = od;
+        blo = olo;
+        bhi = ohi;
+        bs = os;
+        bv = ov;
+        bl = ol;
+      }
+    }
+    thr_d = bd;
+    thr_lo = blo;
+    thr_hi = bhi;
+    thr_lane = bl;
+    thr_slot = bs;
+  }
+
+  // all arguments wave-uniform
+  __device__ __forceinline__ void insert_uniform(float cd, uint32_t cpos, uint32_t clo,
+                                                 uint32_t chi, int lane) {
+    if (!key_less(cd, chi, clo, thr_d, thr_hi, thr_lo)) return;
+    if (lane == thr_lane) {
+#pragma unroll
+      for (int s = 0; s < KPL; ++s)
+        if (s == thr_slot) {
+          d[s] = cd;
+          pos[s] = cpos;
+          lo[s] = clo;
+          hi[s] = chi;
+        }
+    }
+    recompute(lane);
+  }
+
+  // Each lane offers (at most) one candidate; `valid` lanes whose distance can
+  // still beat the threshold are drained one by one.
+  __device__ __forceinline__ void offer(bool valid, float cd, uint32_t cpos, uint64_t cid,
+                                        int lane) {
+    uint64_t mask = __ballot(valid && cd <= thr_d);
+    uint32_t clo = (uint32_t)cid, chi = (uint32_t)(cid >> 32);
+    while (mask) {
+      int l = __ffsll((unsigned long long)mask) - 1;
+      mask &= mask - 1;
+      insert_uniform(readlane_f(cd, l), readlane_u(cpos, l), readlane_u(clo, l),
+                     readlane_u(chi, l), lane);
+    }
+  }
+
+  // dump the kept keys (unsorted) to out[0..kk)
+  __device__ __forceinline__ void store(Cand* out, int lane) const {
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) {
+      uint32_t g = (uint32_t)(s * MI355_WAVE + lane);
+      if (g < kk) {
+        Cand c;
+        c.d = d[s];
+        c.pos = pos[s];
+        c.id = ((uint64_t)hi[s] << 32) | lo[s];
+        out[g] = c;
+      }
+    }
+  }
+
+  // Emit the kept keys in ascending (distance, rowid) order: rank r goes to
+  // emit(r, d, pos, id) on the owning lane.  Returns the number of real rows.
+  template <typename F>
+  __device__ __forceinline__ uint32_t drain_sorted(int lane, F emit) {
+    uint32_t taken = 0;  // per-lane bitmask of emitted slots
+    uint32_t n = 0;
+    for (uint32_t r = 0; r < kk; ++r) {
+      float bd = 0.f;
+      uint32_t blo = 0, bhi = 0;
+      int bs = 0, bv = 0, bl = lane;
+#pragma unroll
+      for (int s = 0; s < KPL; ++s) {
+        bool en = (uint32_t)(s * MI355_WAVE + lane) < kk && !((taken >> s) & 1u) &&
+                  pos[s] != CAND_EMPTY_POS;
+        if (en && (!bv || key_less(d[s], hi[s], lo[s], bd, bhi, blo))) {
+          bd = d[s];
+          blo = lo[s];
+          bhi = hi[s];
+          bs = s;
+          bv = 1;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        float od = __shfl_xor(bd, off);
+        uint32_t olo = __shfl_xor(blo, off), ohi = __shfl_xor(bhi, off);
+        int os = __shfl_xor(bs, off), ov = __shfl_xor(bv, off), ol = __shfl_xor(bl, off);
+        bool take;
+        if (!ov)
+          take = false;
+        else if (!bv)
+          take = true;
+        else if (key_less(od, ohi, olo, bd, bhi, blo))
+          take = true;
+        else if (key_less(bd, bhi, blo, od, ohi, olo))
+          take = false;
+        else
+          take = (ol < bl) || (ol == bl && os < bs);
+        if (take) {
+          bd = od;
+          blo = olo;
+          bhi = ohi;
+          bs = os;
+          bv = ov;
+          bl = ol;
+        }
+      }
+      if (!bv) break;  // wave-uniform: nothing left
+      if (lane == bl) {
+#pragma unroll
+        for (int s = 0; s < KPL; ++s)
+          if (s == bs) {
+            emit(r, d[s], pos[s], ((uint64_t)hi[s] << 32) | lo[s]);
+            taken |= 1u << s;
+          }
+      }
+      ++n;
+    }
+    return n;
+  }
+};
+
+// order-preserving u32 key of an f32 (NaN last; -0 == +0)
+__device__ __forceinline__ uint32_t f32_sort_key(float d) {
+  if (d != d) return 0xFFFFFFFFu;
+  d = d + 0.0f;  // -0 -> +0 (not foldable under IEEE)
+  uint32_t u = __float_as_uint(d);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}

@@ -1,0 +1,621 @@
+// kernels_ivfpq.h — gfx950 kernels of the IVF-PQ search path.
+//
+//   K0 prep_queries     cosine normalisation + |q|^2            (per query)
+//   K1 coarse_tile      q x centroid fma chains -> coarse dist  (E2, table/query.rs:1079)
+//   K1b select_probes   radix-select the nprobe nearest partitions
+//   K2+K3+K4 scan_pair  LUT build in LDS + ADC scan + wave top-k (E3/E5/E6)
+//   K4 merge_cands      per-query reducer over all scan work items (E8)
+//   K6 refine           exact re-rank on raw vectors             (E9)
+//
+// Reference behaviour restated in oracle/ann_oracle.c; every kernel is parity
+// tested against it bit for bit (tests/test_gpu_parity.py).
+#pragma once
+#include "device_common.h"
+
+// ---------------------------------------------------------------------------
+// device view of an opened index
+// ---------------------------------------------------------------------------
+struct IndexView {
+  uint32_t dim, nlist, m, dsub, metric;
+  const float* centroids;     // [nlist, dim]
+  const float* cnorm;         // [nlist] chain_dot(c,c)
+  const float* codebook;      // [m, 256, dsub]
+  const uint8_t* codes;       // partition p: [m, pstride[p]] block at code_off[p]
+  const uint64_t* code_off;   // [nlist] byte offset of the partition block
+  const uint32_t* plen;       // [nlist] rows of p kept on this handle (0 = not owned / empty)
+  const uint32_t* pstride;    // [nlist] plen rounded up to 16
+  const uint32_t* lrow0;      // [nlist] local row position of the partition's first row
+  const uint64_t* grow0;      // [nlist] global index position of the partition's first row
+  const uint64_t* row_ids;    // [n_local] or nullptr (identity: rowid = global position)
+  const void* raw;            // [n_local, dim] or nullptr
+  uint32_t raw_dtype;
+};
+
+// ------------------------------------------------------------------ K0 -----
+// One thread per query: sequential chains (768 fmas) — B is small, this is noise.
+__global__ void k_prep_queries(const float* __restrict__ q, uint32_t nq, uint32_t dim,
+                               uint32_t metric, float* __restrict__ qp,
+                               float* __restrict__ qq) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nq) return;
+  const float* src = q + (size_t)b * dim;
+  float* dst = qp + (size_t)b * dim;
+  float acc = 0.f;
+  for (uint32_t d = 0; d < dim; ++d) acc = __fmaf_rn(src[d], src[d], acc);
+  if (metric == MI355_METRIC_COSINE) {
+    float nrm = __fsqrt_rn(acc);
+    float acc2 = 0.f;
+    for (uint32_t d = 0; d < dim; ++d) {
+      float v = __fdiv_rn(src[d], nrm);
+      dst[d] = v;
+      acc2 = __fmaf_rn(v, v, acc2);
+    }
+    qq[b] = acc2;
+  } else {
+    for (uint32_t d = 0; d < dim; ++d) dst[d] = src[d];
+    qq[b] = acc;
+  }
+}
+
+__global__ void k_centroid_norms(const float* __restrict__ c, uint32_t nlist, uint32_t dim,
+                                 float* __restrict__ cn) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nlist) return;
+  const float* src = c + (size_t)p * dim;
+  float acc = 0.f;
+  for (uint32_t d = 0; d < dim; ++d) acc = __fmaf_rn(src[d], src[d], acc);
+  cn[p] = acc;
+}
+
+// ------------------------------------------------------------------ K1 -----
+// Register-tiled f32 "GEMM" whose every accumulator is the d-ascending fma
+// chain of the contract.  64 queries x 64 centroids per 256-thread block,
+// 4x4 per thread, K staged 16 at a time through LDS (zero padding is exact:
+// fma(0,0,acc) == acc for the +0-started chain).
+#define CO_T 64
+#define CO_K 16
+__global__ __launch_bounds__(256) void k_coarse_tile(
+    const float* __restrict__ qp, const float* __restrict__ qq, uint32_t nq,
+    const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist, uint32_t dim,
+    uint32_t metric, float* __restrict__ out /*[nq, nlist]*/) {
+  __shared__ float sq[CO_K][CO_T + 4];
+  __shared__ float sc[CO_K][CO_T + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const uint32_t q0 = blockIdx.y * CO_T, c0 = blockIdx.x * CO_T;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (uint32_t k0 = 0; k0 < dim; k0 += CO_K) {
+    // 64 rows x 16 k per operand = 1024 elements, 4 per thread
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int idx = tid + e * 256;
+      int r = idx >> 4, kk = idx & 15;
+      uint32_t k = k0 + kk;
+      float vq = 0.f, vc = 0.f;
+      if (k < dim) {
+        if (q0 + r < nq) vq = qp[(size_t)(q0 + r) * dim + k];
+        if (c0 + r < nlist) vc = cen[(size_t)(c0 + r) * dim + k];
+      }
+      sq[kk][r] = vq;
+      sc[kk][r] = vc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < CO_K; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sq[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = sc[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t qi = q0 + ty * 4 + i;
+    if (qi >= nq) continue;
+    float qn = qq[qi];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t ci = c0 + tx * 4 + j;
+      if (ci >= nlist) continue;
+      float v;
+      if (metric == MI355_METRIC_DOT)
+        v = 1.0f - acc[i][j];
+      else
+        v = __fmaf_rn(-2.0f, acc[i][j], qn + cn[ci]);
+      out[(size_t)qi * nlist + ci] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K1b ----
+// One 256-thread block per query: 4-pass byte radix select of the nprobe-th
+// smallest coarse key, then emit {key < T} (any order) followed by the
+// lowest-id {key == T} rows.  Works for any nlist (C4: 65536).  Also adds the
+// query's probed rows to the stats counters.
+__global__ __launch_bounds__(256) void k_select_probes(
+    const float* __restrict__ coarse, uint32_t nlist, uint32_t nprobe,
+    const uint32_t* __restrict__ plen, uint32_t* __restrict__ probes /*[nq, nprobe]*/,
+    unsigned long long* __restrict__ stat_rows) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_prefix, s_need, s_less, s_wave_cnt[4], s_running;
+  __shared__ unsigned long long s_rows;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  const float* src = coarse + (size_t)b * nlist;
+  uint32_t* out = probes + (size_t)b * nprobe;
+  if (tid == 0) {
+    s_prefix = 0;
+    s_need = nprobe;
+    s_less = 0;
+    s_running = 0;
+    s_rows = 0;
+  }
+  uint32_t mask = 0;
+  for (int byte = 3; byte >= 0; --byte) {
+    hist[tid] = 0;
+    __syncthreads();
+    uint32_t prefix = s_prefix;
+    for (uint32_t p = tid; p < nlist; p += 256) {
+      uint32_t key = f32_sort_key(src[p]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * byte)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t need = s_need, cum = 0, bin = 0;
+      for (bin = 0; bin < 256; ++bin) {
+        if (cum + hist[bin] >= need) break;
+        cum += hist[bin];
+      }
+      s_need = need - cum;
+      s_prefix = prefix | (bin << (8 * byte));
+    }
+    mask |= 255u << (8 * byte);
+    __syncthreads();
+  }
+  const uint32_t T = s_prefix;
+  const uint32_t need_eq = s_need;           // rows with key == T to take (>= 1)
+  const uint32_t n_less = nprobe - need_eq;  // rows with key < T
+  unsigned long long rows = 0;
+  for (uint32_t p0 = 0; p0 < nlist; p0 += 256) {
+    uint32_t p = p0 + tid;
+    uint32_t key = p < nlist ? f32_sort_key(src[p]) : 0xFFFFFFFFu;
+    bool less = p < nlist && key < T;
+    bool eq = p < nlist && key == T;
+    if (less) {
+      out[atomicAdd(&s_less, 1u)] = p;
+      rows += plen[p];
+    }
+    // ordered rank among the equal keys (ascending partition id)
+    uint64_t bal = __ballot(eq);
+    if (lane == 0) s_wave_cnt[wid] = (uint32_t)__popcll((unsigned long long)bal);
+    __syncthreads();
+    uint32_t base = s_running;
+    for (int w = 0; w < wid; ++w) base += s_wave_cnt[w];
+    uint32_t rank = base + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
+    if (eq && rank < need_eq) {
+      out[n_less + rank] = p;
+      rows += plen[p];
+    }
+    __syncthreads();
+    if (tid == 0) s_running = base + s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    __syncthreads();
+  }
+  if (rows) atomicAdd(&s_rows, rows);
+  __syncthreads();
+  if (tid == 0 && stat_rows) atomicAdd(stat_rows, s_rows);
+}
+
+// ------------------------------------------------------------ K2+K3+K4 -----
+// SCAN_PAIR: one workgroup per (query, probe rank, slice of the partition).
+//   1. residual r = q - c_p and the m x 256 f32 distance table, built straight
+//      into LDS (never touches HBM);  LDS = m KiB + dim*4 B  (96 KiB + 3 KiB at C3)
+//   2. ADC: each thread streams VPT consecutive rows per sub-quantiser row
+//      (codes are sub-quantiser-major, so a wave reads VPT*64 contiguous bytes
+//      per row: 1 KiB at VPT=16), gathers LUT[j][code] with ds_read_b32 and
+//      accumulates j ascending with plain f32 adds (the contract's order)
+//   3. per-wave exact top-kk (WaveTopK), merged across the block's waves
+//      through the (now dead) LUT area, kk candidates per work item to HBM.
+template <int VPT>
+struct CodeVec;
+template <>
+struct CodeVec<4> {
+  typedef uint32_t type;
+};
+template <>
+struct CodeVec<16> {
+  typedef uint4 type;
+};
+
+template <int VPT>
+__device__ __forceinline__ uint32_t code_byte(const typename CodeVec<VPT>::type& v, int e);
+template <>
+__device__ __forceinline__ uint32_t code_byte<4>(const uint32_t& v, int e) {
+  return (v >> (8 * e)) & 255u;
+}
+template <>
+__device__ __forceinline__ uint32_t code_byte<16>(const uint4& v, int e) {
+  uint32_t w = e < 4 ? v.x : e < 8 ? v.y : e < 12 ? v.z : v.w;
+  return (w >> (8 * (e & 3))) & 255u;
+}
+
+struct ScanArgs {
+  IndexView ix;
+  const float* qp;          // [nq, dim] preprocessed queries
+  const uint32_t* probes;   // [nq, nprobe]
+  uint32_t nprobe;
+  uint32_t slice_rows;      // rows per work item (multiple of 16)
+  uint32_t n_slices;        // grid.x
+  uint32_t kk;
+  RangeFilter range;
+  Cand* cand;               // [nq, nprobe, n_slices, kk]
+};
+
+__device__ __forceinline__ float finalize_dist(float acc, uint32_t metric, uint32_t m) {
+  if (metric == MI355_METRIC_COSINE) return acc * 0.5f;
+  if (metric == MI355_METRIC_DOT) return acc - (float)(m - 1);
+  return acc;
+}
+
+template <int VPT, int KPL, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = NTHREADS / MI355_WAVE;
+  const IndexView& ix = a.ix;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t s = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+  Cand* out = a.cand + (((size_t)b * a.nprobe + r) * a.n_slices + s) * a.kk;
+  const uint32_t p = a.probes[(size_t)b * a.nprobe + r];
+  const uint32_t len = ix.plen[p];
+  const uint32_t v0 = s * a.slice_rows;
+  if (v0 >= len) {  // nothing here: mark the slot empty
+    for (uint32_t g = tid; g < a.kk; g += NTHREADS) {
+      Cand c;
+      c.d = __builtin_huge_valf();
+      c.pos = CAND_EMPTY_POS;
+      c.id = ~0ull;
+      out[g] = c;
+    }
+    return;
+  }
+  const uint32_t v1 = min(len, v0 + a.slice_rows);
+  float* lut = (float*)smem;                       // [m][256]
+  float* res = (float*)(smem + (size_t)ix.m * 1024);  // [dim]
+  const float* q = a.qp + (size_t)b * ix.dim;
+
+  // ---- K2: residual + distance table -------------------------------------
+  if (ix.metric == MI355_METRIC_DOT) {
+    for (uint32_t d = tid; d < ix.dim; d += NTHREADS) res[d] = q[d];
+  } else {
+    const float* c = ix.centroids + (size_t)p * ix.dim;
+    for (uint32_t d = tid; d < ix.dim; d += NTHREADS) res[d] = q[d] - c[d];
+  }
+  __syncthreads();
+  {
+    const uint32_t dsub = ix.dsub;
+    for (uint32_t e = tid; e < ix.m * 256u; e += NTHREADS) {
+      const uint32_t j = e >> 8;
+      const float* cb = ix.codebook + (size_t)e * dsub;  // [j][c][*], coalesced over c
+      const float* rj = res + j * dsub;
+      float acc = 0.f;
+      if (ix.metric == MI355_METRIC_DOT) {
+        for (uint32_t t = 0; t < dsub; ++t) acc = __fmaf_rn(rj[t], cb[t], acc);
+        acc = 1.0f - acc;
+      } else {
+        for (uint32_t t = 0; t < dsub; ++t) {
+          float df = rj[t] - cb[t];
+          acc = __fmaf_rn(df, df, acc);
+        }
+      }
+      lut[e] = acc;
+    }
+  }
+  __syncthreads();
+
+  // ---- K3: ADC scan + K4 wave top-k ---------------------------------------
+  WaveTopK<KPL> top;
+  top.init(a.kk, lane);
+  const uint8_t* codes = ix.codes + ix.code_off[p];
+  const uint32_t stride = ix.pstride[p];
+  const uint32_t lrow0 = ix.lrow0[p];
+  const uint64_t grow0 = ix.grow0[p];
+  typedef typename CodeVec<VPT>::type cvec;
+
+  for (uint32_t i0 = v0 + tid * VPT; i0 < v1; i0 += NTHREADS * VPT) {
+    float acc[VPT];
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) acc[e] = 0.f;
+    const uint8_t* col = codes + i0;
+#pragma unroll 8
+    for (uint32_t j = 0; j < ix.m; ++j) {
+      cvec cv = *(const cvec*)(col + (size_t)j * stride);
+      const float* t = lut + j * 256;
+#pragma unroll
+      for (int e = 0; e < VPT; ++e) acc[e] = acc[e] + t[code_byte<VPT>(cv, e)];
+    }
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < VPT; ++e) {
+      acc[e] = finalize_dist(acc[e], ix.metric, ix.m);
+      any |= acc[e] <= top.thr_d;
+    }
+    if (__any(any)) {
+#pragma unroll
+      for (int e = 0; e < VPT; ++e) {
+        uint32_t i = i0 + e;
+        bool ok = i < v1 && acc[e] <= top.thr_d && in_range(acc[e], a.range);
+        if (__any(ok)) {
+          uint64_t id = 0;
+          if (ok) id = ix.row_ids ? ix.row_ids[lrow0 + i] : grow0 + i;
+          top.offer(ok, acc[e], lrow0 + i, id, lane);
+        }
+      }
+    }
+  }
+
+  // ---- merge the block's waves through the dead LUT area ------------------
+  __syncthreads();
+  Cand* stage = (Cand*)smem;  // [NW][kk]
+  top.store(stage + (size_t)wid * a.kk, lane);
+  __syncthreads();
+  if (wid == 0) {
+    const uint32_t n = (NW - 1) * a.kk;
+    for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
+      uint32_t t = t0 + lane;
+      Cand c;
+      c.d = 0.f;
+      c.pos = CAND_EMPTY_POS;
+      c.id = 0;
+      if (t < n) c = stage[a.kk + t];
+      top.offer(t < n && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
+    }
+    top.store(out, lane);
+  }
+}
+
+// ------------------------------------------------------------------ K4 -----
+// Per-query reducer: one wave scans the query's n_src*kk candidate slots and
+// writes the k_out best in (distance, rowid) order.
+struct MergeArgs {
+  const Cand* cand;   // [nq, n_src, kk_in]
+  uint32_t n_src, kk_in;
+  uint32_t k_out;     // rows written per query (k, or k*refine_factor)
+  uint64_t* out_ids;  // [nq, k_out]
+  float* out_dist;    // [nq, k_out]
+  uint32_t* out_pos;  // [nq, k_out] or nullptr
+  uint32_t* out_cnt;  // [nq]
+};
+
+template <int KPL>
+__global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  WaveTopK<KPL> top;
+  top.init(a.k_out, lane);
+  const Cand* src = a.cand + (size_t)b * a.n_src * a.kk_in;
+  const uint32_t n = a.n_src * a.kk_in;
+  for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
+    uint32_t t = t0 + lane;
+    Cand c;
+    c.d = 0.f;
+    c.pos = CAND_EMPTY_POS;
+    c.id = 0;
+    if (t < n) c = src[t];
+    top.offer(t < n && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
+  }
+  uint64_t* oi = a.out_ids + (size_t)b * a.k_out;
+  float* od = a.out_dist + (size_t)b * a.k_out;
+  uint32_t* op = a.out_pos ? a.out_pos + (size_t)b * a.k_out : nullptr;
+  for (uint32_t g = lane; g < a.k_out; g += MI355_WAVE) {
+    oi[g] = ~0ull;
+    od[g] = __builtin_huge_valf();
+    if (op) op[g] = CAND_EMPTY_POS;
+  }
+  uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t pos, uint64_t id) {
+    oi[rk] = id;
+    od[rk] = d;
+    if (op) op[rk] = pos;
+  });
+  if (lane == 0) a.out_cnt[b] = n_out;
+}
+
+// mi355_merge_topk: n_lists lists of k per query, arrays-of-fields layout
+template <int KPL>
+__global__ __launch_bounds__(64) void k_merge_lists(const uint64_t* __restrict__ in_ids,
+                                                    const float* __restrict__ in_dist,
+                                                    const uint32_t* __restrict__ in_cnt,
+                                                    uint32_t n_lists, uint32_t nq, uint32_t k,
+                                                    uint64_t* __restrict__ out_ids,
+                                                    float* __restrict__ out_dist,
+                                                    uint32_t* __restrict__ out_cnt) {
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  WaveTopK<KPL> top;
+  top.init(k, lane);
+  const uint32_t n = n_lists * k;
+  for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
+    uint32_t t = t0 + lane;
+    bool ok = false;
+    float d = 0.f;
+    uint64_t id = 0;
+    if (t < n) {
+      uint32_t l = t / k, i = t % k;
+      uint32_t cnt = min(in_cnt[(size_t)l * nq + b], k);
+      if (i < cnt) {
+        size_t o = ((size_t)l * nq + b) * k + i;
+        d = in_dist[o];
+        id = in_ids[o];
+        ok = d == d;
+      }
+    }
+    top.offer(ok, d, 0u, id, lane);
+  }
+  uint64_t* oi = out_ids + (size_t)b * k;
+  float* od = out_dist + (size_t)b * k;
+  for (uint32_t g = lane; g < k; g += MI355_WAVE) {
+    oi[g] = ~0ull;
+    od[g] = __builtin_huge_valf();
+  }
+  uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
+    oi[rk] = id;
+    od[rk] = d;
+  });
+  if (lane == 0) out_cnt[b] = n_out;
+}
+
+// ------------------------------------------------------------------ K6 -----
+// exact distance of the flat / refine path on one raw row (sequential chains)
+__device__ __forceinline__ float exact_distance(const float* __restrict__ q, const void* raw,
+                                                uint32_t dtype, uint64_t row, uint32_t dim,
+                                                uint32_t metric, float qq) {
+  const uint64_t base = row * dim;
+  if (metric == MI355_METRIC_L2) {
+    float acc = 0.f;
+    for (uint32_t d = 0; d < dim; ++d) {
+      float t = q[d] - load_elem(raw, dtype, base + d);
+      acc = __fmaf_rn(t, t, acc);
+    }
+    return acc;
+  }
+  float qv = 0.f, vv = 0.f;
+  for (uint32_t d = 0; d < dim; ++d) {
+    float v = load_elem(raw, dtype, base + d);
+    qv = __fmaf_rn(q[d], v, qv);
+    vv = __fmaf_rn(v, v, vv);
+  }
+  if (metric == MI355_METRIC_DOT) return 1.0f - qv;
+  return 1.0f - __fdiv_rn(qv, __fsqrt_rn(qq) * __fsqrt_rn(vv));
+}
+
+// Refine (query.rs:1313-1317): exact distance for the kk approximate winners,
+// range filter on the exact distance, (distance, rowid) sort, keep k.  One
+// 256-thread block per query; the final selection runs on wave 0.
+struct RefineArgs {
+  IndexView ix;
+  const float* q;          // ORIGINAL queries [nq, dim]
+  const uint64_t* in_ids;  // [nq, kk]
+  const uint32_t* in_pos;  // [nq, kk]
+  const uint32_t* in_cnt;  // [nq]
+  uint32_t kk, k;
+  RangeFilter range;
+  uint64_t* out_ids;  // [nq, k]
+  float* out_dist;
+  uint32_t* out_cnt;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void k_refine(RefineArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sq = (float*)smem;                          // [dim]
+  Cand* sc = (Cand*)(smem + (((size_t)a.ix.dim * 4 + 15) & ~(size_t)15));  // [kk]
+  __shared__ float s_qq;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t b = blockIdx.x;
+  const float* q = a.q + (size_t)b * a.ix.dim;
+  for (uint32_t d = tid; d < a.ix.dim; d += 256) sq[d] = q[d];
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.f;
+    for (uint32_t d = 0; d < a.ix.dim; ++d) acc = __fmaf_rn(sq[d], sq[d], acc);
+    s_qq = acc;
+  }
+  __syncthreads();
+  const uint32_t cnt = min(a.in_cnt[b], a.kk);
+  for (uint32_t c = tid; c < a.kk; c += 256) {
+    Cand o;
+    o.d = __builtin_huge_valf();
+    o.pos = CAND_EMPTY_POS;
+    o.id = ~0ull;
+    if (c < cnt) {
+      uint32_t pos = a.in_pos[(size_t)b * a.kk + c];
+      float d = exact_distance(sq, a.ix.raw, a.ix.raw_dtype, pos, a.ix.dim, a.ix.metric, s_qq);
+      if (in_range(d, a.range)) {
+        o.d = d;
+        o.pos = pos;
+        o.id = a.in_ids[(size_t)b * a.kk + c];
+      }
+    }
+    sc[c] = o;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    WaveTopK<KPL> top;
+    top.init(a.k, lane);
+    for (uint32_t t0 = 0; t0 < a.kk; t0 += MI355_WAVE) {
+      uint32_t t = t0 + lane;
+      Cand c;
+      c.d = 0.f;
+      c.pos = CAND_EMPTY_POS;
+      c.id = 0;
+      if (t < a.kk) c = sc[t];
+      top.offer(t < a.kk && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
+    }
+    uint64_t* oi = a.out_ids + (size_t)b * a.k;
+    float* od = a.out_dist + (size_t)b * a.k;
+    for (uint32_t g = lane; g < a.k; g += MI355_WAVE) {
+      oi[g] = ~0ull;
+      od[g] = __builtin_huge_valf();
+    }
+    uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
+      oi[rk] = id;
+      od[rk] = d;
+    });
+    if (lane == 0) a.out_cnt[b] = n_out;
+  }
+}
+
+// ------------------------------------------------------- index packing -----
+// Re-pack one partition's codes into the device layout [m][pstride] (zero
+// padded).  src is either the caller's row-major rows of this partition
+// ([len, m]) or lance's transposed block ([m, len]).  grid = (tiles of 64 rows,
+// partitions in this batch).
+struct RepackArgs {
+  const uint8_t* src;         // base of the staged chunk
+  const uint64_t* src_off;    // [n_parts] byte offset of each partition inside src
+  const uint32_t* part_ids;   // [n_parts] partition ids
+  uint8_t* dst;
+  const uint64_t* code_off;   // [nlist]
+  const uint32_t* plen;
+  const uint32_t* pstride;
+  uint32_t m;
+  uint32_t transposed;
+};
+
+__global__ __launch_bounds__(256) void k_repack_codes(RepackArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [64][m+1]
+  const uint32_t p = a.part_ids[blockIdx.y];
+  const uint32_t len = a.plen[p], stride = a.pstride[p];
+  const uint32_t r0 = blockIdx.x * 64;
+  if (r0 >= stride) return;
+  const uint8_t* src = a.src + a.src_off[blockIdx.y];
+  uint8_t* dst = a.dst + a.code_off[p];
+  const uint32_t m = a.m, pitch = m + 1;
+  const uint32_t nrow = min(64u, stride - r0);
+  for (uint32_t e = threadIdx.x; e < 64u * m; e += 256) {
+    uint32_t v = 0;
+    if (a.transposed) {
+      uint32_t j = e / 64u, i = e % 64u;
+      if (r0 + i < len) v = src[(size_t)j * len + r0 + i];
+      tile[i * pitch + j] = (uint8_t)v;
+    } else {
+      uint32_t i = e / m, j = e % m;
+      if (r0 + i < len) v = src[(size_t)(r0 + i) * m + j];
+      tile[i * pitch + j] = (uint8_t)v;
+    }
+  }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < 64u * m; e += 256) {
+    uint32_t j = e / 64u, i = e % 64u;
+    if (i < nrow) dst[(size_t)j * stride + r0 + i] = tile[i * pitch + j];
+  }
+}

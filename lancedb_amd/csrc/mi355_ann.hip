@@ -1,0 +1,1025 @@
+// mi355_ann.hip — C-ABI implementation (include/mi355_ann.h) of the MI355X ANN
+// scan engine: host-side planner + launches of the gfx950 kernels.
+//
+// Replaces, behind lancedb::query::VectorQuery, what
+// /root/reference/rust/lancedb/src/table/query.rs:219-327 hands to the lance
+// Scanner (E1 in SURVEY.md §2b): nearest / nprobes / refine / distance_range /
+// use_index -> a fixed launch sequence per query batch instead of a DataFusion
+// plan.  No torch, no Triton, no CUDA-compat headers; HIP runtime only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_ann.h"
+#include "kernels_flat.h"
+#include "kernels_ivfpq.h"
+
+// ------------------------------------------------------------------ errors --
+static thread_local std::string g_last_error;
+
+static int32_t fail(int32_t code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return fail(MI355_ERR_RUNTIME, "HIP error %d (%s) at %s:%d: %s", (int)_e,         \
+                  hipGetErrorString(_e), __FILE__, __LINE__, #expr);                    \
+  } while (0)
+
+#define ST_TRY(expr)            \
+  do {                          \
+    int32_t _s = (expr);        \
+    if (_s != MI355_OK) return _s; \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int32_t ensure(size_t bytes) {
+    if (bytes <= cap) return MI355_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(MI355_ERR_RUNTIME, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return MI355_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* s = getenv(name);
+  if (!s || !*s) return dflt;
+  return (uint32_t)strtoul(s, nullptr, 10);
+}
+
+// ---------------------------------------------------------------- handles ---
+struct StageTimer {
+  hipEvent_t ev[8];
+  bool made = false;
+};
+
+struct mi355_index {
+  int32_t device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  // shape
+  uint32_t dim = 0, nlist = 0, m = 0, dsub = 0, metric = 0;
+  uint64_t n_local = 0;
+  uint32_t parts_owned = 0, max_len = 0;
+  uint32_t shard_count = 1, shard_rank = 0;
+  // device data
+  DevBuf centroids, cnorm, codebook, codes, code_off, plen, pstride, lrow0, grow0, row_ids, raw;
+  bool has_row_ids = false, has_raw = false;
+  uint32_t raw_dtype = 0;
+  std::vector<uint32_t> h_plen;
+  // workspace
+  DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2,
+      w_dist2, w_cnt2, w_stat;
+  // config
+  uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
+  mi355_stats stats{};
+  StageTimer timer;
+};
+
+struct mi355_flat {
+  int32_t device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  uint32_t dim = 0, dtype = 0;
+  uint64_t n_rows = 0;
+  DevBuf vectors, row_ids;
+  const void* borrowed_vectors = nullptr;
+  const uint64_t* borrowed_ids = nullptr;
+  bool has_row_ids = false;
+  DevBuf w_q, w_cand, w_ids, w_dist, w_cnt;
+};
+
+static IndexView make_view(const mi355_index* ix) {
+  IndexView v;
+  v.dim = ix->dim;
+  v.nlist = ix->nlist;
+  v.m = ix->m;
+  v.dsub = ix->dsub;
+  v.metric = ix->metric;
+  v.centroids = ix->centroids.as<float>();
+  v.cnorm = ix->cnorm.as<float>();
+  v.codebook = ix->codebook.as<float>();
+  v.codes = ix->codes.as<uint8_t>();
+  v.code_off = ix->code_off.as<uint64_t>();
+  v.plen = ix->plen.as<uint32_t>();
+  v.pstride = ix->pstride.as<uint32_t>();
+  v.lrow0 = ix->lrow0.as<uint32_t>();
+  v.grow0 = ix->grow0.as<uint64_t>();
+  v.row_ids = ix->has_row_ids ? ix->row_ids.as<uint64_t>() : nullptr;
+  v.raw = ix->has_raw ? ix->raw.p : nullptr;
+  v.raw_dtype = ix->raw_dtype;
+  return v;
+}
+
+static size_t dtype_size(uint32_t dt) { return dt == MI355_DTYPE_F32 ? 4 : 2; }
+
+// copy `bytes` from a caller buffer (host or device) to device memory
+static hipError_t copy_in(void* dst, const void* src, size_t bytes, uint32_t mem, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  return hipMemcpyAsync(dst, src, bytes,
+                        mem == MI355_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                        s);
+}
+
+// ------------------------------------------------------------ shard plan ----
+static void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards,
+                            std::vector<uint32_t>& owner) {
+  owner.assign(nlist, 0);
+  if (shards <= 1) return;
+  std::vector<uint32_t> order(nlist);
+  for (uint32_t p = 0; p < nlist; ++p) order[p] = p;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    uint64_t la = po[a + 1] - po[a], lb = po[b + 1] - po[b];
+    if (la != lb) return la > lb;
+    return a < b;
+  });
+  std::vector<uint64_t> load(shards, 0);
+  for (uint32_t i = 0; i < nlist; ++i) {
+    uint32_t p = order[i], best = 0;
+    for (uint32_t s = 1; s < shards; ++s)
+      if (load[s] < load[best]) best = s;
+    owner[p] = best;
+    load[best] += po[p + 1] - po[p];
+  }
+}
+
+// ---------------------------------------------------------------- library ---
+extern "C" uint32_t mi355_abi_version(void) { return MI355_ANN_ABI_VERSION; }
+
+extern "C" int32_t mi355_device_count(int32_t* out_count) {
+  if (!out_count) return fail(MI355_ERR_INVALID_INPUT, "out_count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *out_count = n;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_last_error(char* buf, size_t buf_len) {
+  if (!buf || buf_len == 0) return MI355_ERR_INVALID_INPUT;
+  snprintf(buf, buf_len, "%s", g_last_error.c_str());
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_shard_plan(const uint64_t* part_offsets, uint32_t nlist,
+                                    uint32_t shard_count, uint32_t* out_owner) {
+  if (!part_offsets || !out_owner || shard_count == 0 || nlist == 0)
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_shard_plan: bad arguments");
+  std::vector<uint32_t> owner;
+  shard_plan_host(part_offsets, nlist, shard_count, owner);
+  memcpy(out_owner, owner.data(), sizeof(uint32_t) * nlist);
+  return MI355_OK;
+}
+
+static int32_t need_device(int32_t device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(MI355_ERR_RUNTIME,
+                "no HIP device visible (hipGetDeviceCount: %s); the MI355X engine has no CPU "
+                "fallback",
+                e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  }
+  if (device < 0 || device >= n)
+    return fail(MI355_ERR_INVALID_INPUT, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------- index open ---
+static int32_t validate_index_desc(const mi355_index_desc* d) {
+  if (!d) return fail(MI355_ERR_INVALID_INPUT, "desc is NULL");
+  if (d->struct_size != sizeof(mi355_index_desc))
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_index_desc.struct_size %u != %zu (ABI mismatch)",
+                d->struct_size, sizeof(mi355_index_desc));
+  if (d->nbits == 4)
+    return fail(MI355_ERR_NOT_SUPPORTED, "4-bit PQ is not supported yet (only num_bits=8)");
+  if (d->nbits != 8) return fail(MI355_ERR_INVALID_INPUT, "num_bits must be 4 or 8, got %u", d->nbits);
+  if (d->dim == 0 || d->nlist == 0 || d->m == 0)
+    return fail(MI355_ERR_INVALID_INPUT, "dim, nlist and m must be > 0");
+  if (d->dim % d->m != 0)
+    return fail(MI355_ERR_INVALID_INPUT, "dim %u is not divisible by num_sub_vectors %u", d->dim, d->m);
+  if (d->metric > MI355_METRIC_DOT)
+    return fail(MI355_ERR_INVALID_INPUT, "unknown metric %u", d->metric);
+  if (d->mem > MI355_MEM_DEVICE || d->codes_layout > MI355_CODES_PART_TRANSPOSED ||
+      d->raw_dtype > MI355_DTYPE_F16)
+    return fail(MI355_ERR_INVALID_INPUT, "bad mem / codes_layout / raw_dtype enum");
+  if (!d->centroids || !d->codebook || !d->part_offsets)
+    return fail(MI355_ERR_INVALID_INPUT, "centroids, codebook and part_offsets are required");
+  if (d->n_rows && !d->codes) return fail(MI355_ERR_INVALID_INPUT, "codes is NULL");
+  if (d->part_offsets[0] != 0 || d->part_offsets[d->nlist] != d->n_rows)
+    return fail(MI355_ERR_INVALID_INPUT, "part_offsets must run from 0 to n_rows");
+  for (uint32_t p = 0; p < d->nlist; ++p) {
+    if (d->part_offsets[p + 1] < d->part_offsets[p])
+      return fail(MI355_ERR_INVALID_INPUT, "part_offsets must be non-decreasing");
+    if (d->part_offsets[p + 1] - d->part_offsets[p] >= 0xFFFFFFF0ull)
+      return fail(MI355_ERR_NOT_SUPPORTED, "partition %u has >= 2^32 rows", p);
+  }
+  if (d->shard_count > 1 && d->shard_rank >= d->shard_count)
+    return fail(MI355_ERR_INVALID_INPUT, "shard_rank %u >= shard_count %u", d->shard_rank,
+                d->shard_count);
+  if ((size_t)d->m * 1024 + (size_t)d->dim * 4 > 160u * 1024)
+    return fail(MI355_ERR_NOT_SUPPORTED,
+                "distance table of %u sub-vectors (%u KiB) does not fit the 160 KiB LDS", d->m, d->m);
+  return MI355_OK;
+}
+
+static int32_t index_free(mi355_index* ix) {
+  if (!ix) return MI355_OK;
+  (void)hipSetDevice(ix->device);
+  DevBuf* bufs[] = {&ix->centroids, &ix->cnorm,  &ix->codebook, &ix->codes,   &ix->code_off,
+                    &ix->plen,      &ix->pstride, &ix->lrow0,    &ix->grow0,   &ix->row_ids,
+                    &ix->raw,       &ix->w_q,    &ix->w_qp,     &ix->w_qq,    &ix->w_coarse,
+                    &ix->w_probes,  &ix->w_cand, &ix->w_ids,    &ix->w_dist,  &ix->w_pos,
+                    &ix->w_cnt,     &ix->w_ids2, &ix->w_dist2,  &ix->w_cnt2,  &ix->w_stat};
+  for (DevBuf* b : bufs) b->release();
+  if (ix->timer.made)
+    for (auto& e : ix->timer.ev) (void)hipEventDestroy(e);
+  if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+  delete ix;
+  return MI355_OK;
+}
+
+static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
+  ix->device = d->device;
+  ix->dim = d->dim;
+  ix->nlist = d->nlist;
+  ix->m = d->m;
+  ix->dsub = d->dim / d->m;
+  ix->metric = d->metric;
+  ix->shard_count = d->shard_count > 1 ? d->shard_count : 1;
+  ix->shard_rank = d->shard_count > 1 ? d->shard_rank : 0;
+  HIP_TRY(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
+  ix->stream = ix->own_stream;
+  hipStream_t st = ix->stream;
+  const uint32_t nlist = d->nlist, m = d->m;
+
+  // -- ownership + local layout
+  std::vector<uint32_t> owner;
+  shard_plan_host(d->part_offsets, nlist, ix->shard_count, owner);
+  std::vector<uint32_t> plen(nlist), pstride(nlist), lrow0(nlist);
+  std::vector<uint64_t> code_off(nlist), grow0(nlist);
+  uint64_t rows = 0, bytes = 0;
+  uint32_t owned = 0, max_len = 0;
+  for (uint32_t p = 0; p < nlist; ++p) {
+    uint64_t len = d->part_offsets[p + 1] - d->part_offsets[p];
+    bool mine = owner[p] == ix->shard_rank;
+    plen[p] = mine ? (uint32_t)len : 0;
+    pstride[p] = (plen[p] + 15u) & ~15u;
+    lrow0[p] = (uint32_t)rows;
+    grow0[p] = d->part_offsets[p];
+    code_off[p] = bytes;
+    rows += plen[p];
+    bytes += (uint64_t)m * pstride[p];
+    if (plen[p]) {
+      ++owned;
+      max_len = std::max(max_len, plen[p]);
+    }
+  }
+  if (rows >= 0xFFFFFFF0ull)
+    return fail(MI355_ERR_NOT_SUPPORTED, "%llu rows on one handle (limit 2^32-16); shard the index",
+                (unsigned long long)rows);
+  ix->n_local = rows;
+  ix->parts_owned = owned;
+  ix->max_len = max_len;
+  ix->h_plen = plen;
+
+  // -- small tables
+  ST_TRY(ix->centroids.ensure(sizeof(float) * (size_t)nlist * d->dim));
+  ST_TRY(ix->cnorm.ensure(sizeof(float) * nlist));
+  ST_TRY(ix->codebook.ensure(sizeof(float) * (size_t)m * 256 * ix->dsub));
+  ST_TRY(ix->code_off.ensure(sizeof(uint64_t) * nlist));
+  ST_TRY(ix->plen.ensure(sizeof(uint32_t) * nlist));
+  ST_TRY(ix->pstride.ensure(sizeof(uint32_t) * nlist));
+  ST_TRY(ix->lrow0.ensure(sizeof(uint32_t) * nlist));
+  ST_TRY(ix->grow0.ensure(sizeof(uint64_t) * nlist));
+  HIP_TRY(copy_in(ix->centroids.p, d->centroids, sizeof(float) * (size_t)nlist * d->dim, d->mem, st));
+  HIP_TRY(copy_in(ix->codebook.p, d->codebook, sizeof(float) * (size_t)m * 256 * ix->dsub, d->mem, st));
+  HIP_TRY(hipMemcpyAsync(ix->code_off.p, code_off.data(), sizeof(uint64_t) * nlist, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ix->plen.p, plen.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ix->pstride.p, pstride.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ix->lrow0.p, lrow0.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ix->grow0.p, grow0.data(), sizeof(uint64_t) * nlist, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_centroid_norms, dim3((nlist + 63) / 64), dim3(64), 0, st,
+                     ix->centroids.as<float>(), nlist, d->dim, ix->cnorm.as<float>());
+  HIP_TRY(hipGetLastError());
+
+  // -- PQ codes: stage (host source) and re-pack into [m][pstride] blocks
+  ST_TRY(ix->codes.ensure(bytes + 64));
+  if (rows) {
+    const size_t STAGE = (size_t)env_u32("MI355_STAGE_MB", 256) << 20;
+    DevBuf stage, d_srcoff, d_pids;
+    std::vector<uint64_t> srcoff;
+    std::vector<uint32_t> pids;
+    auto flush = [&](uint32_t batch_max_stride) -> int32_t {
+      if (pids.empty()) return MI355_OK;
+      ST_TRY(d_srcoff.ensure(sizeof(uint64_t) * pids.size()));
+      ST_TRY(d_pids.ensure(sizeof(uint32_t) * pids.size()));
+      HIP_TRY(hipMemcpyAsync(d_srcoff.p, srcoff.data(), sizeof(uint64_t) * pids.size(), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(d_pids.p, pids.data(), sizeof(uint32_t) * pids.size(), hipMemcpyHostToDevice, st));
+      RepackArgs ra;
+      ra.src = d->mem == MI355_MEM_DEVICE ? d->codes : stage.as<uint8_t>();
+      ra.src_off = d_srcoff.as<uint64_t>();
+      ra.part_ids = d_pids.as<uint32_t>();
+      ra.dst = ix->codes.as<uint8_t>();
+      ra.code_off = ix->code_off.as<uint64_t>();
+      ra.plen = ix->plen.as<uint32_t>();
+      ra.pstride = ix->pstride.as<uint32_t>();
+      ra.m = m;
+      ra.transposed = d->codes_layout == MI355_CODES_PART_TRANSPOSED;
+      // grid.y is limited to 65535: split very wide batches
+      for (size_t y0 = 0; y0 < pids.size(); y0 += 32768) {
+        RepackArgs rb = ra;
+        rb.src_off += y0;
+        rb.part_ids += y0;
+        uint32_t ny = (uint32_t)std::min<size_t>(32768, pids.size() - y0);
+        hipLaunchKernelGGL(k_repack_codes, dim3((batch_max_stride + 63) / 64, ny), dim3(256),
+                           64 * (m + 1), st, rb);
+        HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipStreamSynchronize(st));  // staging buffer / host vectors are reused
+      srcoff.clear();
+      pids.clear();
+      return MI355_OK;
+    };
+    if (d->mem == MI355_MEM_HOST) ST_TRY(stage.ensure(STAGE));
+    size_t used = 0;
+    uint32_t bmax = 0;
+    for (uint32_t p = 0; p < nlist; ++p) {
+      if (!plen[p]) continue;
+      size_t pbytes = (size_t)m * plen[p];
+      uint64_t soff = (uint64_t)m * d->part_offsets[p];
+      if (d->mem == MI355_MEM_HOST) {
+        if (pbytes > STAGE) {  // a partition larger than the staging buffer: grow once
+          ST_TRY(flush(bmax));
+          used = 0;
+          bmax = 0;
+          ST_TRY(stage.ensure(pbytes));
+        }
+        if (used + pbytes > stage.cap) {
+          ST_TRY(flush(bmax));
+          used = 0;
+          bmax = 0;
+        }
+        HIP_TRY(hipMemcpyAsync(stage.as<uint8_t>() + used, d->codes + soff, pbytes, hipMemcpyHostToDevice, st));
+        srcoff.push_back(used);
+        used += (pbytes + 15) & ~(size_t)15;
+      } else {
+        srcoff.push_back(soff);
+      }
+      pids.push_back(p);
+      bmax = std::max(bmax, pstride[p]);
+    }
+    ST_TRY(flush(bmax));
+    stage.release();
+    d_srcoff.release();
+    d_pids.release();
+  }
+
+  // -- row ids and raw vectors: owned partitions, concatenated in local order
+  auto gather_rows = [&](DevBuf& dst, const void* src, size_t row_bytes) -> int32_t {
+    ST_TRY(dst.ensure(std::max<size_t>(row_bytes * rows, 16)));
+    uint32_t p = 0;
+    while (p < nlist) {
+      if (!plen[p]) {
+        ++p;
+        continue;
+      }
+      uint32_t e = p;  // extend over a run of consecutive owned partitions
+      uint64_t run = 0;
+      while (e < nlist && (plen[e] || d->part_offsets[e + 1] == d->part_offsets[e])) {
+        run += plen[e];
+        ++e;
+      }
+      HIP_TRY(copy_in((uint8_t*)dst.p + (size_t)lrow0[p] * row_bytes,
+                      (const uint8_t*)src + (size_t)d->part_offsets[p] * row_bytes,
+                      (size_t)run * row_bytes, d->mem, st));
+      p = e;
+    }
+    return MI355_OK;
+  };
+  if (d->row_ids) {
+    ST_TRY(gather_rows(ix->row_ids, d->row_ids, sizeof(uint64_t)));
+    ix->has_row_ids = true;
+  }
+  if (d->raw_vectors) {
+    ST_TRY(gather_rows(ix->raw, d->raw_vectors, dtype_size(d->raw_dtype) * d->dim));
+    ix->has_raw = true;
+    ix->raw_dtype = d->raw_dtype;
+  }
+  ST_TRY(ix->w_stat.ensure(64));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_index_open(const mi355_index_desc* desc, mi355_index** out) {
+  if (!out) return fail(MI355_ERR_INVALID_INPUT, "out is NULL");
+  *out = nullptr;
+  ST_TRY(validate_index_desc(desc));
+  ST_TRY(need_device(desc->device));
+  mi355_index* ix = new (std::nothrow) mi355_index();
+  if (!ix) return fail(MI355_ERR_RUNTIME, "out of host memory");
+  int32_t s = index_open_impl(desc, ix);
+  if (s != MI355_OK) {
+    index_free(ix);
+    return s;
+  }
+  *out = ix;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_index_close(mi355_index* index) { return index_free(index); }
+
+extern "C" int32_t mi355_index_set_stream(mi355_index* ix, void* hip_stream) {
+  if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_index_sync(mi355_index* ix) {
+  if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
+                                         uint32_t slice_rows, uint32_t profile) {
+  if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
+  if (scan_variant > MI355_SCAN_GROUP4) return fail(MI355_ERR_INVALID_INPUT, "unknown scan variant");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  ix->scan_variant = scan_variant;
+  ix->slice_rows = (slice_rows + 15u) & ~15u;
+  ix->profile = profile;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_index_info(const mi355_index* ix, uint64_t* out_rows,
+                                    uint32_t* out_partitions_owned) {
+  if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
+  if (out_rows) *out_rows = ix->n_local;
+  if (out_partitions_owned) *out_partitions_owned = ix->parts_owned;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_last_stats(const mi355_index* ix, mi355_stats* out) {
+  if (!ix || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
+  if (out->struct_size != sizeof(mi355_stats))
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_stats.struct_size mismatch");
+  *out = ix->stats;
+  out->struct_size = sizeof(mi355_stats);
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------ search --
+static int32_t validate_params(const mi355_search_params* p) {
+  if (!p) return fail(MI355_ERR_INVALID_INPUT, "params is NULL");
+  if (p->struct_size != sizeof(mi355_search_params))
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_search_params.struct_size %u != %zu (ABI mismatch)",
+                p->struct_size, sizeof(mi355_search_params));
+  if (p->io_mem > MI355_MEM_DEVICE) return fail(MI355_ERR_INVALID_INPUT, "bad io_mem");
+  return MI355_OK;
+}
+
+static int kpl_for(uint32_t kk) { return kk <= 64 ? 1 : kk <= 128 ? 2 : kk <= 256 ? 4 : 0; }
+
+template <int VPT, int NT>
+static int32_t launch_scan_pair_kpl(const ScanArgs& sa, dim3 grid, size_t lds, hipStream_t st,
+                                    int kpl) {
+#define LAUNCH_SP(K)                                                                       \
+  {                                                                                        \
+    auto kern = k_scan_pair<VPT, K, NT>;                                                   \
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds));                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, sa);                                 \
+  }
+  if (kpl == 1) LAUNCH_SP(1)
+  else if (kpl == 2) LAUNCH_SP(2)
+  else LAUNCH_SP(4)
+#undef LAUNCH_SP
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+static int32_t launch_scan_pair(const ScanArgs& sa, dim3 grid, size_t lds, hipStream_t st, int kpl,
+                                uint32_t vpt, uint32_t nt) {
+  if (vpt == 4 && nt == 256) return launch_scan_pair_kpl<4, 256>(sa, grid, lds, st, kpl);
+  if (vpt == 4 && nt == 512) return launch_scan_pair_kpl<4, 512>(sa, grid, lds, st, kpl);
+  if (vpt == 4 && nt == 1024) return launch_scan_pair_kpl<4, 1024>(sa, grid, lds, st, kpl);
+  if (vpt == 16 && nt == 256) return launch_scan_pair_kpl<16, 256>(sa, grid, lds, st, kpl);
+  if (vpt == 16 && nt == 512) return launch_scan_pair_kpl<16, 512>(sa, grid, lds, st, kpl);
+  if (vpt == 16 && nt == 1024) return launch_scan_pair_kpl<16, 1024>(sa, grid, lds, st, kpl);
+  return fail(MI355_ERR_INVALID_INPUT, "unsupported scan tuning vpt=%u threads=%u", vpt, nt);
+}
+
+template <typename Args, typename KernFn>
+static void launch_by_kpl(int kpl, KernFn k1, KernFn k2, KernFn k4, dim3 grid, dim3 block,
+                          size_t lds, hipStream_t st, const Args& a) {
+  if (kpl == 1)
+    hipLaunchKernelGGL(k1, grid, block, lds, st, a);
+  else if (kpl == 2)
+    hipLaunchKernelGGL(k2, grid, block, lds, st, a);
+  else
+    hipLaunchKernelGGL(k4, grid, block, lds, st, a);
+}
+
+struct SearchPlan {
+  uint32_t k, kk, nprobe;
+  bool refine;
+  RangeFilter range;
+};
+
+// one pass of the pipeline over `nq` queries already resident at d_q;
+// results land in d_ids/d_dist/d_cnt (device, [nq,k])
+static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl,
+                         uint64_t* d_ids, float* d_dist, uint32_t* d_cnt) {
+  hipStream_t st = ix->stream;
+  const IndexView view = make_view(ix);
+  const uint32_t nprobe = pl.nprobe;
+  const int kpl_kk = kpl_for(pl.kk), kpl_k = kpl_for(pl.k);
+
+  // tuning (dev knobs; defaults chosen from the index shape)
+  uint32_t nt = env_u32("MI355_SCAN_THREADS", 0), vpt = env_u32("MI355_SCAN_VPT", 0);
+  if (!nt) nt = ix->max_len >= 8192 ? 1024 : ix->max_len >= 2048 ? 512 : 256;
+  if (!vpt) vpt = ix->max_len >= 4 * nt * 4 ? 16 : 4;
+  uint32_t slice = ix->slice_rows ? ix->slice_rows : std::max(nt * vpt, 16384u);
+  slice = (slice + 15u) & ~15u;
+  const uint32_t n_slices = std::max(1u, (ix->max_len + slice - 1) / slice);
+  const size_t lds = (size_t)ix->m * 1024 + (size_t)ix->dim * 4;
+  if ((size_t)(nt / 64) * pl.kk * sizeof(Cand) > (size_t)ix->m * 1024)
+    return fail(MI355_ERR_NOT_SUPPORTED, "k*refine_factor=%u too large for the in-LDS merge", pl.kk);
+
+  // chunk the batch so the workspace stays bounded
+  const size_t per_q = (size_t)ix->nlist * 4 + (size_t)nprobe * n_slices * pl.kk * sizeof(Cand);
+  const size_t budget = (size_t)env_u32("MI355_WORKSPACE_MB", 2048) << 20;
+  uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / std::max<size_t>(per_q, 1)));
+  chunk = std::min(chunk, 65535u);  // grid.z limit
+  ST_TRY(ix->w_qp.ensure(sizeof(float) * (size_t)chunk * ix->dim));
+  ST_TRY(ix->w_qq.ensure(sizeof(float) * chunk));
+  ST_TRY(ix->w_coarse.ensure(sizeof(float) * (size_t)chunk * ix->nlist));
+  ST_TRY(ix->w_probes.ensure(sizeof(uint32_t) * (size_t)chunk * nprobe));
+  ST_TRY(ix->w_cand.ensure(sizeof(Cand) * (size_t)chunk * nprobe * n_slices * pl.kk));
+  if (pl.refine) {
+    ST_TRY(ix->w_ids2.ensure(sizeof(uint64_t) * (size_t)chunk * pl.kk));
+    ST_TRY(ix->w_dist2.ensure(sizeof(float) * (size_t)chunk * pl.kk));
+    ST_TRY(ix->w_pos.ensure(sizeof(uint32_t) * (size_t)chunk * pl.kk));
+    ST_TRY(ix->w_cnt2.ensure(sizeof(uint32_t) * chunk));
+  }
+  unsigned long long* d_stat = ix->w_stat.as<unsigned long long>();
+  const bool prof = ix->profile != 0;
+  if (prof && !ix->timer.made) {
+    for (auto& e : ix->timer.ev) HIP_TRY(hipEventCreate(&e));
+    ix->timer.made = true;
+  }
+  float us[6] = {0, 0, 0, 0, 0, 0};
+
+  for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
+    const uint32_t n = std::min(chunk, nq - q0);
+    const float* q = d_q + (size_t)q0 * ix->dim;
+    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[0], st));
+    hipLaunchKernelGGL(k_prep_queries, dim3((n + 63) / 64), dim3(64), 0, st, q, n, ix->dim,
+                       ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
+    hipLaunchKernelGGL(k_coarse_tile, dim3((ix->nlist + CO_T - 1) / CO_T, (n + CO_T - 1) / CO_T),
+                       dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
+                       view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
+                       ix->w_coarse.as<float>());
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[1], st));
+    hipLaunchKernelGGL(k_select_probes, dim3(n), dim3(256), 0, st, ix->w_coarse.as<float>(),
+                       ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat);
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[2], st));
+
+    ScanArgs sa;
+    sa.ix = view;
+    sa.qp = ix->w_qp.as<float>();
+    sa.probes = ix->w_probes.as<uint32_t>();
+    sa.nprobe = nprobe;
+    sa.slice_rows = slice;
+    sa.n_slices = n_slices;
+    sa.kk = pl.kk;
+    sa.range = pl.range;
+    sa.cand = ix->w_cand.as<Cand>();
+    ST_TRY(launch_scan_pair(sa, dim3(n_slices, nprobe, n), lds, st, kpl_kk, vpt, nt));
+    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[3], st));
+
+    MergeArgs ma;
+    ma.cand = ix->w_cand.as<Cand>();
+    ma.n_src = nprobe * n_slices;
+    ma.kk_in = pl.kk;
+    if (!pl.refine) {
+      ma.k_out = pl.k;
+      ma.out_ids = d_ids + (size_t)q0 * pl.k;
+      ma.out_dist = d_dist + (size_t)q0 * pl.k;
+      ma.out_pos = nullptr;
+      ma.out_cnt = d_cnt + q0;
+      launch_by_kpl(kpl_k, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
+      HIP_TRY(hipGetLastError());
+      if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[4], st));
+    } else {
+      ma.k_out = pl.kk;
+      ma.out_ids = ix->w_ids2.as<uint64_t>();
+      ma.out_dist = ix->w_dist2.as<float>();
+      ma.out_pos = ix->w_pos.as<uint32_t>();
+      ma.out_cnt = ix->w_cnt2.as<uint32_t>();
+      launch_by_kpl(kpl_kk, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
+      HIP_TRY(hipGetLastError());
+      if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[4], st));
+      RefineArgs ra;
+      ra.ix = view;
+      ra.q = q;
+      ra.in_ids = ix->w_ids2.as<uint64_t>();
+      ra.in_pos = ix->w_pos.as<uint32_t>();
+      ra.in_cnt = ix->w_cnt2.as<uint32_t>();
+      ra.kk = pl.kk;
+      ra.k = pl.k;
+      ra.range = pl.range;
+      ra.out_ids = d_ids + (size_t)q0 * pl.k;
+      ra.out_dist = d_dist + (size_t)q0 * pl.k;
+      ra.out_cnt = d_cnt + q0;
+      size_t rl = (((size_t)ix->dim * 4 + 15) & ~(size_t)15) + sizeof(Cand) * pl.kk;
+      launch_by_kpl(kpl_k, k_refine<1>, k_refine<2>, k_refine<4>, dim3(n), dim3(256), rl, st, ra);
+      HIP_TRY(hipGetLastError());
+    }
+    if (prof) {
+      HIP_TRY(hipEventRecord(ix->timer.ev[5], st));
+      HIP_TRY(hipEventSynchronize(ix->timer.ev[5]));
+      for (int i = 0; i < 5; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->timer.ev[i], ix->timer.ev[i + 1]));
+        us[i] += ms * 1000.f;
+      }
+    }
+  }
+  ix->stats.us_coarse += us[0];
+  ix->stats.us_select += us[1];
+  ix->stats.us_scan += us[2];
+  ix->stats.us_merge += us[3];
+  ix->stats.us_refine += us[4];
+  ix->stats.us_total += us[0] + us[1] + us[2] + us[3] + us[4];
+  ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
+  ix->stats.partitions_probed += (uint64_t)nq * nprobe;
+  ix->stats.scan_variant = MI355_SCAN_PAIR;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t n_queries,
+                                const mi355_search_params* p, uint64_t* out_rowids,
+                                float* out_dist, uint32_t* out_counts) {
+  if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
+  ST_TRY(validate_params(p));
+  // nprobes validation: rust/lancedb/src/query.rs:1232-1275
+  if (p->nprobe_min == 0) return fail(MI355_ERR_INVALID_INPUT, "minimum_nprobes must be greater than 0");
+  if (p->nprobe_max != 0 && p->nprobe_max < p->nprobe_min)
+    return fail(MI355_ERR_INVALID_INPUT, "maximum_nprobes must be greater than or equal to minimum_nprobes");
+  if (p->metric != MI355_METRIC_DEFAULT && p->metric != ix->metric)
+    return fail(MI355_ERR_INVALID_INPUT,
+                "distance type %u does not match the metric the index was trained with (%u)",
+                p->metric, ix->metric);
+  if (n_queries == 0) return MI355_OK;
+  if (!queries || !out_counts || (p->k && (!out_rowids || !out_dist)))
+    return fail(MI355_ERR_INVALID_INPUT, "NULL query / output buffer");
+  if (p->refine_factor && !ix->has_raw)
+    return fail(MI355_ERR_INVALID_INPUT, "refine_factor needs raw vectors on the index handle");
+  const uint32_t k = p->k;
+  uint64_t kk64 = (uint64_t)k * (p->refine_factor ? p->refine_factor : 1);
+  if (k == 0) {
+    if (p->io_mem == MI355_MEM_HOST) memset(out_counts, 0, sizeof(uint32_t) * n_queries);
+    else {
+      HIP_TRY(hipSetDevice(ix->device));
+      HIP_TRY(hipMemsetAsync(out_counts, 0, sizeof(uint32_t) * n_queries, ix->stream));
+    }
+    return MI355_OK;
+  }
+  if (kk64 > 256 || kpl_for((uint32_t)kk64) == 0)
+    return fail(MI355_ERR_NOT_SUPPORTED, "k * refine_factor = %llu exceeds the supported 256",
+                (unsigned long long)kk64);
+  uint32_t np_min = std::min(p->nprobe_min, ix->nlist);
+  uint32_t np_max = (p->nprobe_max == 0 || p->nprobe_max > ix->nlist) ? ix->nlist : p->nprobe_max;
+  if (ix->shard_count > 1 && np_max != np_min)
+    return fail(MI355_ERR_NOT_SUPPORTED,
+                "maximum_nprobes expansion on a sharded handle must be driven by the caller after "
+                "the cross-shard merge");
+
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t st = ix->stream;
+  auto t_start = std::chrono::steady_clock::now();
+  ix->stats = mi355_stats{};
+  ix->stats.struct_size = sizeof(mi355_stats);
+  ix->stats.n_queries = n_queries;
+  HIP_TRY(hipMemsetAsync(ix->w_stat.p, 0, 64, st));
+
+  const bool host_io = p->io_mem == MI355_MEM_HOST;
+  const float* d_q = queries;
+  uint64_t* d_ids = out_rowids;
+  float* d_dist = out_dist;
+  uint32_t* d_cnt = out_counts;
+  if (host_io) {
+    ST_TRY(ix->w_q.ensure(sizeof(float) * (size_t)n_queries * ix->dim));
+    ST_TRY(ix->w_ids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
+    ST_TRY(ix->w_dist.ensure(sizeof(float) * (size_t)n_queries * k));
+    ST_TRY(ix->w_cnt.ensure(sizeof(uint32_t) * n_queries));
+    HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)n_queries * ix->dim, hipMemcpyHostToDevice, st));
+    d_q = ix->w_q.as<float>();
+    d_ids = ix->w_ids.as<uint64_t>();
+    d_dist = ix->w_dist.as<float>();
+    d_cnt = ix->w_cnt.as<uint32_t>();
+  }
+  SearchPlan pl;
+  pl.k = k;
+  pl.kk = (uint32_t)kk64;
+  pl.refine = p->refine_factor != 0;
+  pl.nprobe = np_min;
+  pl.range.has_lower = p->has_lower_bound;
+  pl.range.has_upper = p->has_upper_bound;
+  pl.range.lower = p->lower_bound;
+  pl.range.upper = p->upper_bound;
+  ST_TRY(run_ivfpq(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt));
+
+  if (np_max > np_min) {
+    // maximum_nprobes (query.rs:1246-1262): queries that came back short are
+    // searched again over the first np_max partitions.
+    std::vector<uint32_t> cnt(n_queries);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> shortq;
+    for (uint32_t i = 0; i < n_queries; ++i)
+      if (cnt[i] < k) shortq.push_back(i);
+    if (!shortq.empty()) {
+      const uint32_t ns = (uint32_t)shortq.size();
+      DevBuf sq, sids, sdist, scnt;
+      ST_TRY(sq.ensure(sizeof(float) * (size_t)ns * ix->dim));
+      ST_TRY(sids.ensure(sizeof(uint64_t) * (size_t)ns * k));
+      ST_TRY(sdist.ensure(sizeof(float) * (size_t)ns * k));
+      ST_TRY(scnt.ensure(sizeof(uint32_t) * ns));
+      for (uint32_t i = 0; i < ns; ++i)
+        HIP_TRY(hipMemcpyAsync(sq.as<float>() + (size_t)i * ix->dim, d_q + (size_t)shortq[i] * ix->dim,
+                               sizeof(float) * ix->dim, hipMemcpyDeviceToDevice, st));
+      SearchPlan p2 = pl;
+      p2.nprobe = np_max;
+      int32_t s2 = run_ivfpq(ix, sq.as<float>(), ns, p2, sids.as<uint64_t>(), sdist.as<float>(), scnt.as<uint32_t>());
+      if (s2 == MI355_OK) {
+        for (uint32_t i = 0; i < ns && s2 == MI355_OK; ++i) {
+          size_t o = (size_t)shortq[i] * k;
+          if (hipMemcpyAsync(d_ids + o, sids.as<uint64_t>() + (size_t)i * k, sizeof(uint64_t) * k, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(d_dist + o, sdist.as<float>() + (size_t)i * k, sizeof(float) * k, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+              hipMemcpyAsync(d_cnt + shortq[i], scnt.as<uint32_t>() + i, sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            s2 = fail(MI355_ERR_RUNTIME, "scatter of expanded-probe results failed");
+        }
+      }
+      (void)hipStreamSynchronize(st);
+      sq.release();
+      sids.release();
+      sdist.release();
+      scnt.release();
+      if (s2 != MI355_OK) return s2;
+    }
+  }
+
+  if (host_io) {
+    HIP_TRY(hipMemcpyAsync(out_rowids, d_ids, sizeof(uint64_t) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
+    unsigned long long rows = 0;
+    HIP_TRY(hipMemcpyAsync(&rows, ix->w_stat.p, sizeof(rows), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ix->stats.vectors_scanned = rows;
+    ix->stats.code_bytes_scanned = rows * ix->m;
+    if (p->timeout_ms) {
+      auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
+      if (ms > (long long)p->timeout_ms)
+        return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms", (long long)ms, p->timeout_ms);
+    }
+  }
+  return MI355_OK;
+}
+
+// -------------------------------------------------------------------- flat --
+extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
+  if (!out) return fail(MI355_ERR_INVALID_INPUT, "out is NULL");
+  *out = nullptr;
+  if (!d) return fail(MI355_ERR_INVALID_INPUT, "desc is NULL");
+  if (d->struct_size != sizeof(mi355_flat_desc))
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_flat_desc.struct_size %u != %zu (ABI mismatch)",
+                d->struct_size, sizeof(mi355_flat_desc));
+  if (d->dim == 0) return fail(MI355_ERR_INVALID_INPUT, "dim must be > 0");
+  if (d->dtype > MI355_DTYPE_F16 || d->mem > MI355_MEM_DEVICE)
+    return fail(MI355_ERR_INVALID_INPUT, "bad dtype / mem enum");
+  if (d->n_rows && !d->vectors) return fail(MI355_ERR_INVALID_INPUT, "vectors is NULL");
+  if (d->n_rows >= 0xFFFFFFF0ull) return fail(MI355_ERR_NOT_SUPPORTED, "flat column limited to 2^32-16 rows");
+  if ((size_t)d->dim * 4 > 60u * 1024) return fail(MI355_ERR_NOT_SUPPORTED, "dim %u too large", d->dim);
+  ST_TRY(need_device(d->device));
+  mi355_flat* f = new (std::nothrow) mi355_flat();
+  if (!f) return fail(MI355_ERR_RUNTIME, "out of host memory");
+  f->device = d->device;
+  f->dim = d->dim;
+  f->dtype = d->dtype;
+  f->n_rows = d->n_rows;
+  auto bail = [&](int32_t s) {
+    mi355_flat_close(f);
+    return s;
+  };
+  if (hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(MI355_ERR_RUNTIME, "hipStreamCreate failed"));
+  f->stream = f->own_stream;
+  size_t vb = dtype_size(d->dtype) * (size_t)d->dim * d->n_rows;
+  int32_t s = f->vectors.ensure(std::max<size_t>(vb, 16));
+  if (s) return bail(s);
+  if (copy_in(f->vectors.p, d->vectors, vb, d->mem, f->stream) != hipSuccess)
+    return bail(fail(MI355_ERR_RUNTIME, "upload of the vector column failed"));
+  if (d->row_ids) {
+    s = f->row_ids.ensure(std::max<size_t>(sizeof(uint64_t) * d->n_rows, 16));
+    if (s) return bail(s);
+    if (copy_in(f->row_ids.p, d->row_ids, sizeof(uint64_t) * d->n_rows, d->mem, f->stream) != hipSuccess)
+      return bail(fail(MI355_ERR_RUNTIME, "upload of row ids failed"));
+    f->has_row_ids = true;
+  }
+  if (hipStreamSynchronize(f->stream) != hipSuccess) return bail(fail(MI355_ERR_RUNTIME, "sync failed"));
+  *out = f;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_flat_close(mi355_flat* f) {
+  if (!f) return MI355_OK;
+  (void)hipSetDevice(f->device);
+  DevBuf* bufs[] = {&f->vectors, &f->row_ids, &f->w_q, &f->w_cand, &f->w_ids, &f->w_dist, &f->w_cnt};
+  for (DevBuf* b : bufs) b->release();
+  if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
+  delete f;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_flat_set_stream(mi355_flat* f, void* hip_stream) {
+  if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
+  std::lock_guard<std::mutex> lk(f->mu);
+  f->stream = hip_stream ? (hipStream_t)hip_stream : f->own_stream;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_flat_sync(mi355_flat* f) {
+  if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
+  HIP_TRY(hipSetDevice(f->device));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32_t n_queries,
+                                     const mi355_search_params* p, uint64_t* out_rowids,
+                                     float* out_dist, uint32_t* out_counts) {
+  if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
+  ST_TRY(validate_params(p));
+  uint32_t metric = p->metric == MI355_METRIC_DEFAULT ? (uint32_t)MI355_METRIC_L2 : p->metric;
+  if (metric > MI355_METRIC_DOT) return fail(MI355_ERR_INVALID_INPUT, "unknown metric %u", metric);
+  if (n_queries == 0) return MI355_OK;
+  if (!queries || !out_counts || (p->k && (!out_rowids || !out_dist)))
+    return fail(MI355_ERR_INVALID_INPUT, "NULL query / output buffer");
+  const uint32_t k = p->k;
+  std::lock_guard<std::mutex> lk(f->mu);
+  HIP_TRY(hipSetDevice(f->device));
+  hipStream_t st = f->stream;
+  const bool host_io = p->io_mem == MI355_MEM_HOST;
+  if (k == 0) {
+    if (host_io) memset(out_counts, 0, sizeof(uint32_t) * n_queries);
+    else HIP_TRY(hipMemsetAsync(out_counts, 0, sizeof(uint32_t) * n_queries, st));
+    return MI355_OK;
+  }
+  const int kpl = kpl_for(k);
+  if (!kpl) return fail(MI355_ERR_NOT_SUPPORTED, "k = %u exceeds the supported 256", k);
+  auto t_start = std::chrono::steady_clock::now();
+  const float* d_q = queries;
+  uint64_t* d_ids = out_rowids;
+  float* d_dist = out_dist;
+  uint32_t* d_cnt = out_counts;
+  if (host_io) {
+    ST_TRY(f->w_q.ensure(sizeof(float) * (size_t)n_queries * f->dim));
+    ST_TRY(f->w_ids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
+    ST_TRY(f->w_dist.ensure(sizeof(float) * (size_t)n_queries * k));
+    ST_TRY(f->w_cnt.ensure(sizeof(uint32_t) * n_queries));
+    HIP_TRY(hipMemcpyAsync(f->w_q.p, queries, sizeof(float) * (size_t)n_queries * f->dim, hipMemcpyHostToDevice, st));
+    d_q = f->w_q.as<float>();
+    d_ids = f->w_ids.as<uint64_t>();
+    d_dist = f->w_dist.as<float>();
+    d_cnt = f->w_cnt.as<uint32_t>();
+  }
+  // enough work items to fill 256 CUs, at least 1024 rows each
+  uint32_t slice = (uint32_t)std::max<uint64_t>(1024, (f->n_rows + 2047) / 2048);
+  slice = (slice + 255u) & ~255u;
+  const uint32_t n_slices = (uint32_t)std::max<uint64_t>(1, (f->n_rows + slice - 1) / slice);
+  const uint32_t chunk = std::min(n_queries, 65535u);
+  ST_TRY(f->w_cand.ensure(sizeof(Cand) * (size_t)chunk * n_slices * k));
+  for (uint32_t q0 = 0; q0 < n_queries; q0 += chunk) {
+    const uint32_t n = std::min(chunk, n_queries - q0);
+    FlatArgs fa;
+    fa.vectors = f->vectors.p;
+    fa.dtype = f->dtype;
+    fa.row_ids = f->has_row_ids ? f->row_ids.as<uint64_t>() : nullptr;
+    fa.n_rows = f->n_rows;
+    fa.dim = f->dim;
+    fa.metric = metric;
+    fa.q = d_q + (size_t)q0 * f->dim;
+    fa.slice_rows = slice;
+    fa.n_slices = n_slices;
+    fa.kk = k;
+    fa.range.has_lower = p->has_lower_bound;
+    fa.range.has_upper = p->has_upper_bound;
+    fa.range.lower = p->lower_bound;
+    fa.range.upper = p->upper_bound;
+    fa.cand = f->w_cand.as<Cand>();
+    size_t lds = (((size_t)f->dim * 4 + 15) & ~(size_t)15) + sizeof(Cand) * 4 * k;
+    launch_by_kpl(kpl, k_flat_scan<1>, k_flat_scan<2>, k_flat_scan<4>, dim3(n_slices, 1, n), dim3(256), lds, st, fa);
+    HIP_TRY(hipGetLastError());
+    MergeArgs ma;
+    ma.cand = f->w_cand.as<Cand>();
+    ma.n_src = n_slices;
+    ma.kk_in = k;
+    ma.k_out = k;
+    ma.out_ids = d_ids + (size_t)q0 * k;
+    ma.out_dist = d_dist + (size_t)q0 * k;
+    ma.out_pos = nullptr;
+    ma.out_cnt = d_cnt + q0;
+    launch_by_kpl(kpl, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
+    HIP_TRY(hipGetLastError());
+  }
+  if (host_io) {
+    HIP_TRY(hipMemcpyAsync(out_rowids, d_ids, sizeof(uint64_t) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (p->timeout_ms) {
+      auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
+      if (ms > (long long)p->timeout_ms)
+        return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms", (long long)ms, p->timeout_ms);
+    }
+  }
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------- merge --
+extern "C" int32_t mi355_merge_topk(int32_t device, void* hip_stream, const uint64_t* in_rowids,
+                                    const float* in_dist, const uint32_t* in_counts,
+                                    uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                                    uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) {
+  if (n_queries == 0) return MI355_OK;
+  if (!in_rowids || !in_dist || !in_counts || !out_rowids || !out_dist || !out_counts)
+    return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
+  if (n_lists == 0 || k == 0) return fail(MI355_ERR_INVALID_INPUT, "n_lists and k must be > 0");
+  const int kpl = kpl_for(k);
+  if (!kpl) return fail(MI355_ERR_NOT_SUPPORTED, "k = %u exceeds the supported 256", k);
+  ST_TRY(need_device(device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (kpl == 1)
+    hipLaunchKernelGGL(k_merge_lists<1>, dim3(n_queries), dim3(64), 0, st, in_rowids, in_dist, in_counts, n_lists, n_queries, k, out_rowids, out_dist, out_counts);
+  else if (kpl == 2)
+    hipLaunchKernelGGL(k_merge_lists<2>, dim3(n_queries), dim3(64), 0, st, in_rowids, in_dist, in_counts, n_lists, n_queries, k, out_rowids, out_dist, out_counts);
+  else
+    hipLaunchKernelGGL(k_merge_lists<4>, dim3(n_queries), dim3(64), 0, st, in_rowids, in_dist, in_counts, n_lists, n_queries, k, out_rowids, out_dist, out_counts);
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}

@@ -1,0 +1,224 @@
+"""Device-resident index handles over the C ABI (include/mi355_ann.h).
+
+`IvfPqIndex` plays the role the lance `Session` index cache plays in the
+reference (python/src/session.rs:49-50): open once, search many times.
+Arrays may be numpy (host) or anything exposing a device pointer through
+`data_ptr()` (e.g. a torch tensor on the GPU) — only raw pointers cross the ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import check, lib
+
+
+def _is_device(a):
+    return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _host(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+class SearchResult:
+    """Per query: `counts[q]` rows sorted by (_distance, _rowid); padded with
+    UINT64_MAX / +inf (python/python/lancedb/query.py:1365-1370)."""
+
+    def __init__(self, rowids, distances, counts):
+        self.rowids, self.distances, self.counts = rowids, distances, counts
+
+    def __iter__(self):
+        return iter((self.rowids, self.distances, self.counts))
+
+
+class _Handle:
+    _close_fn = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            getattr(lib(), self._close_fn)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _run_search(fn, handle, dim, queries, params, out=None):
+    """Shared host/device marshalling of mi355_search / mi355_flat_search."""
+    if _is_device(queries):
+        import torch
+        q = queries.contiguous().view(-1, dim)
+        assert q.dtype == torch.float32
+        nq, k = q.shape[0], params.k
+        if out is None:
+            ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            cnt = torch.empty((nq,), dtype=torch.int32, device=q.device)
+        else:
+            ids, dist, cnt = out
+        params.io_mem = _abi.MEM_DEVICE
+        check(fn(handle, _ptr(q), C.c_uint32(nq), C.byref(params), _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return SearchResult(ids, dist, cnt)
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, dim)
+    nq, k = q.shape[0], params.k
+    ids = np.empty((nq, k), dtype=np.uint64)
+    dist = np.empty((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    params.io_mem = _abi.MEM_HOST
+    check(fn(handle, _ptr(q), C.c_uint32(nq), C.byref(params), _ptr(ids), _ptr(dist), _ptr(cnt)))
+    return SearchResult(ids, dist, cnt)
+
+
+class IvfPqIndex(_Handle):
+    """An IVF-PQ index resident on one MI355X.
+
+    Parameters mirror IvfPqIndexBuilder's outputs
+    (rust/lancedb/src/index/vector.rs:266-319): `centroids` [nlist, dim] f32,
+    `codebook` [m, 256, dim/m] f32, `part_offsets` [nlist+1], `codes` u8 in
+    `codes_layout`, optional `row_ids` / `raw_vectors` in index order.
+    """
+    _close_fn = "mi355_index_close"
+
+    def __init__(self, centroids, codebook, part_offsets, codes, row_ids=None, raw_vectors=None,
+                 metric="l2", codes_layout=_abi.CODES_ROW_MAJOR, raw_dtype=_abi.DTYPE_F32,
+                 device=0, shard_count=1, shard_rank=0):
+        super().__init__()
+        on_dev = _is_device(codes)
+        po = np.ascontiguousarray(part_offsets, dtype=np.uint64)  # always host
+        if on_dev:
+            cen, cb, cd, rid, raw = centroids, codebook, codes, row_ids, raw_vectors
+            nlist, dim = cen.shape
+            m = cb.shape[0]
+        else:
+            cen = _host(centroids, np.float32)
+            cb = _host(codebook, np.float32)
+            cd = _host(codes, np.uint8)
+            rid = _host(row_ids, np.uint64)
+            raw = None if raw_vectors is None else np.ascontiguousarray(raw_vectors)
+            nlist, dim = cen.shape
+            m = cb.shape[0]
+        self.dim, self.nlist, self.m = int(dim), int(nlist), int(m)
+        self.metric = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else int(metric)
+        d = _abi.IndexDesc()
+        d.struct_size = C.sizeof(_abi.IndexDesc)
+        d.dim, d.nlist, d.m, d.nbits = self.dim, self.nlist, self.m, 8
+        d.metric = self.metric
+        d.n_rows = int(po[-1])
+        d.mem = _abi.MEM_DEVICE if on_dev else _abi.MEM_HOST
+        d.codes_layout = codes_layout
+        d.centroids, d.codebook, d.part_offsets = _ptr(cen), _ptr(cb), _ptr(po)
+        d.codes, d.row_ids, d.raw_vectors = _ptr(cd), _ptr(rid), _ptr(raw)
+        d.raw_dtype = raw_dtype
+        d.device = device
+        d.shard_count, d.shard_rank = shard_count, shard_rank
+        self.n_rows = d.n_rows
+        self._keep = [cen, cb, po, cd, rid, raw]
+        check(lib().mi355_index_open(C.byref(d), C.byref(self._h)))
+        self._keep = []  # the library copied everything it needs
+
+    def configure(self, scan_variant=_abi.SCAN_AUTO, slice_rows=0, profile=False):
+        check(lib().mi355_index_configure(self._h, C.c_uint32(scan_variant), C.c_uint32(slice_rows),
+                                          C.c_uint32(1 if profile else 0)))
+
+    def set_stream(self, hip_stream):
+        check(lib().mi355_index_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def sync(self):
+        check(lib().mi355_index_sync(self._h))
+
+    def info(self):
+        rows, parts = C.c_uint64(0), C.c_uint32(0)
+        check(lib().mi355_index_info(self._h, C.byref(rows), C.byref(parts)))
+        return rows.value, parts.value
+
+    def stats(self):
+        s = _abi.Stats()
+        s.struct_size = C.sizeof(_abi.Stats)
+        check(lib().mi355_last_stats(self._h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in _abi.Stats._fields_ if name != "struct_size"}
+
+    def search(self, queries, params=None, out=None, **kw):
+        """queries [nq, dim] f32 (numpy or device tensor) -> SearchResult."""
+        p = params if params is not None else _abi.make_params(**kw)
+        return _run_search(lib().mi355_search, self._h, self.dim, queries, p, out)
+
+
+class FlatIndex(_Handle):
+    """A raw vector column on the GPU for exhaustive search
+    (bypass_vector_index, rust/lancedb/src/query.rs:1360-1370)."""
+    _close_fn = "mi355_flat_close"
+
+    def __init__(self, vectors, row_ids=None, dtype=_abi.DTYPE_F32, device=0):
+        super().__init__()
+        on_dev = _is_device(vectors)
+        if on_dev:
+            v, rid = vectors, row_ids
+        else:
+            v = np.ascontiguousarray(vectors)
+            if dtype == _abi.DTYPE_F32:
+                v = np.ascontiguousarray(v, dtype=np.float32)
+            rid = _host(row_ids, np.uint64)
+        n, dim = v.shape
+        self.dim, self.n_rows = int(dim), int(n)
+        d = _abi.FlatDesc()
+        d.struct_size = C.sizeof(_abi.FlatDesc)
+        d.dim, d.n_rows, d.dtype = self.dim, self.n_rows, dtype
+        d.mem = _abi.MEM_DEVICE if on_dev else _abi.MEM_HOST
+        d.vectors, d.row_ids, d.device = _ptr(v), _ptr(rid), device
+        check(lib().mi355_flat_open(C.byref(d), C.byref(self._h)))
+
+    def set_stream(self, hip_stream):
+        check(lib().mi355_flat_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def sync(self):
+        check(lib().mi355_flat_sync(self._h))
+
+    def search(self, queries, params=None, out=None, **kw):
+        kw.setdefault("nprobe_min", 1)
+        kw.setdefault("nprobe_max", 1)
+        p = params if params is not None else _abi.make_params(**kw)
+        return _run_search(lib().mi355_flat_search, self._h, self.dim, queries, p, out)
+
+
+def merge_topk(in_rowids, in_dist, in_counts, k, stream=0):
+    """Device-side k-way merge of [n_lists, nq, k] candidate lists (torch CUDA
+    tensors): the reducer after the multi-GPU all-gather."""
+    import torch
+    n_lists, nq = in_counts.shape
+    dev = in_dist.device
+    ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    check(lib().mi355_merge_topk(C.c_int32(dev.index or 0), C.c_void_p(stream), _ptr(in_rowids),
+                                 _ptr(in_dist), _ptr(in_counts), C.c_uint32(n_lists),
+                                 C.c_uint32(nq), C.c_uint32(k), _ptr(ids), _ptr(dist), _ptr(cnt)))
+    return ids, dist, cnt
+
+
+def shard_plan(part_offsets, shard_count):
+    po = np.ascontiguousarray(part_offsets, dtype=np.uint64)
+    out = np.empty(po.size - 1, dtype=np.uint32)
+    check(lib().mi355_shard_plan(_ptr(po), C.c_uint32(po.size - 1), C.c_uint32(shard_count), _ptr(out)))
+    return out

@@ -1,0 +1,108 @@
+"""The C-ABI library loads, exports every symbol include/mi355_ann.h declares,
+and rejects bad input before touching a device.  No GPU needed."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lancedb_amd
+from lancedb_amd import _abi, _lib
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "mi355_ann.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    _lib.build()
+    return _lib.lib()
+
+
+def test_exports_match_header(L):
+    src = open(HEADER).read()
+    declared = set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", src))
+    assert declared == set(_abi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.mi355_abi_version() == _abi.ABI_VERSION
+
+
+def test_struct_sizes_match_c_layout(tmp_path):
+    """Compile a tiny C program against the header and compare sizeof()s."""
+    import subprocess
+    c = tmp_path / "sz.c"
+    c.write_text('#include "mi355_ann.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n",'
+                 'sizeof(mi355_index_desc),sizeof(mi355_search_params),sizeof(mi355_flat_desc),sizeof(mi355_stats));return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.dirname(HEADER), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in out] == [C.sizeof(_abi.IndexDesc), C.sizeof(_abi.SearchParams),
+                                     C.sizeof(_abi.FlatDesc), C.sizeof(_abi.Stats)]
+
+
+def _desc(**over):
+    cen = np.zeros((4, 8), np.float32)
+    cb = np.zeros((2, 256, 4), np.float32)
+    po = np.array([0, 1, 2, 3, 4], np.uint64)
+    codes = np.zeros((4, 2), np.uint8)
+    d = _abi.IndexDesc()
+    d.struct_size = C.sizeof(_abi.IndexDesc)
+    d.dim, d.nlist, d.m, d.nbits, d.metric, d.n_rows = 8, 4, 2, 8, 0, 4
+    d.centroids = cen.ctypes.data_as(C.c_void_p)
+    d.codebook = cb.ctypes.data_as(C.c_void_p)
+    d.part_offsets = po.ctypes.data_as(C.c_void_p)
+    d.codes = codes.ctypes.data_as(C.c_void_p)
+    d.shard_count = 1
+    for k, v in over.items():
+        setattr(d, k, v)
+    return d, (cen, cb, po, codes)
+
+
+@pytest.mark.parametrize("over,status,needle", [
+    (dict(struct_size=8), _abi.ERR_INVALID_INPUT, "struct_size"),
+    (dict(nbits=4), _abi.ERR_NOT_SUPPORTED, "4-bit"),
+    (dict(nbits=7), _abi.ERR_INVALID_INPUT, "num_bits"),
+    (dict(m=3), _abi.ERR_INVALID_INPUT, "divisible"),
+    (dict(metric=9), _abi.ERR_INVALID_INPUT, "metric"),
+    (dict(n_rows=5), _abi.ERR_INVALID_INPUT, "part_offsets"),
+    (dict(shard_count=2, shard_rank=2), _abi.ERR_INVALID_INPUT, "shard_rank"),
+    (dict(m=200, dim=1600), _abi.ERR_NOT_SUPPORTED, "LDS"),
+])
+def test_index_open_rejects_bad_descriptors(L, over, status, needle):
+    d, keep = _desc(**over)
+    h = C.c_void_p()
+    assert L.mi355_index_open(C.byref(d), C.byref(h)) == status
+    assert needle in _lib.last_error()
+    assert not h.value
+
+
+def test_open_without_gpu_fails_loudly(L):
+    """No CPU fallback: on a box without a device the open is a Runtime error."""
+    if lancedb_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    d, keep = _desc()
+    h = C.c_void_p()
+    assert L.mi355_index_open(C.byref(d), C.byref(h)) == _abi.ERR_RUNTIME
+    assert "no HIP device" in _lib.last_error() and "no CPU fallback" in _lib.last_error()
+    with pytest.raises(lancedb_amd.EngineError):
+        lancedb_amd.FlatIndex(np.zeros((4, 4), np.float32))
+
+
+def test_shard_plan_matches_oracle(L, oracle):
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 500, size=300)
+    po = np.zeros(301, np.uint64)
+    po[1:] = np.cumsum(lens)
+    for shards in (1, 2, 3, 8):
+        got = lancedb_amd.shard_plan(po, shards)
+        assert (got == oracle.shard_plan(po, shards)).all()
+        loads = np.array([lens[got == s].sum() for s in range(shards)])
+        assert loads.max() - loads.min() <= lens.max()
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.lib()

@@ -1,0 +1,247 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): returned row ids bit-exact, distances within
+1e-4 relative.  The kernels follow the oracle's arithmetic contract, so the
+distances are in fact compared for exact equality wherever the chain order is
+fixed by the contract.
+"""
+import numpy as np
+import pytest
+
+import lancedb_amd
+from lancedb_amd import _abi
+from oracle import train
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north_star tolerance on distances
+
+
+def _both(oracle, s, metric="l2", raw=None, layout=_abi.CODES_ROW_MAJOR, codes=None):
+    codes = s["codes"] if codes is None else codes
+    g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], codes, s.get("row_ids"),
+                               raw_vectors=raw, metric=metric, codes_layout=layout)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], codes, s.get("row_ids"),
+                           raw_vectors=raw, metric=metric, codes_layout=layout)
+    return g, o
+
+
+def _assert_same(got, exp, exact_dist=True):
+    ids, dist, cnt, st = exp
+    assert st == 0
+    assert (got.counts == cnt).all()
+    assert (got.rowids == ids).all()
+    if exact_dist:
+        assert (got.distances == dist).all()
+    else:
+        fin = np.isfinite(dist)
+        np.testing.assert_allclose(got.distances[fin], dist[fin], rtol=RTOL, atol=0)
+        assert (got.distances[~fin] == dist[~fin]).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+@pytest.mark.parametrize("shape", [(5000, 32, 16, 8), (20000, 64, 64, 16), (3000, 24, 7, 3)])
+def test_ivfpq_matches_oracle(oracle, metric, shape):
+    n, dim, nlist, m = shape
+    s = train.synthetic_index(n, dim, nlist, m, seed=n + m, empty_parts=min(2, nlist // 4))
+    g, o = _both(oracle, s, metric)
+    q = np.random.default_rng(3).normal(size=(9, dim)).astype(np.float32)
+    for nprobe in (1, max(1, nlist // 4), nlist):
+        for k in (1, 10, 70):
+            _assert_same(g.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe),
+                         o.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe))
+
+
+def test_ivfpq_c3_shaped_partition_sizes(oracle):
+    """dim 768 / m 96 (the C3 sub-vector shape) with partitions long enough to
+    exercise the 16-rows-per-thread path, several slices and ragged tails."""
+    s = train.synthetic_index(120000, 768, 8, 96, seed=5, skew=0.8)
+    g, o = _both(oracle, s)
+    q = (s["centroids"][:6] + np.random.default_rng(1).normal(0, 0.5, size=(6, 768))).astype(np.float32)
+    _assert_same(g.search(q, k=10, nprobe_min=4, nprobe_max=4), o.search(q, k=10, nprobe_min=4, nprobe_max=4))
+    g.configure(slice_rows=4096)
+    _assert_same(g.search(q, k=100, nprobe_min=8, nprobe_max=8), o.search(q, k=100, nprobe_min=8, nprobe_max=8))
+    st = g.stats()
+    assert st["vectors_scanned"] == o.last_vectors_scanned
+    assert st["code_bytes_scanned"] == o.last_vectors_scanned * 96
+
+
+def test_ivfpq_trained_index_with_refine_and_recall(oracle):
+    rng = np.random.default_rng(21)
+    cent = rng.normal(size=(64, 64)).astype(np.float32) * 3
+    x = (cent[rng.integers(0, 64, size=30000)] + rng.normal(size=(30000, 64))).astype(np.float32)
+    for metric in ("l2", "cosine"):
+        t = train.train_ivfpq(x, nlist=32, m=16, metric=metric, iters=5)
+        g, o = _both(oracle, t, metric, raw=t["raw"])
+        q = (cent[rng.integers(0, 64, size=32)] + rng.normal(size=(32, 64))).astype(np.float32)
+        _assert_same(g.search(q, k=10, nprobe_min=8, nprobe_max=8), o.search(q, k=10, nprobe_min=8, nprobe_max=8))
+        got = g.search(q, k=10, nprobe_min=8, nprobe_max=8, refine_factor=5)
+        _assert_same(got, o.search(q, k=10, nprobe_min=8, nprobe_max=8, refine_factor=5))
+        truth, _, _, _ = oracle.flat_search(x, q, k=10, metric=_abi.METRIC_NAMES[metric])
+        recall = np.mean([len(set(truth[i]) & set(got.rowids[i])) / 10 for i in range(32)])
+        assert recall > 0.8
+
+
+def test_ivfpq_ties_duplicates_and_ranges(oracle):
+    """Collisions: every row of a partition has the same code -> identical
+    distances; the order must come from the row id alone."""
+    s = train.synthetic_index(6000, 32, 8, 8, seed=2)
+    s["codes"][:] = s["codes"][0]
+    s["row_ids"] = np.random.default_rng(0).permutation(6000).astype(np.uint64) + (1 << 40)
+    g, o = _both(oracle, s)
+    q = np.random.default_rng(4).normal(size=(4, 32)).astype(np.float32)
+    _assert_same(g.search(q, k=25, nprobe_min=3, nprobe_max=3), o.search(q, k=25, nprobe_min=3, nprobe_max=3))
+    # distance_range [lower, upper) on a normal index
+    s2 = train.synthetic_index(8000, 32, 8, 8, seed=9)
+    g2, o2 = _both(oracle, s2)
+    ids, dist, cnt, _ = o2.search(q, k=20, nprobe_min=8, nprobe_max=8)
+    lo, hi = float(dist[0, 3]), float(dist[0, 12])
+    kw = dict(k=20, nprobe_min=8, nprobe_max=8, lower_bound=lo, upper_bound=hi)
+    got = g2.search(q, **kw)
+    _assert_same(got, o2.search(q, **kw))
+    assert got.counts[0] == 9 and got.distances[0, 0] == lo and (got.distances[0, :9] < hi).all()
+    # NaN query -> NULL distances -> no rows
+    qn = q.copy()
+    qn[1, 5] = np.nan
+    _assert_same(g2.search(qn, k=5, nprobe_min=2, nprobe_max=2), o2.search(qn, k=5, nprobe_min=2, nprobe_max=2))
+
+
+def test_ivfpq_small_and_ragged(oracle):
+    # k larger than the index, empty partitions, nprobe > nlist, identity row ids
+    s = train.synthetic_index(37, 8, 4, 2, seed=1, empty_parts=1)
+    del s["row_ids"]
+    g, o = _both(oracle, s)
+    q = np.zeros((2, 8), np.float32)
+    _assert_same(g.search(q, k=64, nprobe_min=9, nprobe_max=9), o.search(q, k=64, nprobe_min=9, nprobe_max=9))
+    # maximum_nprobes expansion only for queries that come back short
+    _assert_same(g.search(q, k=30, nprobe_min=1, nprobe_max=4), o.search(q, k=30, nprobe_min=1, nprobe_max=4))
+    _assert_same(g.search(q, k=30, nprobe_min=1, nprobe_max=None), o.search(q, k=30, nprobe_min=1, nprobe_max=None))
+    # k = 0 and zero queries
+    r = g.search(q, k=0, nprobe_min=1, nprobe_max=1)
+    assert (r.counts == 0).all()
+    # lance's transposed code layout gives identical results
+    t = train.to_part_transposed(s["codes"], s["part_offsets"])
+    g2, o2 = _both(oracle, s, layout=_abi.CODES_PART_TRANSPOSED, codes=t)
+    _assert_same(g2.search(q, k=10, nprobe_min=4, nprobe_max=4), o.search(q, k=10, nprobe_min=4, nprobe_max=4))
+
+
+def test_ivfpq_errors_mirror_reference(oracle):
+    s = train.synthetic_index(500, 8, 4, 2, seed=1)
+    g, _ = _both(oracle, s)
+    q = np.zeros((1, 8), np.float32)
+    with pytest.raises(lancedb_amd.InvalidInput, match="minimum_nprobes must be greater than 0"):
+        g.search(q, k=5, nprobe_min=0, nprobe_max=4)
+    with pytest.raises(lancedb_amd.InvalidInput, match="maximum_nprobes must be greater than or equal"):
+        g.search(q, k=5, nprobe_min=5, nprobe_max=4)
+    with pytest.raises(lancedb_amd.InvalidInput, match="distance type"):
+        g.search(q, k=5, metric=_abi.METRIC_COSINE)
+    with pytest.raises(lancedb_amd.InvalidInput, match="refine_factor"):
+        g.search(q, k=5, refine_factor=2)
+    with pytest.raises(lancedb_amd.NotSupported):
+        g.search(q, k=300)
+
+
+def test_sharded_handles_merge_to_unsharded_result(oracle):
+    import torch
+    s = train.synthetic_index(40000, 32, 64, 8, seed=13, skew=0.9)
+    q = np.random.default_rng(6).normal(size=(33, 32)).astype(np.float32)
+    _, o = _both(oracle, s)
+    exp = o.search(q, k=10, nprobe_min=16, nprobe_max=16)
+    for shards in (2, 8):
+        parts = []
+        rows = 0
+        for r in range(shards):
+            g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"],
+                                       s["row_ids"], shard_count=shards, shard_rank=r)
+            rows += g.info()[0]
+            parts.append(g.search(q, k=10, nprobe_min=16, nprobe_max=16))
+        assert rows == 40000
+        dev = torch.device("cuda:0")
+        ids = torch.stack([torch.from_numpy(p.rowids.astype(np.int64)) for p in parts]).to(dev)
+        dist = torch.stack([torch.from_numpy(p.distances) for p in parts]).to(dev)
+        cnt = torch.stack([torch.from_numpy(p.counts.astype(np.int32)) for p in parts]).to(dev)
+        mi, md, mc = lancedb_amd.merge_topk(ids, dist, cnt, 10, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert (mi.cpu().numpy().astype(np.uint64) == exp[0]).all()
+        assert (md.cpu().numpy() == exp[1]).all()
+        assert (mc.cpu().numpy().astype(np.uint32) == exp[2]).all()
+
+
+def test_device_resident_io_and_device_index(oracle):
+    import torch
+    dev = torch.device("cuda:0")
+    s = train.synthetic_index(30000, 64, 16, 8, seed=3)
+    _, o = _both(oracle, s)
+    g = lancedb_amd.IvfPqIndex(torch.from_numpy(s["centroids"]).to(dev), torch.from_numpy(s["codebook"]).to(dev),
+                               s["part_offsets"], torch.from_numpy(s["codes"]).to(dev),
+                               torch.from_numpy(s["row_ids"].astype(np.int64)).to(dev))
+    q = np.random.default_rng(2).normal(size=(17, 64)).astype(np.float32)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    r = g.search(torch.from_numpy(q).to(dev), k=10, nprobe_min=4, nprobe_max=4)
+    torch.cuda.synchronize()
+    exp = o.search(q, k=10, nprobe_min=4, nprobe_max=4)
+    assert (r.rowids.cpu().numpy().astype(np.uint64) == exp[0]).all()
+    assert (r.distances.cpu().numpy() == exp[1]).all()
+
+
+# ------------------------------------------------------------------ flat ----
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_flat_matches_oracle(oracle, metric):
+    rng = np.random.default_rng(8)
+    v = rng.normal(size=(70000, 48)).astype(np.float32)
+    rid = rng.permutation(70000).astype(np.uint64)
+    q = rng.normal(size=(5, 48)).astype(np.float32)
+    f = lancedb_amd.FlatIndex(v, rid)
+    mt = _abi.METRIC_NAMES[metric]
+    for k in (1, 10, 100):
+        _assert_same(f.search(q, k=k, metric=mt), oracle.flat_search(v, q, k=k, row_ids=rid, metric=mt))
+    # half-open range and bf16 / f16 columns
+    ids, dist, _, _ = oracle.flat_search(v, q, k=10, row_ids=rid, metric=mt)
+    kw = dict(k=10, metric=mt, lower_bound=float(dist[0, 2]), upper_bound=float(dist[0, 6]))
+    _assert_same(f.search(q, **kw), oracle.flat_search(v, q, row_ids=rid, **kw))
+    bf = (v[:5000].view(np.uint32) >> 16).astype(np.uint16)
+    fb = lancedb_amd.FlatIndex(bf, dtype=_abi.DTYPE_BF16)
+    _assert_same(fb.search(q, k=10, metric=mt), oracle.flat_search(bf, q, k=10, dtype=_abi.DTYPE_BF16, metric=mt))
+    h = v[:5000].astype(np.float16).view(np.uint16)
+    fh = lancedb_amd.FlatIndex(h, dtype=_abi.DTYPE_F16)
+    _assert_same(fh.search(q, k=10, metric=mt), oracle.flat_search(h, q, k=10, dtype=_abi.DTYPE_F16, metric=mt))
+
+
+def test_flat_reference_goldens_on_gpu():
+    """The reference's own flat-search expectations, run through the HIP path."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "flat_reference_cases.json")))
+    for case in gold["cases"]:
+        v = np.asarray(case["vectors"], dtype=np.float32)
+        f = lancedb_amd.FlatIndex(v)
+        r = f.search(np.asarray(case["query"], np.float32), k=case["k"], metric=_abi.METRIC_NAMES[case["metric"]])
+        n = min(case["k"], len(v))
+        assert r.counts[0] == n and r.rowids[0, :n].tolist() == case["expect_rowids"], case["name"]
+        if "expect_dist" in case:
+            np.testing.assert_allclose(r.distances[0, :n], case["expect_dist"], rtol=0, atol=case["atol"])
+
+
+def test_c1_config_flat_100k_x_128(oracle):
+    """BASELINE.json configs[0]: flat L2, 100k x 128 f32, one query."""
+    rng = np.random.default_rng(0x1A2CE)
+    v = rng.random(size=(100_000, 128), dtype=np.float32)
+    q = rng.random(size=(1, 128), dtype=np.float32)
+    f = lancedb_amd.FlatIndex(v)
+    _assert_same(f.search(q, k=10), oracle.flat_search(v, q, k=10))
+
+
+def test_vector_table_mirror_end_to_end(oracle):
+    s = train.synthetic_index(9000, 16, 8, 4, seed=4)
+    g, o = _both(oracle, s)
+    raw = np.random.default_rng(0).normal(size=(9000, 16)).astype(np.float32)
+    t = lancedb_amd.VectorTable(index=g, flat=lancedb_amd.FlatIndex(raw))
+    q = np.random.default_rng(1).normal(size=(2, 16)).astype(np.float32)
+    out = t.vector_search(q[0]).nprobes(4).limit(5).offset(2).execute()
+    exp = o.search(q[:1], k=7, nprobe_min=4, nprobe_max=4)
+    assert out["_rowid"].tolist() == exp[0][0, 2:7].tolist() and "query_index" not in out
+    multi = t.vector_search(q).nprobes(4).limit(3).execute()  # table/query.rs:334-381
+    assert multi["query_index"].tolist() == [0, 0, 0, 1, 1, 1]
+    flat = t.vector_search(q[1]).bypass_vector_index().limit(4).execute()
+    fi, fd, _, _ = oracle.flat_search(raw, q[1:], k=4)
+    assert flat["_rowid"].tolist() == fi[0].tolist() and (flat["_distance"] == fd[0]).all()

@@ -17,8 +17,9 @@ _SOURCES = [os.path.join(_PKG, "csrc", f) for f in
             ("mi355_ann.hip", "kernels_ivfpq.h", "kernels_flat.h", "kernels_group.h", "device_common.h")]
 _HEADER = os.path.join(ROOT, "include", "mi355_ann.h")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-shared", "-Wall", "-Wno-unused-function"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-function"]
 
 _lib = None
 
@@ -67,6 +68,34 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def _bind_hip_runtime():
+    """One HIP runtime per process.  libmi355_ann.so needs `libamdhip64.so.7`.
+    A PyTorch-ROCm wheel ships its own copy with that SONAME but loads it under
+    the name `libamdhip64.so`, so if the engine pulled in /opt/rocm's copy first
+    a later `import torch` would start a SECOND runtime and fail with "No HIP
+    GPUs are available".  When torch is installed (bench.py / torch.distributed
+    plumbing), pre-load its copy so the engine's NEEDED entry resolves to it by
+    SONAME; otherwise the system runtime is used.  MI355_HIP_RUNTIME=system opts out."""
+    if os.environ.get("MI355_HIP_RUNTIME", "auto") == "system":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch already loaded its runtime; the SONAME match reuses it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """The loaded C-ABI library.  Raises if it has not been built (never falls
     back to anything else)."""
@@ -76,6 +105,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  The MI355X engine has no CPU fallback.")
+        _bind_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.mi355_abi_version.restype = C.c_uint32
         for name in _abi.EXPORTED_SYMBOLS:

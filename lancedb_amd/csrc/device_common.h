@@ -19,6 +19,13 @@ struct Cand {  // 16 B candidate record kept between scan -> merge -> refine
 
 #define CAND_EMPTY_POS 0xFFFFFFFFu
 
+// Correctly rounded sqrt / divide.  NOT __fsqrt_rn / __fdiv_rn: without
+// OCML_BASIC_ROUNDED_OPERATIONS hipcc maps __fsqrt_rn to the approximate native
+// sqrt (__clang_hip_math.h).  sqrtf() and '/' are IEEE under
+// -fhip-fp32-correctly-rounded-divide-sqrt (on by default, set explicitly in the build).
+__device__ __forceinline__ float ieee_sqrtf(float x) { return sqrtf(x); }
+__device__ __forceinline__ float ieee_divf(float a, float b) { return a / b; }
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }

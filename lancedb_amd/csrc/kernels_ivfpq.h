@@ -43,10 +43,10 @@ __global__ void k_prep_queries(const float* __restrict__ q, uint32_t nq, uint32_
   float acc = 0.f;
   for (uint32_t d = 0; d < dim; ++d) acc = __fmaf_rn(src[d], src[d], acc);
   if (metric == MI355_METRIC_COSINE) {
-    float nrm = __fsqrt_rn(acc);
+    float nrm = ieee_sqrtf(acc);
     float acc2 = 0.f;
     for (uint32_t d = 0; d < dim; ++d) {
-      float v = __fdiv_rn(src[d], nrm);
+      float v = ieee_divf(src[d], nrm);
       dst[d] = v;
       acc2 = __fmaf_rn(v, v, acc2);
     }
@@ -331,7 +331,13 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   const uint64_t grow0 = ix.grow0[p];
   typedef typename CodeVec<VPT>::type cvec;
 
-  for (uint32_t i0 = v0 + tid * VPT; i0 < v1; i0 += NTHREADS * VPT) {
+  // The trip count is block-uniform: the body uses wave collectives (ballot,
+  // shuffles), so lanes past the end of the slice stay in the loop, re-read the
+  // slice's first rows (always mapped) and are masked out of the top-k.
+  for (uint32_t base = v0; base < v1; base += NTHREADS * VPT) {
+    const uint32_t i0r = base + tid * VPT;
+    const bool act = i0r < v1;
+    const uint32_t i0 = act ? i0r : v0;
     float acc[VPT];
 #pragma unroll
     for (int e = 0; e < VPT; ++e) acc[e] = 0.f;
@@ -349,11 +355,11 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
       acc[e] = finalize_dist(acc[e], ix.metric, ix.m);
       any |= acc[e] <= top.thr_d;
     }
-    if (__any(any)) {
+    if (__any(any && act)) {
 #pragma unroll
       for (int e = 0; e < VPT; ++e) {
-        uint32_t i = i0 + e;
-        bool ok = i < v1 && acc[e] <= top.thr_d && in_range(acc[e], a.range);
+        uint32_t i = i0r + e;
+        bool ok = act && i < v1 && acc[e] <= top.thr_d && in_range(acc[e], a.range);
         if (__any(ok)) {
           uint64_t id = 0;
           if (ok) id = ix.row_ids ? ix.row_ids[lrow0 + i] : grow0 + i;
@@ -494,7 +500,7 @@ __device__ __forceinline__ float exact_distance(const float* __restrict__ q, con
     vv = __fmaf_rn(v, v, vv);
   }
   if (metric == MI355_METRIC_DOT) return 1.0f - qv;
-  return 1.0f - __fdiv_rn(qv, __fsqrt_rn(qq) * __fsqrt_rn(vv));
+  return 1.0f - ieee_divf(qv, ieee_sqrtf(qq) * ieee_sqrtf(vv));
 }
 
 // Refine (query.rs:1313-1317): exact distance for the kk approximate winners,

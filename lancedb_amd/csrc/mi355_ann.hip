@@ -591,8 +591,11 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
   uint32_t slice = ix->slice_rows ? ix->slice_rows : std::max(nt * vpt, 16384u);
   slice = (slice + 15u) & ~15u;
   const uint32_t n_slices = std::max(1u, (ix->max_len + slice - 1) / slice);
-  const size_t lds = (size_t)ix->m * 1024 + (size_t)ix->dim * 4;
-  if ((size_t)(nt / 64) * pl.kk * sizeof(Cand) > (size_t)ix->m * 1024)
+  // LDS: distance table + residual; the same area later stages the per-wave
+  // top-k lists for the in-block merge
+  const size_t lds = std::max((size_t)ix->m * 1024 + (size_t)ix->dim * 4,
+                              (size_t)(nt / 64) * pl.kk * sizeof(Cand));
+  if (lds > 160u * 1024)
     return fail(MI355_ERR_NOT_SUPPORTED, "k*refine_factor=%u too large for the in-LDS merge", pl.kk);
 
   // chunk the batch so the workspace stays bounded

@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec of the IVF-PQ search hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+            --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Workload (BASELINE.json `metric`, configs[2] = C3): IVF-PQ 100 M x 768, nlist
+4096, PQ m = 96 x 8 bit, nprobe 64, k 10, L2.  A *step* is one pass of the whole
+search path (coarse quantiser -> probe select -> LUT build + ADC scan + top-k ->
+merge) over one batch of `--batch` queries whose vectors are already resident
+in HBM; results stay in HBM.  value = queries / second over all N GPUs.
+
+Synthetic data: the index cannot be trained from 307 GB of raw
+vectors, so centroids ~ N(0,1), codebook ~ N(0,0.25), uniform u8 codes,
+log-normally skewed partition lengths (sigma 0.5) and a random row-id
+permutation are generated on the device with seed 0x1A2CE; queries are
+centroid[random] + N(0, 0.25).  PyTorch is used only for device memory, the RNG
+and torch.distributed; every timed kernel is the engine's own HIP code behind
+the C ABI.
+
+N > 1 shards the IVF partition list (greedy bytes-balanced plan) with the coarse
+quantiser replicated; per step every rank scans the probed partitions it owns,
+then ONE all-gather of the per-shard top-k candidates (RCCL over xGMI) and a
+k-way merge on every rank.  The index size is fixed, so scaling is "strong".
+
+One JSON line on rank 0, with `roofline` (dominant kernel = the ADC scan, HIP
+events recorded on the search stream inside the timed region) and, at N = 1,
+`cpu_baseline` (the C oracle on a bounded sample of the same queries, also used
+as a full-size parity check).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 0x1A2CE
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=2048, help="queries per step")
+    ap.add_argument("--n-rows", type=int, default=100_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--m", type=int, default=96)
+    ap.add_argument("--nprobe", type=int, default=64)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--skew", type=float, default=0.5, help="sigma of the log-normal partition-length skew")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--scan-variant", type=int, default=0)
+    ap.add_argument("--slice-rows", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import lancedb_amd
+    from lancedb_amd import _abi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, dim, nlist, m = a.n_rows, a.dim, a.nlist, a.m
+    dsub = dim // m
+    # ---- synthetic index, identical on every rank (same seed, same device type)
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED)
+    centroids = torch.randn((nlist, dim), generator=g, device=dev, dtype=torch.float32)
+    codebook = torch.randn((m, 256, dsub), generator=g, device=dev, dtype=torch.float32) * 0.5
+    rng = np.random.default_rng(SEED)
+    w = np.exp(rng.normal(0.0, a.skew, size=nlist))
+    lens = rng.multinomial(n, w / w.sum())
+    part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
+    part_offsets[1:] = np.cumsum(lens)
+    codes = torch.randint(0, 256, (n * m,), generator=g, device=dev, dtype=torch.uint8)
+    row_ids = torch.randperm(n, generator=g, device=dev)  # int64, a permutation of 0..n
+    torch.cuda.synchronize()
+
+    t_open = time.time()
+    # the uniform code bytes are declared to be in lance's per-partition transposed layout
+    ix = lancedb_amd.IvfPqIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
+                                codes_layout=_abi.CODES_PART_TRANSPOSED, device=local_rank,
+                                shard_count=world, shard_rank=rank)
+    t_open = time.time() - t_open
+    rows_local, parts_local = ix.info()
+
+    want_cpu = rank == 0 and world == 1 and a.cpu_seconds > 0
+    h_codes = h_rowids = None
+    if want_cpu:
+        h_codes = codes.cpu().numpy()
+        h_rowids = row_ids.cpu().numpy().astype(np.uint64, copy=False)
+    h_centroids = centroids.cpu().numpy()
+    h_codebook = codebook.cpu().numpy()
+    del codes, row_ids
+    torch.cuda.empty_cache()
+
+    # ---- query batches (resident in HBM before the timed region)
+    P = 4
+    qpool = []
+    for _ in range(P):
+        pick = torch.randint(0, nlist, (a.batch,), generator=g, device=dev)
+        qpool.append((centroids[pick] + 0.5 * torch.randn((a.batch, dim), generator=g, device=dev)).contiguous())
+    params = _abi.make_params(k=a.k, nprobe_min=a.nprobe, nprobe_max=a.nprobe)
+    B, k = a.batch, a.k
+    out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+           torch.empty((B,), dtype=torch.int32, device=dev))
+    if world > 1:
+        g_ids = torch.empty((world, B, k), dtype=torch.int64, device=dev)
+        g_dist = torch.empty((world, B, k), dtype=torch.float32, device=dev)
+        g_cnt = torch.empty((world, B), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ix.set_stream(stream)  # engine kernels, RCCL and torch share one ordered stream
+    ix.configure(scan_variant=a.scan_variant, slice_rows=a.slice_rows, profile=0)
+
+    def step(i):
+        r = ix.search(qpool[i % P], params, out=out)
+        if world == 1:
+            return r.rowids, r.distances, r.counts
+        dist.all_gather_into_tensor(g_ids, r.rowids)
+        dist.all_gather_into_tensor(g_dist, r.distances)
+        dist.all_gather_into_tensor(g_cnt, r.counts)
+        return lancedb_amd.merge_topk(g_ids, g_dist, g_cnt, k, stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    ix.configure(scan_variant=a.scan_variant, slice_rows=a.slice_rows, profile=2)  # cumulative, non-blocking
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        last = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = ix.stats()
+
+    # roofline of the dominant kernel (ADC scan): algorithmic code bytes per launch
+    launches = max(st["scan_launches"], 1)
+    bytes_per_launch = st["code_bytes_scanned"] / launches
+    us_per_launch = st["us_scan"] / launches
+    stat = torch.tensor([st["code_bytes_scanned"], st["us_scan"], float(launches)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM)  # whole-job bytes / summed kernel time
+    achieved = (float(stat[0]) / float(stat[2])) / (float(stat[1]) / float(stat[2]) * 1e-6) / 1e9 if float(stat[1]) > 0 else 0.0
+    qps = a.batch * a.steps / elapsed
+
+    result = {
+        "metric": "queries/sec @ recall@10, 100M×768 IVF-PQ nprobe=64 k=10",
+        "value": qps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{a.nprobe}_k{a.k}_l2",
+            "batch_queries": a.batch, "n_rows": n, "dim": dim, "nlist": nlist, "m": m, "nprobe": a.nprobe,
+            "k": a.k, "partition_skew_sigma": a.skew, "parallelism": f"ivf_partition_shard{world}",
+            "scan_variant": st["scan_variant"], "rows_on_rank0": rows_local, "partitions_on_rank0": parts_local,
+            "index_open_s": round(t_open, 2),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_scan (LUT build + ADC scan + top-k)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
+            "launches": int(float(stat[2])),
+            "stage_us_per_step": {s: st["us_" + s] / a.steps for s in ("coarse", "select", "scan", "merge")},
+        },
+    }
+
+    if want_cpu:
+        result["cpu_baseline"] = cpu_baseline(a, np, h_centroids, h_codebook, part_offsets, h_codes, h_rowids,
+                                              qpool[(a.steps - 1) % P], last, params)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, np, centroids, codebook, part_offsets, codes, row_ids, d_queries, last, params):
+    """The C oracle (a restatement, kind = "port") on this box's host cores over a
+    bounded sample of the last batch; doubles as the full-size parity check."""
+    from oracle import oracle as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    ox = orc.OracleIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
+                         codes_layout=1, borrow=True)
+    q = d_queries.cpu().numpy()
+    t0 = time.perf_counter()
+    ids0, dist0, cnt0, st = ox.search(q[:cores], params)
+    t_probe = time.perf_counter() - t0
+    n_more = int(max(0, min(len(q) - cores, (a.cpu_seconds - t_probe) / max(t_probe, 1e-3) * cores)))
+    n_more -= n_more % cores
+    t1 = time.perf_counter()
+    if n_more:
+        ids1, dist1, cnt1, _ = ox.search(q[cores:cores + n_more], params)
+    t_more = time.perf_counter() - t1
+    nq = cores + n_more
+    ids = np.concatenate([ids0, ids1]) if n_more else ids0
+    dst = np.concatenate([dist0, dist1]) if n_more else dist0
+    g_ids = last[0][:nq].cpu().numpy().astype(np.uint64)
+    g_dist = last[1][:nq].cpu().numpy()
+    rel = float(np.max(np.abs(g_dist - dst) / np.maximum(np.abs(dst), 1e-30)))
+    return {
+        "value": nq / (t_probe + t_more), "unit": "queries/s", "cores": cores, "kind": "port",
+        "sample": f"{nq} queries of the last timed batch, one query per thread (OpenMP), "
+                  f"{t_probe + t_more:.1f} s of wall time on {cores} host cores; C restatement of the "
+                  "lance-index IVF-PQ path (oracle/ann_oracle.c, -O3 -mavx2 -mfma), not the reference binary",
+        "parity": {"queries": nq, "rowids_bit_exact": bool((g_ids == ids).all()), "max_rel_distance_error": rel},
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -170,6 +170,8 @@ typedef struct mi355_stats {
   float us_refine;
   float us_total;
   uint32_t scan_variant;       /* which ADC kernel ran (MI355_SCAN_*) */
+  uint32_t scan_launches;      /* timed launch sequences folded into us_* */
+  uint32_t reserved;
 } mi355_stats;
 
 enum {
@@ -194,7 +196,10 @@ int32_t mi355_index_close(mi355_index *index);
 int32_t mi355_index_set_stream(mi355_index *index, void *hip_stream);
 int32_t mi355_index_sync(mi355_index *index);
 /* tuning knobs: MI355_SCAN_* variant, slice length (rows per scan work item,
-   0 = default), profile!=0 records per-stage times into mi355_stats */
+   0 = default) and profiling: 0 = counters only, 1 = also per-stage device
+   times of the LAST search, 2 = counters and times ACCUMULATE over searches
+   until the next configure().  Times come from hipEvents recorded on the search
+   stream with no host synchronisation; they are read back by mi355_last_stats. */
 int32_t mi355_index_configure(mi355_index *index, uint32_t scan_variant,
                               uint32_t slice_rows, uint32_t profile);
 /* rows kept on this handle and how many partitions are non-empty here */
@@ -213,7 +218,8 @@ int32_t mi355_search(mi355_index *index, const float *queries,
                      uint32_t n_queries, const mi355_search_params *params,
                      uint64_t *out_rowids, float *out_dist,
                      uint32_t *out_counts);
-int32_t mi355_last_stats(const mi355_index *index, mi355_stats *out);
+/* waits for the handle's stream, then returns the counters (see profile modes) */
+int32_t mi355_last_stats(mi355_index *index, mi355_stats *out);
 
 /* ---- flat (no index / bypass_vector_index, query.rs:1360-1370) ---------- */
 int32_t mi355_flat_open(const mi355_flat_desc *desc, mi355_flat **out);

@@ -107,6 +107,8 @@ class Stats(C.Structure):
         ("us_refine", C.c_float),
         ("us_total", C.c_float),
         ("scan_variant", C.c_uint32),
+        ("scan_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -256,6 +256,134 @@ struct WaveTopK {
   }
 };
 
+// ---------------------------------------------------------------------------
+// K4 (scan-side): shuffle-free selection for the ADC hot loop.
+//
+//  * wave_kth_smallest_key: exact k-th smallest of the 64 lanes' keys by a
+//    bitwise radix select on ballots (32 x {v_cmp, s_bcnt1}; no LDS, no DPP).
+//    Applied to each lane's minimum over its rows it yields a threshold T' with
+//    at least k rows <= T' in this wave, so the k best rows of the wave survive.
+//  * WaveList: per-wave candidate list in LDS, 8 B per entry (distance, row
+//    position).  Rows passing the threshold are appended with a ballot prefix;
+//    when the list is full it is compacted to its exact kk best by rank
+//    counting (every lane ranks its entries against a broadcast sweep of the
+//    list).  Ties on the distance are broken by the row id, fetched lazily.
+// Correct for any input (all-equal distances just compact more often);
+// expected work per 1024 rows is ~kk appends and no compaction.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_sort_key(float d);
+
+__device__ __forceinline__ float f32_from_sort_key(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+
+// k is 1-based and must be <= 64; lanes that hold nothing pass key 0xFFFFFFFF
+__device__ __forceinline__ uint32_t wave_kth_smallest_key(uint32_t key, uint32_t k) {
+  uint64_t alive = ~0ull;
+  uint32_t prefix = 0, need = k;
+#pragma unroll
+  for (int bit = 31; bit >= 0; --bit) {
+    uint64_t zero = __ballot(((key >> bit) & 1u) == 0u) & alive;
+    uint32_t c = (uint32_t)__popcll((unsigned long long)zero);
+    if (c >= need) {
+      alive = zero;
+    } else {
+      need -= c;
+      alive &= ~zero;
+      prefix |= 1u << bit;
+    }
+  }
+  return prefix;
+}
+
+struct ListEnt {
+  float d;
+  uint32_t pos;
+};
+
+template <int R>  // capacity = 64 * R entries
+struct WaveList {
+  ListEnt* list;  // LDS
+  uint32_t cnt;   // wave-uniform
+  uint32_t kk;
+  float t_run;    // distance of the kk-th best row seen so far (+inf until then)
+
+  __device__ __forceinline__ void init(ListEnt* lds, uint32_t kk_) {
+    list = lds;
+    cnt = 0;
+    kk = kk_;
+    t_run = __builtin_huge_valf();
+  }
+
+  // keep the kk best entries, sorted by (distance, id); idof(pos) -> row id
+  template <typename IdOf>
+  __device__ __forceinline__ void compact(int lane, IdOf idof) {
+    __threadfence_block();
+    ListEnt mine[R];
+    bool val[R];
+    uint32_t rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      uint32_t slot = (uint32_t)(r * MI355_WAVE + lane);
+      val[r] = slot < cnt;
+      mine[r].d = __builtin_huge_valf();
+      mine[r].pos = CAND_EMPTY_POS;
+      if (val[r]) mine[r] = list[slot];
+      rank[r] = 0;
+    }
+    for (uint32_t j = 0; j < cnt; ++j) {
+      ListEnt c = list[j];  // same address in every lane: LDS broadcast
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        bool lt = c.d < mine[r].d;
+        if (val[r] && c.d == mine[r].d && c.pos != mine[r].pos) lt = idof(c.pos) < idof(mine[r].pos);
+        rank[r] += (val[r] && lt) ? 1u : 0u;
+      }
+    }
+    __threadfence_block();
+    float kth = __builtin_huge_valf();
+    bool has_kth = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (val[r] && rank[r] < kk) list[rank[r]] = mine[r];
+      if (val[r] && rank[r] == kk - 1) {
+        has_kth = true;
+        kth = mine[r].d;
+      }
+    }
+    uint64_t mk = __ballot(has_kth);
+    if (mk) t_run = fminf(t_run, readlane_f(kth, __ffsll((unsigned long long)mk) - 1));
+    cnt = min(cnt, kk);
+    __threadfence_block();
+  }
+
+  // Every lane offers at most one row.  `thr` is the caller's current
+  // admission threshold (updated when a compaction tightens it).
+  template <typename IdOf>
+  __device__ __forceinline__ void append(bool ok, float d, uint32_t pos, float& thr, int lane,
+                                         IdOf idof) {
+    uint64_t mask = __ballot(ok);
+    if (!mask) return;
+    uint32_t n = (uint32_t)__popcll((unsigned long long)mask);
+    if (cnt + n > (uint32_t)(R * MI355_WAVE)) {
+      compact(lane, idof);
+      thr = fminf(thr, t_run);
+      ok = ok && d <= thr;
+      mask = __ballot(ok);
+      n = (uint32_t)__popcll((unsigned long long)mask);
+    }
+    if (ok) {
+      uint32_t idx = cnt + (uint32_t)__popcll((unsigned long long)(mask & ((1ull << lane) - 1ull)));
+      ListEnt e;
+      e.d = d;
+      e.pos = pos;
+      list[idx] = e;
+    }
+    cnt += n;
+  }
+};
+
 // order-preserving u32 key of an f32 (NaN last; -0 == +0)
 __device__ __forceinline__ uint32_t f32_sort_key(float d) {
   if (d != d) return 0xFFFFFFFFu;

@@ -259,6 +259,7 @@ struct ScanArgs {
   uint32_t kk;
   RangeFilter range;
   Cand* cand;               // [nq, nprobe, n_slices, kk]
+  uint32_t dbg;             // dev ablation mask (MI355_DBG_SKIP): 1 LUT build, 2 ADC loop, 4 top-k
 };
 
 __device__ __forceinline__ float finalize_dist(float acc, uint32_t metric, uint32_t m) {
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
     for (uint32_t d = tid; d < ix.dim; d += NTHREADS) res[d] = q[d] - c[d];
   }
   __syncthreads();
-  {
+  if (!(a.dbg & 1u)) {
     const uint32_t dsub = ix.dsub;
     for (uint32_t e = tid; e < ix.m * 256u; e += NTHREADS) {
       const uint32_t j = e >> 8;
@@ -322,19 +323,25 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   }
   __syncthreads();
 
-  // ---- K3: ADC scan + K4 wave top-k ---------------------------------------
-  WaveTopK<KPL> top;
-  top.init(a.kk, lane);
+  // ---- K3: ADC scan + K4 shuffle-free selection ----------------------------
+  constexpr int LR = KPL == 1 ? 2 : 5;  // per-wave list capacity 128 (kk<=64) or 320 (kk<=256)
+  ListEnt* lists = (ListEnt*)(smem + (size_t)ix.m * 1024 + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
+  uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);
+  WaveList<LR> wl;
+  wl.init(lists + (size_t)wid * LR * MI355_WAVE, a.kk);
   const uint8_t* codes = ix.codes + ix.code_off[p];
   const uint32_t stride = ix.pstride[p];
   const uint32_t lrow0 = ix.lrow0[p];
   const uint64_t grow0 = ix.grow0[p];
+  const uint64_t* rid = ix.row_ids;
+  auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
+  const bool ranged = a.range.has_lower || a.range.has_upper;
   typedef typename CodeVec<VPT>::type cvec;
 
-  // The trip count is block-uniform: the body uses wave collectives (ballot,
-  // shuffles), so lanes past the end of the slice stay in the loop, re-read the
-  // slice's first rows (always mapped) and are masked out of the top-k.
-  for (uint32_t base = v0; base < v1; base += NTHREADS * VPT) {
+  // The trip count is block-uniform: the body uses wave collectives (ballots),
+  // so lanes past the end of the slice stay in the loop, re-read the slice's
+  // first rows (always mapped) and are masked out of the selection.
+  for (uint32_t base = v0; base < v1 && !(a.dbg & 2u); base += NTHREADS * VPT) {
     const uint32_t i0r = base + tid * VPT;
     const bool act = i0r < v1;
     const uint32_t i0 = act ? i0r : v0;
@@ -349,43 +356,76 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
 #pragma unroll
       for (int e = 0; e < VPT; ++e) acc[e] = acc[e] + t[code_byte<VPT>(cv, e)];
     }
-    bool any = false;
+    if (a.dbg & 4u) {  // ablation: keep the distances live, skip the selection
+      float keep = 0.f;
+#pragma unroll
+      for (int e = 0; e < VPT; ++e) keep += acc[e];
+      if (keep == -1.2345f) out[0].d = keep;
+      continue;
+    }
+    // eligible rows: inside the slice, not NULL, inside the distance range
+    uint32_t elig = 0;
+    float lmin = __builtin_huge_valf();
 #pragma unroll
     for (int e = 0; e < VPT; ++e) {
       acc[e] = finalize_dist(acc[e], ix.metric, ix.m);
-      any |= acc[e] <= top.thr_d;
+      bool ok = act && (i0r + e < v1) && (ranged ? in_range(acc[e], a.range) : acc[e] == acc[e]);
+      elig |= ok ? (1u << e) : 0u;
+      lmin = ok ? fminf(lmin, acc[e]) : lmin;
     }
-    if (__any(any && act)) {
+    // threshold: kk-th smallest lane minimum (>= kk rows of this wave are below it)
+    float thr = wl.t_run;
+    if (a.kk <= MI355_WAVE) {
+      uint32_t tk = wave_kth_smallest_key(elig ? f32_sort_key(lmin) : 0xFFFFFFFFu, a.kk);
+      if (tk < 0xFF800000u) thr = fminf(thr, f32_from_sort_key(tk));  // below +inf's key
+    }
+    bool any = false;
 #pragma unroll
-      for (int e = 0; e < VPT; ++e) {
-        uint32_t i = i0r + e;
-        bool ok = act && i < v1 && acc[e] <= top.thr_d && in_range(acc[e], a.range);
-        if (__any(ok)) {
-          uint64_t id = 0;
-          if (ok) id = ix.row_ids ? ix.row_ids[lrow0 + i] : grow0 + i;
-          top.offer(ok, acc[e], lrow0 + i, id, lane);
-        }
-      }
+    for (int e = 0; e < VPT; ++e) any |= ((elig >> e) & 1u) && acc[e] <= thr;
+    if (__any(any)) {
+#pragma unroll
+      for (int e = 0; e < VPT; ++e)
+        wl.append(((elig >> e) & 1u) && acc[e] <= thr, acc[e], lrow0 + i0r + e, thr, lane, idof);
     }
   }
 
-  // ---- merge the block's waves through the dead LUT area ------------------
+  // ---- block result: exact kk best of all waves' lists, written sorted -----
+  if (wl.cnt > a.kk) wl.compact(lane, idof);
+  if (lane == 0) s_cnt[wid] = wl.cnt;
   __syncthreads();
-  Cand* stage = (Cand*)smem;  // [NW][kk]
-  top.store(stage + (size_t)wid * a.kk, lane);
-  __syncthreads();
-  if (wid == 0) {
-    const uint32_t n = (NW - 1) * a.kk;
-    for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
-      uint32_t t = t0 + lane;
-      Cand c;
-      c.d = 0.f;
-      c.pos = CAND_EMPTY_POS;
-      c.id = 0;
-      if (t < n) c = stage[a.kk + t];
-      top.offer(t < n && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
+  uint32_t total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) total += s_cnt[w];
+  const uint32_t n_out = min(total, a.kk);
+  for (uint32_t g = tid; g < (uint32_t)NW * a.kk; g += NTHREADS) {
+    const uint32_t w = g / a.kk, j = g % a.kk;
+    if (j >= s_cnt[w]) continue;
+    const ListEnt mine = lists[(size_t)w * LR * MI355_WAVE + j];
+    uint32_t rank = 0;
+    for (int w2 = 0; w2 < NW; ++w2) {
+      const ListEnt* l2 = lists + (size_t)w2 * LR * MI355_WAVE;
+      const uint32_t c2 = s_cnt[w2];
+      for (uint32_t j2 = 0; j2 < c2; ++j2) {
+        const ListEnt c = l2[j2];
+        bool lt = c.d < mine.d;
+        if (c.d == mine.d && c.pos != mine.pos) lt = idof(c.pos) < idof(mine.pos);
+        rank += lt ? 1u : 0u;
+      }
     }
-    top.store(out, lane);
+    if (rank < a.kk) {
+      Cand o;
+      o.d = mine.d;
+      o.pos = mine.pos;
+      o.id = idof(mine.pos);
+      out[rank] = o;
+    }
+  }
+  for (uint32_t g = n_out + tid; g < a.kk; g += NTHREADS) {
+    Cand o;
+    o.d = __builtin_huge_valf();
+    o.pos = CAND_EMPTY_POS;
+    o.id = ~0ull;
+    out[g] = o;
   }
 }
 

@@ -87,9 +87,10 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 }
 
 // ---------------------------------------------------------------- handles ---
-struct StageTimer {
-  hipEvent_t ev[8];
-  bool made = false;
+// Per-launch-sequence timestamps, recorded on the search stream without any
+// host synchronisation; elapsed times are read back in mi355_last_stats.
+struct EventSet {
+  hipEvent_t ev[6];
 };
 
 struct mi355_index {
@@ -113,7 +114,7 @@ struct mi355_index {
   // config
   uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
   mi355_stats stats{};
-  StageTimer timer;
+  std::vector<EventSet> ev_free, ev_pending;
 };
 
 struct mi355_flat {
@@ -129,6 +130,9 @@ struct mi355_flat {
   bool has_row_ids = false;
   DevBuf w_q, w_cand, w_ids, w_dist, w_cnt;
 };
+
+static int32_t drain_events(mi355_index* ix, bool discard);
+static void reset_stats(mi355_index* ix);
 
 static IndexView make_view(const mi355_index* ix) {
   IndexView v;
@@ -278,8 +282,9 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->w_probes,  &ix->w_cand, &ix->w_ids,    &ix->w_dist,  &ix->w_pos,
                     &ix->w_cnt,     &ix->w_ids2, &ix->w_dist2,  &ix->w_cnt2,  &ix->w_stat};
   for (DevBuf* b : bufs) b->release();
-  if (ix->timer.made)
-    for (auto& e : ix->timer.ev) (void)hipEventDestroy(e);
+  for (auto* v : {&ix->ev_free, &ix->ev_pending})
+    for (auto& es : *v)
+      for (auto& e : es.ev) (void)hipEventDestroy(e);
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
   delete ix;
   return MI355_OK;
@@ -497,6 +502,11 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   ix->scan_variant = scan_variant;
   ix->slice_rows = (slice_rows + 15u) & ~15u;
   ix->profile = profile;
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ST_TRY(drain_events(ix, true));
+  reset_stats(ix);
+  HIP_TRY(hipMemset(ix->w_stat.p, 0, 64));
   return MI355_OK;
 }
 
@@ -508,10 +518,48 @@ extern "C" int32_t mi355_index_info(const mi355_index* ix, uint64_t* out_rows,
   return MI355_OK;
 }
 
-extern "C" int32_t mi355_last_stats(const mi355_index* ix, mi355_stats* out) {
+// fold the pending timestamps into the stats (waits for the recorded work)
+static int32_t drain_events(mi355_index* ix, bool discard) {
+  for (auto& es : ix->ev_pending) {
+    HIP_TRY(hipEventSynchronize(es.ev[5]));
+    if (!discard) {
+      float us[5];
+      for (int i = 0; i < 5; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, es.ev[i], es.ev[i + 1]));
+        us[i] = ms * 1000.f;
+      }
+      ix->stats.us_coarse += us[0];
+      ix->stats.us_select += us[1];
+      ix->stats.us_scan += us[2];
+      ix->stats.us_merge += us[3];
+      ix->stats.us_refine += us[4];
+      ix->stats.us_total += us[0] + us[1] + us[2] + us[3] + us[4];
+      ix->stats.scan_launches += 1;
+    }
+    ix->ev_free.push_back(es);
+  }
+  ix->ev_pending.clear();
+  return MI355_OK;
+}
+
+static void reset_stats(mi355_index* ix) {
+  ix->stats = mi355_stats{};
+  ix->stats.struct_size = sizeof(mi355_stats);
+}
+
+extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) {
   if (!ix || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
   if (out->struct_size != sizeof(mi355_stats))
     return fail(MI355_ERR_INVALID_INPUT, "mi355_stats.struct_size mismatch");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ST_TRY(drain_events(ix, false));
+  unsigned long long rows = 0;
+  HIP_TRY(hipMemcpy(&rows, ix->w_stat.p, sizeof(rows), hipMemcpyDeviceToHost));
+  ix->stats.vectors_scanned = rows;
+  ix->stats.code_bytes_scanned = rows * ix->m;
   *out = ix->stats;
   out->struct_size = sizeof(mi355_stats);
   return MI355_OK;
@@ -586,17 +634,26 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
 
   // tuning (dev knobs; defaults chosen from the index shape)
   uint32_t nt = env_u32("MI355_SCAN_THREADS", 0), vpt = env_u32("MI355_SCAN_VPT", 0);
-  if (!nt) nt = ix->max_len >= 8192 ? 1024 : ix->max_len >= 2048 ? 512 : 256;
+  if (!nt) nt = pl.kk > 64 ? 256 : ix->max_len >= 8192 ? 1024 : ix->max_len >= 2048 ? 512 : 256;
   if (!vpt) vpt = ix->max_len >= 4 * nt * 4 ? 16 : 4;
-  uint32_t slice = ix->slice_rows ? ix->slice_rows : std::max(nt * vpt, 16384u);
+  // One work item per (query, partition) whenever the batch alone fills the
+  // chip: the distance table is then built once per pair and skewed partitions
+  // cost no empty blocks.  Small batches (latency mode) split partitions into
+  // slices so that >= ~4 work items per CU exist.
+  uint32_t slice = ix->slice_rows;
+  if (!slice) {
+    const uint64_t pairs = (uint64_t)nq * nprobe;
+    uint32_t want = pairs >= 1024 ? 1u : (uint32_t)((1024 + pairs - 1) / std::max<uint64_t>(pairs, 1));
+    slice = std::max((ix->max_len + want - 1) / want, nt * vpt);
+  }
   slice = (slice + 15u) & ~15u;
   const uint32_t n_slices = std::max(1u, (ix->max_len + slice - 1) / slice);
-  // LDS: distance table + residual; the same area later stages the per-wave
-  // top-k lists for the in-block merge
-  const size_t lds = std::max((size_t)ix->m * 1024 + (size_t)ix->dim * 4,
-                              (size_t)(nt / 64) * pl.kk * sizeof(Cand));
+  // LDS: distance table + residual + per-wave candidate lists + wave counters
+  const uint32_t lr = pl.kk <= 64 ? 2 : 5;
+  const size_t lds = (size_t)ix->m * 1024 + (((size_t)ix->dim * 4 + 15) & ~(size_t)15) +
+                     (size_t)(nt / 64) * lr * 64 * 8 + (size_t)(nt / 64) * 4;
   if (lds > 160u * 1024)
-    return fail(MI355_ERR_NOT_SUPPORTED, "k*refine_factor=%u too large for the in-LDS merge", pl.kk);
+    return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds);
 
   // chunk the batch so the workspace stays bounded
   const size_t per_q = (size_t)ix->nlist * 4 + (size_t)nprobe * n_slices * pl.kk * sizeof(Cand);
@@ -616,16 +673,20 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
   }
   unsigned long long* d_stat = ix->w_stat.as<unsigned long long>();
   const bool prof = ix->profile != 0;
-  if (prof && !ix->timer.made) {
-    for (auto& e : ix->timer.ev) HIP_TRY(hipEventCreate(&e));
-    ix->timer.made = true;
-  }
-  float us[6] = {0, 0, 0, 0, 0, 0};
 
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t n = std::min(chunk, nq - q0);
     const float* q = d_q + (size_t)q0 * ix->dim;
-    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[0], st));
+    EventSet es{};
+    if (prof) {
+      if (!ix->ev_free.empty()) {
+        es = ix->ev_free.back();
+        ix->ev_free.pop_back();
+      } else {
+        for (auto& e : es.ev) HIP_TRY(hipEventCreate(&e));
+      }
+      HIP_TRY(hipEventRecord(es.ev[0], st));
+    }
     hipLaunchKernelGGL(k_prep_queries, dim3((n + 63) / 64), dim3(64), 0, st, q, n, ix->dim,
                        ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
     hipLaunchKernelGGL(k_coarse_tile, dim3((ix->nlist + CO_T - 1) / CO_T, (n + CO_T - 1) / CO_T),
@@ -633,11 +694,11 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
                        view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
                        ix->w_coarse.as<float>());
     HIP_TRY(hipGetLastError());
-    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[1], st));
+    if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
     hipLaunchKernelGGL(k_select_probes, dim3(n), dim3(256), 0, st, ix->w_coarse.as<float>(),
                        ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat);
     HIP_TRY(hipGetLastError());
-    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[2], st));
+    if (prof) HIP_TRY(hipEventRecord(es.ev[2], st));
 
     ScanArgs sa;
     sa.ix = view;
@@ -649,8 +710,9 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
     sa.kk = pl.kk;
     sa.range = pl.range;
     sa.cand = ix->w_cand.as<Cand>();
+    sa.dbg = env_u32("MI355_DBG_SKIP", 0);
     ST_TRY(launch_scan_pair(sa, dim3(n_slices, nprobe, n), lds, st, kpl_kk, vpt, nt));
-    if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[3], st));
+    if (prof) HIP_TRY(hipEventRecord(es.ev[3], st));
 
     MergeArgs ma;
     ma.cand = ix->w_cand.as<Cand>();
@@ -664,7 +726,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       ma.out_cnt = d_cnt + q0;
       launch_by_kpl(kpl_k, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
       HIP_TRY(hipGetLastError());
-      if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[4], st));
+      if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
     } else {
       ma.k_out = pl.kk;
       ma.out_ids = ix->w_ids2.as<uint64_t>();
@@ -673,7 +735,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       ma.out_cnt = ix->w_cnt2.as<uint32_t>();
       launch_by_kpl(kpl_kk, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
       HIP_TRY(hipGetLastError());
-      if (prof) HIP_TRY(hipEventRecord(ix->timer.ev[4], st));
+      if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
       RefineArgs ra;
       ra.ix = view;
       ra.q = q;
@@ -691,21 +753,11 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       HIP_TRY(hipGetLastError());
     }
     if (prof) {
-      HIP_TRY(hipEventRecord(ix->timer.ev[5], st));
-      HIP_TRY(hipEventSynchronize(ix->timer.ev[5]));
-      for (int i = 0; i < 5; ++i) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, ix->timer.ev[i], ix->timer.ev[i + 1]));
-        us[i] += ms * 1000.f;
-      }
+      HIP_TRY(hipEventRecord(es.ev[5], st));
+      ix->ev_pending.push_back(es);
     }
   }
-  ix->stats.us_coarse += us[0];
-  ix->stats.us_select += us[1];
-  ix->stats.us_scan += us[2];
-  ix->stats.us_merge += us[3];
-  ix->stats.us_refine += us[4];
-  ix->stats.us_total += us[0] + us[1] + us[2] + us[3] + us[4];
+  ix->stats.n_queries += nq;
   ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
   ix->stats.partitions_probed += (uint64_t)nq * nprobe;
   ix->stats.scan_variant = MI355_SCAN_PAIR;
@@ -754,10 +806,11 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
   auto t_start = std::chrono::steady_clock::now();
-  ix->stats = mi355_stats{};
-  ix->stats.struct_size = sizeof(mi355_stats);
-  ix->stats.n_queries = n_queries;
-  HIP_TRY(hipMemsetAsync(ix->w_stat.p, 0, 64, st));
+  if (ix->profile != 2) {  // 2 = cumulative: counters run until the next configure()
+    ST_TRY(drain_events(ix, true));
+    reset_stats(ix);
+    HIP_TRY(hipMemsetAsync(ix->w_stat.p, 0, 64, st));
+  }
 
   const bool host_io = p->io_mem == MI355_MEM_HOST;
   const float* d_q = queries;
@@ -830,11 +883,7 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
     HIP_TRY(hipMemcpyAsync(out_rowids, d_ids, sizeof(uint64_t) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
-    unsigned long long rows = 0;
-    HIP_TRY(hipMemcpyAsync(&rows, ix->w_stat.p, sizeof(rows), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    ix->stats.vectors_scanned = rows;
-    ix->stats.code_bytes_scanned = rows * ix->m;
     if (p->timeout_ms) {
       auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
       if (ms > (long long)p->timeout_ms)

@@ -138,9 +138,11 @@ class IvfPqIndex(_Handle):
         check(lib().mi355_index_open(C.byref(d), C.byref(self._h)))
         self._keep = []  # the library copied everything it needs
 
-    def configure(self, scan_variant=_abi.SCAN_AUTO, slice_rows=0, profile=False):
+    def configure(self, scan_variant=_abi.SCAN_AUTO, slice_rows=0, profile=0):
+        """profile: 0 counters only, 1 per-stage times of the last search,
+        2 accumulate over searches until the next configure()."""
         check(lib().mi355_index_configure(self._h, C.c_uint32(scan_variant), C.c_uint32(slice_rows),
-                                          C.c_uint32(1 if profile else 0)))
+                                          C.c_uint32(int(profile))))
 
     def set_stream(self, hip_stream):
         check(lib().mi355_index_set_stream(self._h, C.c_void_p(hip_stream or 0)))

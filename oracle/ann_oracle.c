@@ -70,6 +70,7 @@ typedef struct orc_index {
   uint64_t *row_ids;  /* [n_rows] */
   void *raw;          /* [n_rows, dim] or NULL */
   uint32_t raw_dtype;
+  int borrowed;       /* codes_t / row_ids / raw point into caller memory */
 } orc_index;
 
 /* ------------------------------------------------------------------ chains */
@@ -221,14 +222,24 @@ int32_t orc_index_close(orc_index *ix) {
   free(ix->cnorm);
   free(ix->codebook);
   free(ix->part_off);
-  free(ix->codes_t);
-  free(ix->row_ids);
-  free(ix->raw);
+  if (!ix->borrowed) {
+    free(ix->codes_t);
+    free(ix->row_ids);
+    free(ix->raw);
+  }
   free(ix);
   return MI355_OK;
 }
 
+/* borrow != 0: keep pointers to the caller's transposed codes / row ids / raw
+   vectors instead of copying them (bench.py: a 9.6 GB code block). */
+int32_t orc_index_open2(const mi355_index_desc *d, orc_index **out, int borrow);
+
 int32_t orc_index_open(const mi355_index_desc *d, orc_index **out) {
+  return orc_index_open2(d, out, 0);
+}
+
+int32_t orc_index_open2(const mi355_index_desc *d, orc_index **out, int borrow) {
   if (!d || !out || d->struct_size != sizeof(mi355_index_desc))
     return MI355_ERR_INVALID_INPUT;
   if (d->mem != MI355_MEM_HOST) return MI355_ERR_INVALID_INPUT;
@@ -245,7 +256,10 @@ int32_t orc_index_open(const mi355_index_desc *d, orc_index **out) {
     if (d->part_offsets[p + 1] < d->part_offsets[p])
       return MI355_ERR_INVALID_INPUT;
 
+  if (borrow && (d->codes_layout != MI355_CODES_PART_TRANSPOSED || !d->row_ids))
+    return MI355_ERR_INVALID_INPUT;
   orc_index *ix = (orc_index *)calloc(1, sizeof(orc_index));
+  ix->borrowed = borrow;
   ix->dim = d->dim;
   ix->nlist = d->nlist;
   ix->m = d->m;
@@ -265,6 +279,14 @@ int32_t orc_index_open(const mi355_index_desc *d, orc_index **out) {
   memcpy(ix->codebook, d->codebook, sizeof(float) * ncb);
   ix->part_off = (uint64_t *)malloc(sizeof(uint64_t) * (d->nlist + 1));
   memcpy(ix->part_off, d->part_offsets, sizeof(uint64_t) * (d->nlist + 1));
+  if (borrow) {
+    ix->codes_t = (uint8_t *)d->codes;
+    ix->row_ids = (uint64_t *)d->row_ids;
+    ix->raw = (void *)d->raw_vectors;
+    ix->raw_dtype = d->raw_dtype;
+    *out = ix;
+    return MI355_OK;
+  }
   ix->codes_t = (uint8_t *)malloc((size_t)d->n_rows * d->m + 1);
   if (d->codes_layout == MI355_CODES_PART_TRANSPOSED) {
     memcpy(ix->codes_t, d->codes, (size_t)d->n_rows * d->m);

@@ -54,7 +54,7 @@ class OracleIndex:
 
     def __init__(self, centroids, codebook, part_offsets, codes, row_ids=None,
                  raw_vectors=None, metric="l2", codes_layout=_abi.CODES_ROW_MAJOR,
-                 raw_dtype=_abi.DTYPE_F32):
+                 raw_dtype=_abi.DTYPE_F32, borrow=False):
         self.centroids = _f32(centroids)
         self.codebook = _f32(codebook)
         self.part_offsets = np.ascontiguousarray(part_offsets, dtype=np.uint64)
@@ -83,7 +83,7 @@ class OracleIndex:
         self.desc = d
         self.n_rows = d.n_rows
         h = C.c_void_p()
-        st = lib().orc_index_open(C.byref(d), C.byref(h))
+        st = lib().orc_index_open2(C.byref(d), C.byref(h), C.c_int(1 if borrow else 0))
         if st != 0:
             raise ValueError(f"orc_index_open failed with status {st}")
         self._h = h

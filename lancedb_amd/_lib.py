@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libmi355_ann.so")
 _SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-            ("mi355_ann.hip", "kernels_ivfpq.h", "kernels_flat.h", "kernels_group.h", "device_common.h")]
+            ("mi355_ann.hip", "kernels_ivfpq.h", "kernels_flat.h", "device_common.h")]
 _HEADER = os.path.join(ROOT, "include", "mi355_ann.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",

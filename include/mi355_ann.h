@@ -176,8 +176,11 @@ typedef struct mi355_stats {
 
 enum {
   MI355_SCAN_AUTO = 0,
-  MI355_SCAN_PAIR = 1,   /* one work item per (query, partition slice), f32 LUT */
-  MI355_SCAN_GROUP4 = 2  /* partition-major, 4 queries share one code stream */
+  MI355_SCAN_PAIR = 1,   /* generic: one workgroup per (query, partition slice),
+                            [sub-quantiser][code] table, any m */
+  MI355_SCAN_SKEW = 2    /* production: pre-skewed code streams + [code][column]
+                            table (bank-conflict-free gathers), partition-major
+                            work queues per XCD; m in {32,48,64,80,96} */
 };
 
 /* ---- library ------------------------------------------------------------ */
@@ -195,8 +198,10 @@ int32_t mi355_index_close(mi355_index *index);
    restores the handle's own stream */
 int32_t mi355_index_set_stream(mi355_index *index, void *hip_stream);
 int32_t mi355_index_sync(mi355_index *index);
-/* tuning knobs: MI355_SCAN_* variant, slice length (rows per scan work item,
-   0 = default) and profiling: 0 = counters only, 1 = also per-stage device
+/* tuning knobs: MI355_SCAN_* variant (AUTO = the one the index layout was
+   packed for at open; a mismatching explicit choice is INVALID_INPUT), slice
+   length (rows per scan work item of the generic kernel, 0 = default) and
+   profiling: 0 = counters only, 1 = also per-stage device
    times of the LAST search, 2 = counters and times ACCUMULATE over searches
    until the next configure().  Times come from hipEvents recorded on the search
    stream with no host synchronisation; they are read back by mi355_last_stats. */

@@ -31,7 +31,7 @@ CODES_PART_TRANSPOSED = 1
 
 SCAN_AUTO = 0
 SCAN_PAIR = 1
-SCAN_GROUP4 = 2
+SCAN_SKEW = 2
 
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 

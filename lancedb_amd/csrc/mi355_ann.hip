@@ -23,6 +23,7 @@
 #include "../../include/mi355_ann.h"
 #include "kernels_flat.h"
 #include "kernels_ivfpq.h"
+#include "kernels_skew.h"
 
 // ------------------------------------------------------------------ errors --
 static thread_local std::string g_last_error;
@@ -108,6 +109,10 @@ struct mi355_index {
   bool has_row_ids = false, has_raw = false;
   uint32_t raw_dtype = 0;
   std::vector<uint32_t> h_plen;
+  // code layout: MI355_SCAN_PAIR = [m][pstride] blocks, MI355_SCAN_SKEW = pre-skewed streams
+  uint32_t layout = MI355_SCAN_PAIR;
+  uint32_t n_cus = 256;
+  DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr;
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2,
       w_dist2, w_cnt2, w_stat;
@@ -280,7 +285,9 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->plen,      &ix->pstride, &ix->lrow0,    &ix->grow0,   &ix->row_ids,
                     &ix->raw,       &ix->w_q,    &ix->w_qp,     &ix->w_qq,    &ix->w_coarse,
                     &ix->w_probes,  &ix->w_cand, &ix->w_ids,    &ix->w_dist,  &ix->w_pos,
-                    &ix->w_cnt,     &ix->w_ids2, &ix->w_dist2,  &ix->w_cnt2,  &ix->w_stat};
+                    &ix->w_cnt,     &ix->w_ids2, &ix->w_dist2,  &ix->w_cnt2,  &ix->w_stat,
+                    &ix->cbT,       &ix->order,  &ix->xcd_first, &ix->p_cnt,  &ix->p_off,
+                    &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -311,6 +318,14 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   std::vector<uint64_t> code_off(nlist), grow0(nlist);
   uint64_t rows = 0, bytes = 0;
   uint32_t owned = 0, max_len = 0;
+  {
+    const char* lay = getenv("MI355_LAYOUT");  // dev knob: "pair" forces the generic layout
+    const bool force_pair = lay && !strcmp(lay, "pair");
+    // the skewed layout needs the 256 x P-dword table + residual + lists in 160 KiB of LDS
+    const size_t lds_skew = (size_t)256 * sk_pitch_dwords(m) * 4 + (size_t)d->dim * 4 + 25 * 1024;
+    ix->layout = (!force_pair && sk_supported_m(m) && lds_skew <= 160u * 1024) ? MI355_SCAN_SKEW : MI355_SCAN_PAIR;
+  }
+  const bool skew = ix->layout == MI355_SCAN_SKEW;
   for (uint32_t p = 0; p < nlist; ++p) {
     uint64_t len = d->part_offsets[p + 1] - d->part_offsets[p];
     bool mine = owner[p] == ix->shard_rank;
@@ -320,7 +335,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     grow0[p] = d->part_offsets[p];
     code_off[p] = bytes;
     rows += plen[p];
-    bytes += (uint64_t)m * pstride[p];
+    bytes += skew ? sk_part_chunks((plen[p] + SK_TILE - 1) / SK_TILE, m / 16) * 1024u : (uint64_t)m * pstride[p];
     if (plen[p]) {
       ++owned;
       max_len = std::max(max_len, plen[p]);
@@ -377,14 +392,31 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
       ra.pstride = ix->pstride.as<uint32_t>();
       ra.m = m;
       ra.transposed = d->codes_layout == MI355_CODES_PART_TRANSPOSED;
+      SkewPackArgs sp;
+      sp.src = ra.src;
+      sp.src_off = ra.src_off;
+      sp.part_ids = ra.part_ids;
+      sp.dst = ra.dst;
+      sp.code_off = ra.code_off;
+      sp.plen = ra.plen;
+      sp.m = m;
+      sp.transposed = ra.transposed;
       // grid.y is limited to 65535: split very wide batches
       for (size_t y0 = 0; y0 < pids.size(); y0 += 32768) {
-        RepackArgs rb = ra;
-        rb.src_off += y0;
-        rb.part_ids += y0;
         uint32_t ny = (uint32_t)std::min<size_t>(32768, pids.size() - y0);
-        hipLaunchKernelGGL(k_repack_codes, dim3((batch_max_stride + 63) / 64, ny), dim3(256),
-                           64 * (m + 1), st, rb);
+        if (skew) {
+          SkewPackArgs sb = sp;
+          sb.src_off += y0;
+          sb.part_ids += y0;
+          hipLaunchKernelGGL(k_pack_skew, dim3((batch_max_stride + 63) / 64 + SK_STREAMS, ny), dim3(256),
+                             2 * 64 * (m + 1), st, sb);
+        } else {
+          RepackArgs rb = ra;
+          rb.src_off += y0;
+          rb.part_ids += y0;
+          hipLaunchKernelGGL(k_repack_codes, dim3((batch_max_stride + 63) / 64, ny), dim3(256),
+                             64 * (m + 1), st, rb);
+        }
         HIP_TRY(hipGetLastError());
       }
       HIP_TRY(hipStreamSynchronize(st));  // staging buffer / host vectors are reused
@@ -424,6 +456,53 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     stage.release();
     d_srcoff.release();
     d_pids.release();
+  }
+
+  // -- skewed layout: transposed codebook, static partition order and planner buffers
+  if (skew) {
+    const size_t cb_elems = (size_t)m * 256 * ix->dsub;
+    ST_TRY(ix->cbT.ensure(sizeof(float) * cb_elems));
+    hipLaunchKernelGGL(k_transpose_codebook, dim3((uint32_t)((cb_elems + 255) / 256)), dim3(256), 0, st,
+                       ix->codebook.as<float>(), m, ix->dsub, ix->cbT.as<float>());
+    HIP_TRY(hipGetLastError());
+    // Queue x (the XCD that scans it first) gets partitions by greedy
+    // longest-first bin packing; inside a queue the longest partitions go first
+    // so that the tail of a batch is made of short work items.
+    std::vector<uint32_t> by_len(nlist);
+    for (uint32_t p = 0; p < nlist; ++p) by_len[p] = p;
+    std::sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) {
+      if (plen[a] != plen[b]) return plen[a] > plen[b];
+      return a < b;
+    });
+    std::vector<std::vector<uint32_t>> queue(8);
+    uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < nlist; ++i) {
+      uint32_t p = by_len[i], best = 0;
+      for (uint32_t x = 1; x < 8; ++x)
+        if (load[x] < load[best]) best = x;
+      queue[best].push_back(p);
+      load[best] += plen[p] + 1;  // +1: spread empty partitions too
+    }
+    std::vector<uint32_t> order, xcd_first(9);
+    for (uint32_t x = 0; x < 8; ++x) {
+      xcd_first[x] = (uint32_t)order.size();
+      order.insert(order.end(), queue[x].begin(), queue[x].end());
+    }
+    xcd_first[8] = nlist;
+    ST_TRY(ix->order.ensure(sizeof(uint32_t) * nlist));
+    ST_TRY(ix->xcd_first.ensure(sizeof(uint32_t) * 9));
+    ST_TRY(ix->p_cnt.ensure(sizeof(uint32_t) * nlist));
+    ST_TRY(ix->p_off.ensure(sizeof(uint32_t) * nlist));
+    ST_TRY(ix->p_fill.ensure(sizeof(uint32_t) * nlist));
+    ST_TRY(ix->q_start.ensure(sizeof(uint32_t) * 16));
+    ST_TRY(ix->heads.ensure(sizeof(uint32_t) * 8 * SK_HEAD_STRIDE));
+    HIP_TRY(hipMemcpyAsync(ix->order.p, order.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ix->xcd_first.p, xcd_first.data(), sizeof(uint32_t) * 9, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ix->p_cnt.p, 0, sizeof(uint32_t) * nlist, st));
+    HIP_TRY(hipStreamSynchronize(st));  // host vectors above go out of scope
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
+    ix->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
   }
 
   // -- row ids and raw vectors: owned partitions, concatenated in local order
@@ -497,7 +576,11 @@ extern "C" int32_t mi355_index_sync(mi355_index* ix) {
 extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
                                          uint32_t slice_rows, uint32_t profile) {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
-  if (scan_variant > MI355_SCAN_GROUP4) return fail(MI355_ERR_INVALID_INPUT, "unknown scan variant");
+  if (scan_variant > MI355_SCAN_SKEW) return fail(MI355_ERR_INVALID_INPUT, "unknown scan variant");
+  if (scan_variant != MI355_SCAN_AUTO && scan_variant != ix->layout)
+    return fail(MI355_ERR_INVALID_INPUT,
+                "scan variant %u does not match the code layout this index was packed for (%u)",
+                scan_variant, ix->layout);
   std::lock_guard<std::mutex> lk(ix->mu);
   ix->scan_variant = scan_variant;
   ix->slice_rows = (slice_rows + 15u) & ~15u;
@@ -617,6 +700,43 @@ static void launch_by_kpl(int kpl, KernFn k1, KernFn k2, KernFn k4, dim3 grid, d
     hipLaunchKernelGGL(k4, grid, block, lds, st, a);
 }
 
+template <int M>
+static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_t dim, uint32_t kk,
+                                  hipStream_t st) {
+  auto lds_of = [&](int nw, int lr) {
+    return (size_t)256 * sk_pitch_dwords(M) * 4 + (((size_t)dim * 4 + 15) & ~(size_t)15) +
+           (size_t)nw * lr * 64 * 8 + (size_t)(nw + 2) * 4;
+  };
+#define LAUNCH_SK(LR, NT)                                                                       \
+  {                                                                                             \
+    auto kern = k_scan_skew<M, LR, NT>;                                                         \
+    const size_t lds = lds_of(NT / 64, LR);                                                     \
+    if (lds > 160u * 1024)                                                                      \
+      return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds));                                                     \
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(NT), lds, st, sa);                            \
+  }
+  if (kk <= 64) LAUNCH_SK(2, 1024)
+  else if (kk <= 128) LAUNCH_SK(3, 1024)
+  else LAUNCH_SK(5, 512)
+#undef LAUNCH_SK
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+static int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint32_t dim,
+                                uint32_t kk, hipStream_t st) {
+  switch (m) {
+    case 32: return launch_scan_skew_m<32>(sa, n_blocks, dim, kk, st);
+    case 48: return launch_scan_skew_m<48>(sa, n_blocks, dim, kk, st);
+    case 64: return launch_scan_skew_m<64>(sa, n_blocks, dim, kk, st);
+    case 80: return launch_scan_skew_m<80>(sa, n_blocks, dim, kk, st);
+    case 96: return launch_scan_skew_m<96>(sa, n_blocks, dim, kk, st);
+  }
+  return fail(MI355_ERR_NOT_SUPPORTED, "no skewed scan kernel for m = %u", m);
+}
+
 struct SearchPlan {
   uint32_t k, kk, nprobe;
   bool refine;
@@ -632,14 +752,16 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
   const uint32_t nprobe = pl.nprobe;
   const int kpl_kk = kpl_for(pl.kk), kpl_k = kpl_for(pl.k);
 
+  const bool skew = ix->layout == MI355_SCAN_SKEW;
   // tuning (dev knobs; defaults chosen from the index shape)
   uint32_t nt = env_u32("MI355_SCAN_THREADS", 0), vpt = env_u32("MI355_SCAN_VPT", 0);
   if (!nt) nt = pl.kk > 64 ? 256 : ix->max_len >= 8192 ? 1024 : ix->max_len >= 2048 ? 512 : 256;
   if (!vpt) vpt = ix->max_len >= 4 * nt * 4 ? 16 : 4;
-  // One work item per (query, partition) whenever the batch alone fills the
-  // chip: the distance table is then built once per pair and skewed partitions
-  // cost no empty blocks.  Small batches (latency mode) split partitions into
-  // slices so that >= ~4 work items per CU exist.
+  // Generic kernel: one work item per (query, partition) whenever the batch
+  // alone fills the chip: the distance table is then built once per pair and
+  // skewed partitions cost no empty blocks.  Small batches (latency mode) split
+  // partitions into slices so that >= ~4 work items per CU exist.  The skewed
+  // kernel always takes whole partitions (its 16 streams are the split).
   uint32_t slice = ix->slice_rows;
   if (!slice) {
     const uint64_t pairs = (uint64_t)nq * nprobe;
@@ -647,12 +769,12 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
     slice = std::max((ix->max_len + want - 1) / want, nt * vpt);
   }
   slice = (slice + 15u) & ~15u;
-  const uint32_t n_slices = std::max(1u, (ix->max_len + slice - 1) / slice);
+  const uint32_t n_slices = skew ? 1u : std::max(1u, (ix->max_len + slice - 1) / slice);
   // LDS: distance table + residual + per-wave candidate lists + wave counters
   const uint32_t lr = pl.kk <= 64 ? 2 : 5;
   const size_t lds = (size_t)ix->m * 1024 + (((size_t)ix->dim * 4 + 15) & ~(size_t)15) +
                      (size_t)(nt / 64) * lr * 64 * 8 + (size_t)(nt / 64) * 4;
-  if (lds > 160u * 1024)
+  if (!skew && lds > 160u * 1024)
     return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds);
 
   // chunk the batch so the workspace stays bounded
@@ -660,6 +782,10 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
   const size_t budget = (size_t)env_u32("MI355_WORKSPACE_MB", 2048) << 20;
   uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / std::max<size_t>(per_q, 1)));
   chunk = std::min(chunk, 65535u);  // grid.z limit
+  if (skew) {
+    ST_TRY(ix->items.ensure(sizeof(uint32_t) * (size_t)chunk * nprobe));
+    ST_TRY(ix->qthr.ensure(sizeof(uint32_t) * chunk));
+  }
   ST_TRY(ix->w_qp.ensure(sizeof(float) * (size_t)chunk * ix->dim));
   ST_TRY(ix->w_qq.ensure(sizeof(float) * chunk));
   ST_TRY(ix->w_coarse.ensure(sizeof(float) * (size_t)chunk * ix->nlist));
@@ -700,18 +826,58 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(es.ev[2], st));
 
-    ScanArgs sa;
-    sa.ix = view;
-    sa.qp = ix->w_qp.as<float>();
-    sa.probes = ix->w_probes.as<uint32_t>();
-    sa.nprobe = nprobe;
-    sa.slice_rows = slice;
-    sa.n_slices = n_slices;
-    sa.kk = pl.kk;
-    sa.range = pl.range;
-    sa.cand = ix->w_cand.as<Cand>();
-    sa.dbg = env_u32("MI355_DBG_SKIP", 0);
-    ST_TRY(launch_scan_pair(sa, dim3(n_slices, nprobe, n), lds, st, kpl_kk, vpt, nt));
+    if (skew) {
+      PlanArgs pa;
+      pa.probes = ix->w_probes.as<uint32_t>();
+      pa.n_pairs = n * nprobe;
+      pa.nlist = ix->nlist;
+      pa.plen = view.plen;
+      pa.order = ix->order.as<uint32_t>();
+      pa.xcd_first = ix->xcd_first.as<uint32_t>();
+      pa.cnt = ix->p_cnt.as<uint32_t>();
+      pa.off = ix->p_off.as<uint32_t>();
+      pa.fill = ix->p_fill.as<uint32_t>();
+      pa.q_start = ix->q_start.as<uint32_t>();
+      pa.heads = ix->heads.as<uint32_t>();
+      pa.items = ix->items.as<uint32_t>();
+      pa.cand = ix->w_cand.as<Cand>();
+      pa.kk = pl.kk;
+      const uint32_t pb = (pa.n_pairs + 255) / 256;
+      HIP_TRY(hipMemsetAsync(ix->qthr.p, 0xFF, sizeof(uint32_t) * n, st));
+      hipLaunchKernelGGL(k_plan_count, dim3(pb), dim3(256), 0, st, pa);
+      hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, pa);
+      hipLaunchKernelGGL(k_plan_fill, dim3(pb), dim3(256), 0, st, pa);
+      HIP_TRY(hipGetLastError());
+      SkewArgs ka;
+      ka.ix = view;
+      ka.cbT = ix->cbT.as<float>();
+      ka.qp = ix->w_qp.as<float>();
+      ka.probes = ix->w_probes.as<uint32_t>();
+      ka.items = ix->items.as<uint32_t>();
+      ka.q_start = ix->q_start.as<uint32_t>();
+      ka.heads = ix->heads.as<uint32_t>();
+      ka.qthr = ix->qthr.as<uint32_t>();
+      ka.nprobe = nprobe;
+      ka.kk = pl.kk;
+      ka.range = pl.range;
+      ka.cand = ix->w_cand.as<Cand>();
+      ka.dbg = env_u32("MI355_DBG_SKIP", 0);
+      const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(ix->n_cus, (uint64_t)n * nprobe);
+      ST_TRY(launch_scan_skew(ka, ix->m, std::max(n_blocks, 1u), ix->dim, pl.kk, st));
+    } else {
+      ScanArgs sa;
+      sa.ix = view;
+      sa.qp = ix->w_qp.as<float>();
+      sa.probes = ix->w_probes.as<uint32_t>();
+      sa.nprobe = nprobe;
+      sa.slice_rows = slice;
+      sa.n_slices = n_slices;
+      sa.kk = pl.kk;
+      sa.range = pl.range;
+      sa.cand = ix->w_cand.as<Cand>();
+      sa.dbg = env_u32("MI355_DBG_SKIP", 0);
+      ST_TRY(launch_scan_pair(sa, dim3(n_slices, nprobe, n), lds, st, kpl_kk, vpt, nt));
+    }
     if (prof) HIP_TRY(hipEventRecord(es.ev[3], st));
 
     MergeArgs ma;
@@ -760,7 +926,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
   ix->stats.n_queries += nq;
   ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
   ix->stats.partitions_probed += (uint64_t)nq * nprobe;
-  ix->stats.scan_variant = MI355_SCAN_PAIR;
+  ix->stats.scan_variant = ix->layout;
   return MI355_OK;
 }
 

@@ -125,6 +125,71 @@ def test_ivfpq_small_and_ragged(oracle):
     _assert_same(g2.search(q, k=10, nprobe_min=4, nprobe_max=4), o.search(q, k=10, nprobe_min=4, nprobe_max=4))
 
 
+# ------------------------------------------------- skewed (production) scan --
+@pytest.mark.parametrize("m", [32, 48, 64, 80, 96])
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_ivfpq_skew_layout_matches_oracle(oracle, m, metric):
+    """m in {32,48,64,80,96} takes the pre-skewed stream layout + conflict-free
+    table (kernels_skew.h).  Partition lengths cover: empty, < 1 tile, exactly
+    16 tiles, ragged tails, > 16 tiles per stream."""
+    dim, nlist = m * 4, 12
+    rng = np.random.default_rng(m)
+    lens = np.array([0, 1, 63, 64, 65, 1024, 1025, 3000, 0, 5000, 17, 2047], dtype=np.int64)
+    n = int(lens.sum())
+    s = train.synthetic_index(n, dim, nlist, m, seed=m)
+    s["part_offsets"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    g, o = _both(oracle, s, metric)
+    assert g.stats()["scan_variant"] in (0, _abi.SCAN_SKEW)
+    q = (s["centroids"][rng.integers(0, nlist, size=7)] + rng.normal(0, 0.5, size=(7, dim))).astype(np.float32)
+    for nprobe, k in ((1, 10), (5, 1), (12, 10), (12, 64), (12, 100), (12, 200)):
+        _assert_same(g.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe),
+                     o.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe))
+    assert g.stats()["scan_variant"] == _abi.SCAN_SKEW
+    # lance's per-partition transposed source layout packs to the same streams
+    t = train.to_part_transposed(s["codes"], s["part_offsets"])
+    g2, _ = _both(oracle, s, metric, layout=_abi.CODES_PART_TRANSPOSED, codes=t)
+    _assert_same(g2.search(q, k=10, nprobe_min=12, nprobe_max=12), o.search(q, k=10, nprobe_min=12, nprobe_max=12))
+
+
+def test_ivfpq_skew_ties_ranges_and_batches(oracle):
+    """All rows of a partition share one code (every distance ties: order comes
+    from the row id alone), distance ranges, and a batch large enough that every
+    queue of the partition-major work list is used and stolen from."""
+    s = train.synthetic_index(30000, 128, 24, 32, seed=77, skew=1.0)
+    s["codes"][:] = s["codes"][0]
+    s["row_ids"] = np.random.default_rng(0).permutation(30000).astype(np.uint64) + (1 << 40)
+    g, o = _both(oracle, s)
+    q = np.random.default_rng(4).normal(size=(300, 128)).astype(np.float32)
+    _assert_same(g.search(q, k=25, nprobe_min=6, nprobe_max=6), o.search(q, k=25, nprobe_min=6, nprobe_max=6))
+    s2 = train.synthetic_index(50000, 192, 32, 48, seed=9, skew=0.7)
+    g2, o2 = _both(oracle, s2)
+    q2 = (s2["centroids"][np.random.default_rng(1).integers(0, 32, size=300)]
+          + np.random.default_rng(2).normal(0, 0.5, size=(300, 192))).astype(np.float32)
+    exp = o2.search(q2, k=10, nprobe_min=8, nprobe_max=8)
+    _assert_same(g2.search(q2, k=10, nprobe_min=8, nprobe_max=8), exp)
+    lo, hi = float(exp[1][0, 2]), float(exp[1][0, 8])
+    kw = dict(k=10, nprobe_min=8, nprobe_max=8, lower_bound=lo, upper_bound=hi)
+    _assert_same(g2.search(q2, **kw), o2.search(q2, **kw))
+    qn = q2[:4].copy()
+    qn[1, 5] = np.nan
+    _assert_same(g2.search(qn, k=5, nprobe_min=2, nprobe_max=2), o2.search(qn, k=5, nprobe_min=2, nprobe_max=2))
+    # maximum_nprobes expansion and refine on the skewed layout
+    raw = np.random.default_rng(3).normal(size=(50000, 192)).astype(np.float32)
+    g3, o3 = _both(oracle, s2, raw=raw)
+    _assert_same(g3.search(q2[:16], k=10, nprobe_min=4, nprobe_max=4, refine_factor=10),
+                 o3.search(q2[:16], k=10, nprobe_min=4, nprobe_max=4, refine_factor=10))
+
+
+def test_generic_layout_still_serves_m96(oracle, monkeypatch):
+    """MI355_LAYOUT=pair keeps the generic [m][rows] layout for a supported m."""
+    monkeypatch.setenv("MI355_LAYOUT", "pair")
+    s = train.synthetic_index(20000, 192, 8, 96, seed=5)
+    g, o = _both(oracle, s)
+    q = np.random.default_rng(1).normal(size=(5, 192)).astype(np.float32)
+    _assert_same(g.search(q, k=10, nprobe_min=4, nprobe_max=4), o.search(q, k=10, nprobe_min=4, nprobe_max=4))
+    assert g.stats()["scan_variant"] == _abi.SCAN_PAIR
+
+
 def test_ivfpq_errors_mirror_reference(oracle):
     s = train.synthetic_index(500, 8, 4, 2, seed=1)
     g, _ = _both(oracle, s)

@@ -174,6 +174,8 @@ def main():
         dist.all_reduce(stat, op=dist.ReduceOp.SUM)  # whole-job bytes / summed kernel time
     achieved = (float(stat[0]) / float(stat[2])) / (float(stat[1]) / float(stat[2]) * 1e-6) / 1e9 if float(stat[1]) > 0 else 0.0
     qps = a.batch * a.steps / elapsed
+    workload = f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{a.nprobe}_k{a.k}_l2"
+    traffic = traffic_from_profiles(workload, a.batch) if world == 1 else None
 
     result = {
         "metric": "queries/sec @ recall@10, 100M×768 IVF-PQ nprobe=64 k=10",
@@ -189,7 +191,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{a.nprobe}_k{a.k}_l2",
+            "workload": workload,
             "batch_queries": a.batch, "n_rows": n, "dim": dim, "nlist": nlist, "m": m, "nprobe": a.nprobe,
             "k": a.k, "partition_skew_sigma": a.skew, "parallelism": f"ivf_partition_shard{world}",
             "scan_variant": st["scan_variant"], "rows_on_rank0": rows_local, "partitions_on_rank0": parts_local,
@@ -198,7 +200,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_scan (LUT build + ADC scan + top-k)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
             "launches": int(float(stat[2])),
             "stage_us_per_step": {s: st["us_" + s] / a.steps for s in ("coarse", "select", "scan", "merge")},
@@ -213,6 +215,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def traffic_from_profiles(workload, batch):
+    """HBM bytes per launch of the scan kernel.  PMC counters cannot be read from
+    inside the timed process (rocprofv3 collects them in a separate pass, which
+    must not be combined with timing), so this is the committed measurement of
+    the SAME workload under profiles/ (FETCH_SIZE x 2, the gfx950 correction of
+    MI355X_MICROARCH.md); null when no matching measurement is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if t.get("workload") == workload and t.get("batch_queries") == batch:
+            best = t.get("traffic_bytes_per_launch")
+    return best
 
 
 def cpu_baseline(a, np, centroids, codebook, part_offsets, codes, row_ids, d_queries, last, params):

@@ -7,6 +7,7 @@ oracle/ (test infrastructure) and nothing falls back to the CPU.
 from . import _abi  # noqa: F401
 from ._lib import (EngineError, InvalidInput, NotSupported, QueryTimeout, build, device_count,  # noqa: F401
                    lib)
+from ._hip import DeviceArray, synchronize  # noqa: F401
 from .index import FlatIndex, IvfPqIndex, SearchResult, merge_topk, shard_plan  # noqa: F401
 from .query import DEFAULT_TOP_K, VectorQuery, VectorQueryRequest, VectorTable  # noqa: F401
 

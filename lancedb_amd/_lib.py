@@ -12,9 +12,12 @@ from . import _abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libmi355_ann.so")
-_SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-            ("mi355_ann.hip", "kernels_ivfpq.h", "kernels_flat.h", "device_common.h")]
+# MI355_ANN_LIB: dev override used to A/B kernel variants built side by side
+LIB_PATH = os.environ.get("MI355_ANN_LIB") or os.path.join(_PKG, "libmi355_ann.so")
+_CSRC = os.path.join(_PKG, "csrc")
+# the translation unit first, then everything it includes (any change rebuilds)
+_SOURCES = [os.path.join(_CSRC, "mi355_ann.hip")] + sorted(
+    os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".inc")))
 _HEADER = os.path.join(ROOT, "include", "mi355_ann.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",

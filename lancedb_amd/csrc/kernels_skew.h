@@ -41,6 +41,7 @@
 // L2.  Placement only affects speed; any CU may steal from any queue.
 #pragma once
 #include "kernels_ivfpq.h"
+#include "skew_chunks.inc"  // generated inner blocks; defines SK_ADDR_* / SK_SPLIT_*
 
 #define SK_STREAMS 16u
 #define SK_TILE 64u
@@ -48,7 +49,27 @@
 #define SK_NONE 0xFFFFFFFFu
 #define SK_HEAD_STRIDE 32u  // u32 words between the per-XCD queue heads (128 B)
 
+// One scan work item, self-contained so that a workgroup needs ONE dependent
+// load after the queue pop (written per batch by k_plan_fill).
+struct __attribute__((aligned(32))) SkewItem {
+  uint32_t pair;      // b * nprobe + r (indexes probes[] and the candidate slots)
+  uint32_t part;      // partition id
+  uint32_t len;       // rows of the partition on this handle
+  uint32_t lrow0;     // local position of its first row
+  uint64_t grow0;     // global index position of its first row
+  uint64_t code_off;  // byte offset of its code block
+};
+
 __host__ __device__ __forceinline__ uint32_t sk_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// phase (steps of delay) of lane l: distinct inside each 32-lane bank group
+__host__ __device__ __forceinline__ uint32_t sk_phase(uint32_t l) {
+#ifdef SK_SPLIT_BFM
+  return l < 32u ? l : 63u - l;  // mirrored: the lanes still on the old row are contiguous (s_bfm_b64)
+#else
+  return l & 31u;
+#endif
+}
 
 // tiles of stream w of a partition with n_tiles tiles
 __host__ __device__ __forceinline__ uint32_t sk_stream_tiles(uint32_t n_tiles, uint32_t w) {
@@ -68,7 +89,9 @@ __host__ __device__ __forceinline__ uint64_t sk_part_chunks(uint32_t n_tiles, ui
 __host__ __device__ __forceinline__ bool sk_supported_m(uint32_t m) {
   return m == 32 || m == 48 || m == 64 || m == 80 || m == 96;
 }
-__host__ __device__ __forceinline__ uint32_t sk_pitch_dwords(uint32_t m) { return ((m + 32u + 31u) / 32u) * 32u; }
+// LUT pitch in dwords: >= m + 32 columns and a power of two, so that the address
+// is (code << 9) | column bytes (three 2-cycle VOP2 ops, scripts/gen_skew_chunks.py)
+__host__ __device__ __forceinline__ uint32_t sk_pitch_dwords(uint32_t) { return 128u; }
 
 // ------------------------------------------------------------ index packing --
 // Destination-driven: one 256-thread block per (partition, slot g).  Slots
@@ -127,7 +150,7 @@ __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
   const uint32_t n_chunks = tail ? SK_TAIL_CHUNKS : cpt;
   uint8_t* dst = a.dst + a.code_off[p] + ((size_t)sk_stream_chunk0(n_tiles, w, cpt) + (size_t)cpt * n) * 1024u;
   for (uint32_t e = threadIdx.x; e < n_chunks * 64u; e += 256) {
-    const uint32_t cc = e / 64u, l = e % 64u, lm = l & 31u;
+    const uint32_t cc = e / 64u, l = e % 64u, lm = sk_phase(l);
     uint32_t wds[4];
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
@@ -176,7 +199,10 @@ struct PlanArgs {
   uint32_t* fill;           // [nlist]
   uint32_t* q_start;        // [9]
   uint32_t* heads;          // [8 * SK_HEAD_STRIDE]
-  uint32_t* items;          // [n_pairs]
+  SkewItem* items;          // [n_pairs]
+  const uint32_t* lrow0;    // [nlist]
+  const uint64_t* grow0;    // [nlist]
+  const uint64_t* code_off; // [nlist]
   Cand* cand;               // [n_pairs][kk]
   uint32_t kk;
 };
@@ -237,8 +263,16 @@ __global__ void k_plan_fill(PlanArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_pairs) return;
   const uint32_t p = a.probes[i];
-  if (!a.plen[p]) return;
-  a.items[a.off[p] + atomicAdd(&a.fill[p], 1u)] = i;
+  const uint32_t len = a.plen[p];
+  if (!len) return;
+  SkewItem it;
+  it.pair = i;
+  it.part = p;
+  it.len = len;
+  it.lrow0 = a.lrow0[p];
+  it.grow0 = a.grow0[p];
+  it.code_off = a.code_off[p];
+  a.items[a.off[p] + atomicAdd(&a.fill[p], 1u)] = it;
 }
 
 // ------------------------------------------------------------------- scan ----
@@ -247,7 +281,7 @@ struct SkewArgs {
   const float* cbT;         // [256][m][dsub]
   const float* qp;          // [nq, dim] preprocessed queries
   const uint32_t* probes;   // [nq * nprobe]
-  const uint32_t* items;    // [n_items] pair index b*nprobe + r, partition-major
+  const SkewItem* items;    // [n_items] partition-major work list
   const uint32_t* q_start;  // [9]
   uint32_t* heads;          // [8 * SK_HEAD_STRIDE]
   uint32_t* qthr;           // [nq] running per-query threshold (f32 sort key)
@@ -263,8 +297,6 @@ __device__ __forceinline__ uint32_t xcc_id() {
   return v & 7u;
 }
 
-#include "skew_chunks.inc"
-
 // plain chunks g = G .. CPT-1 of a tile (steps >= 32)
 template <int G, int CPT>
 __device__ __forceinline__ void skew_plain_chunks(const uint4 (&cv)[CPT], uint32_t lb, uint32_t pb, float& x,
@@ -275,109 +307,203 @@ __device__ __forceinline__ void skew_plain_chunks(const uint4 (&cv)[CPT], uint32
   }
 }
 
+// Queue pop for the persistent scan (thread 0 only).  `q` is the queue this
+// workgroup currently drains (its own XCD's first, then the others in ring
+// order).  Returns the global item index or SK_NONE when every queue is dry.
+__device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_t* s_q, uint32_t& q, uint32_t& tried) {
+  while (tried < 8) {
+    const uint32_t q0 = s_q[q], n = s_q[q + 1] - q0;
+    uint32_t* head = a.heads + q * SK_HEAD_STRIDE;
+    if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+      const uint32_t i = atomicAdd(head, 1u);
+      if (i < n) return q0 + i;
+    }
+    q = (q + 1) & 7u;
+    ++tried;
+  }
+  return SK_NONE;
+}
+
 template <int M, int LR, int NT>
 __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / MI355_WAVE;
-  constexpr int P = ((M + 32 + 31) / 32) * 32;  // LUT pitch in dwords
+  constexpr int P = 128;       // LUT pitch in dwords (sk_pitch_dwords)
   constexpr int PB = P * 4;
-  constexpr int CPT = M / 16;                   // 1-KiB chunks per tile
+  constexpr int CPT = M / 16;  // 1-KiB chunks per tile
+  static_assert(M + 32 <= P, "table columns exceed the pitch");
   const IndexView& ix = a.ix;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t lm = lane & 31;
+  const uint32_t lm = sk_phase(lane);
   float* lut = (float*)smem;                                  // [256][P]
   float* res = (float*)(smem + 256 * PB);                     // [dim]
   ListEnt* lists = (ListEnt*)(smem + 256 * PB + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
   uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);  // [NW]
-  uint32_t* s_item = s_cnt + NW;                              // [1]
-  uint32_t* s_thr = s_item + 1;                               // [1] block threshold (sort key)
-  const uint32_t lb = (uint32_t)(size_t)smem + 4u * (32u - lm);  // LDS address of this lane's column origin
-  const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane(PB);
-  const uint32_t xcd = xcc_id();
+  uint32_t* s_thr = s_cnt + NW;                               // [1] block threshold (sort key)
+  uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
+  SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
+  // the gather address is (code << 9) | column bytes: the table must start at LDS address 0
+  if ((uint32_t)(size_t)smem != 0u) __builtin_trap();
+  const uint32_t lb = 4u * (32u - lm);  // this lane's column origin (bytes)
+#ifdef SK_ADDR_BFE
+  const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane(PB);        // table pitch
+#else
+  const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane(0x1fe00);   // code field of the address
+#endif
   const uint64_t* rid = ix.row_ids;
   const bool ranged = a.range.has_lower || a.range.has_upper;
 
-  for (;;) {
-    // ---- next work item: own XCD's queue first, then steal -----------------
-    if (tid == 0) {
-      uint32_t it = SK_NONE;
-      for (uint32_t k = 0; k < 8 && it == SK_NONE; ++k) {
-        const uint32_t x = (xcd + k) & 7u;
-        const uint32_t q0 = a.q_start[x], n = a.q_start[x + 1] - q0;
-        uint32_t* head = a.heads + x * SK_HEAD_STRIDE;
-        if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n) continue;
-        const uint32_t i = atomicAdd(head, 1u);
-        if (i < n) it = a.items[q0 + i];
+  // ---- first item (synchronous) ---------------------------------------------
+  uint32_t q_cur = 0, q_tried = 0;  // thread 0's queue cursor
+  if (tid < 9) s_q[tid] = a.q_start[tid];
+  __syncthreads();
+  if (tid == 0) {
+    q_cur = xcc_id();
+    const uint32_t gi = sk_pop_sync(a, s_q, q_cur, q_tried);
+    SkewItem it;
+    it.pair = SK_NONE;
+    if (gi != SK_NONE) it = a.items[gi];
+    s_rec[0] = it;
+  }
+  __syncthreads();
+  // every thread's share of the first residual
+  float pre_q[4], pre_c[4];  // up to 4 elements per thread (dim <= 4 * NT, checked at open)
+  auto prefetch_res = [&](const SkewItem& it) {
+    const float* q = a.qp + (size_t)(it.pair / a.nprobe) * ix.dim;
+    const float* c = ix.centroids + (size_t)it.part * ix.dim;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t d = tid + u * NT;
+      pre_q[u] = 0.f;
+      pre_c[u] = 0.f;
+      if (d < ix.dim) {
+        pre_q[u] = q[d];
+        if (ix.metric != MI355_METRIC_DOT) pre_c[u] = c[d];
       }
-      *s_item = it;
     }
-    __syncthreads();
-    const uint32_t pair = *s_item;
+  };
+  if (s_rec[0].pair != SK_NONE) prefetch_res(s_rec[0]);
+
+  for (uint32_t slot = 0;; slot ^= 1u) {
+    // the record is wave-uniform: keep it in SGPRs
+    const SkewItem* rec = s_rec + slot;
+    auto uni32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni64 = [&](uint64_t v) -> uint64_t { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | (uint64_t)uni32((uint32_t)v); };
+    const uint32_t pair = uni32(rec->pair);
     if (pair == SK_NONE) break;
+    const uint32_t len = uni32(rec->len);
+    const uint32_t lrow0 = uni32(rec->lrow0);
+    const uint64_t grow0 = uni64(rec->grow0);
+    const uint64_t code_off = uni64(rec->code_off);
     const uint32_t b = pair / a.nprobe;
-    const uint32_t p = a.probes[pair];
-    const uint32_t len = ix.plen[p];
     const uint32_t n_tiles = (len + SK_TILE - 1) / SK_TILE;
     Cand* out = a.cand + (size_t)pair * a.kk;
-    const float* q = a.qp + (size_t)b * ix.dim;
 
-    // ---- K2: residual + distance table, [code][column] with duplicated tail -
-    if (ix.metric == MI355_METRIC_DOT) {
-      for (uint32_t d = tid; d < ix.dim; d += NT) res[d] = q[d];
-    } else {
-      const float* c = ix.centroids + (size_t)p * ix.dim;
-      for (uint32_t d = tid; d < ix.dim; d += NT) res[d] = q[d] - c[d];
+    // ---- pop the NEXT item now; its index arrives behind the LUT phase's loads
+    uint32_t pf = SK_NONE, pf_q0 = 0, pf_n = 0;
+    if (tid == 0 && q_tried < 8) {
+      pf_q0 = s_q[q_cur];
+      pf_n = s_q[q_cur + 1] - pf_q0;
+      pf = atomicAdd(a.heads + q_cur * SK_HEAD_STRIDE, 1u);
+    }
+
+    // ---- K2: residual (prefetched) + distance table ---------------------------
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t d = tid + u * NT;
+      if (d < ix.dim) res[d] = pre_q[u] - pre_c[u];  // dot: pre_c == 0, q - 0 == q exactly
     }
     if (tid == 0) *s_thr = __hip_atomic_load(a.qthr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (!(a.dbg & 1u)) {
       const uint32_t dsub = ix.dsub;
-      for (uint32_t e = tid; e < 256u * M; e += NT) {
+      const bool dotm = ix.metric == MI355_METRIC_DOT;
+      auto put = [&](uint32_t e, float acc) {
         const uint32_t c = e / (uint32_t)M, j = e % (uint32_t)M;
-        const float* cb = a.cbT + (size_t)e * dsub;
-        const float* rj = res + j * dsub;
-        float acc = 0.f;
-        if ((dsub & 3u) == 0) {  // 16-B loads; same d-ascending chain
-          for (uint32_t t = 0; t < dsub; t += 4) {
-            const float4 cv4 = *(const float4*)(cb + t);
-            const float4 rv4 = *(const float4*)(rj + t);
-            if (ix.metric == MI355_METRIC_DOT) {
-              acc = __fmaf_rn(rv4.x, cv4.x, acc);
-              acc = __fmaf_rn(rv4.y, cv4.y, acc);
-              acc = __fmaf_rn(rv4.z, cv4.z, acc);
-              acc = __fmaf_rn(rv4.w, cv4.w, acc);
-            } else {
-              float d0 = rv4.x - cv4.x, d1 = rv4.y - cv4.y, d2 = rv4.z - cv4.z, d3 = rv4.w - cv4.w;
-              acc = __fmaf_rn(d0, d0, acc);
-              acc = __fmaf_rn(d1, d1, acc);
-              acc = __fmaf_rn(d2, d2, acc);
-              acc = __fmaf_rn(d3, d3, acc);
-            }
-          }
-        } else if (ix.metric == MI355_METRIC_DOT) {
-          for (uint32_t t = 0; t < dsub; ++t) acc = __fmaf_rn(rj[t], cb[t], acc);
-        } else {
-          for (uint32_t t = 0; t < dsub; ++t) {
-            float df = rj[t] - cb[t];
-            acc = __fmaf_rn(df, df, acc);
-          }
-        }
-        if (ix.metric == MI355_METRIC_DOT) acc = 1.0f - acc;
+        if (dotm) acc = 1.0f - acc;
         lut[c * P + j + 32] = acc;
         if (j >= (uint32_t)(M - 31)) lut[c * P + j - (M - 32)] = acc;
+      };
+      if (dsub == 8) {
+        // 4 entries per thread per round: 8 independent 16-B loads in flight
+        constexpr uint32_t TOTAL = 256u * M;
+        for (uint32_t e0 = tid; e0 < TOTAL; e0 += 4 * NT) {
+          float4 cv4[4][2];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t e = e0 + u * NT;
+            if (e < TOTAL) {
+              cv4[u][0] = *(const float4*)(a.cbT + (size_t)e * 8);
+              cv4[u][1] = *(const float4*)(a.cbT + (size_t)e * 8 + 4);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t e = e0 + u * NT;
+            if (e < TOTAL) {
+              const float* rj = res + (e % (uint32_t)M) * 8;
+              const float4 r0 = *(const float4*)rj, r1 = *(const float4*)(rj + 4);
+              const float4 c0 = cv4[u][0], c1 = cv4[u][1];
+              float acc = 0.f;
+              if (dotm) {
+                acc = __fmaf_rn(r0.x, c0.x, acc);
+                acc = __fmaf_rn(r0.y, c0.y, acc);
+                acc = __fmaf_rn(r0.z, c0.z, acc);
+                acc = __fmaf_rn(r0.w, c0.w, acc);
+                acc = __fmaf_rn(r1.x, c1.x, acc);
+                acc = __fmaf_rn(r1.y, c1.y, acc);
+                acc = __fmaf_rn(r1.z, c1.z, acc);
+                acc = __fmaf_rn(r1.w, c1.w, acc);
+              } else {
+                float d0 = r0.x - c0.x, d1 = r0.y - c0.y, d2 = r0.z - c0.z, d3 = r0.w - c0.w;
+                float d4 = r1.x - c1.x, d5 = r1.y - c1.y, d6 = r1.z - c1.z, d7 = r1.w - c1.w;
+                acc = __fmaf_rn(d0, d0, acc);
+                acc = __fmaf_rn(d1, d1, acc);
+                acc = __fmaf_rn(d2, d2, acc);
+                acc = __fmaf_rn(d3, d3, acc);
+                acc = __fmaf_rn(d4, d4, acc);
+                acc = __fmaf_rn(d5, d5, acc);
+                acc = __fmaf_rn(d6, d6, acc);
+                acc = __fmaf_rn(d7, d7, acc);
+              }
+              put(e, acc);
+            }
+          }
+        }
+      } else {
+        for (uint32_t e = tid; e < 256u * M; e += NT) {
+          const float* cb = a.cbT + (size_t)e * dsub;
+          const float* rj = res + (e % (uint32_t)M) * dsub;
+          float acc = 0.f;
+          if (dotm) {
+            for (uint32_t t = 0; t < dsub; ++t) acc = __fmaf_rn(rj[t], cb[t], acc);
+          } else {
+            for (uint32_t t = 0; t < dsub; ++t) {
+              float df = rj[t] - cb[t];
+              acc = __fmaf_rn(df, df, acc);
+            }
+          }
+          put(e, acc);
+        }
       }
+    }
+    // the next item's record: one dependent load, lands during the scan
+    SkewItem nxt;
+    nxt.pair = SK_NONE;
+    bool nxt_valid = false;
+    if (tid == 0 && pf != SK_NONE && pf < pf_n) {
+      nxt = a.items[pf_q0 + pf];
+      nxt_valid = true;
     }
     __syncthreads();
 
     // ---- K3 + K4: skewed ADC scan, one stream per wave ----------------------
     WaveList<LR> wl;
     wl.init(lists + (size_t)wid * LR * MI355_WAVE, a.kk);
-    const uint32_t lrow0 = ix.lrow0[p];
-    const uint64_t grow0 = ix.grow0[p];
     auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
     float thr = f32_from_sort_key(*s_thr);
     if (*s_thr == 0xFFFFFFFFu) thr = __builtin_huge_valf();
-    const uint8_t* pcodes = ix.codes + ix.code_off[p];
+    const uint8_t* pcodes = ix.codes + code_off;
 
     // a finished row: tile position tp of stream w, this lane's row
     float published = __builtin_huge_valf();
@@ -420,6 +546,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         skew_chunk_split0<0>(cv[0], lb, pb, x, y);
         skew_chunk_split1<64>(cv[1], lb, pb, x, y);
         if (n > 0) consume(y, w, n - 1);  // row n-1 is complete on every lane after step 30
+        if (n == 0 && tid == 0 && nxt_valid) s_rec[slot ^ 1u] = nxt;  // landed long ago; frees its registers
         skew_plain_chunks<2, CPT>(cv, lb, pb, x, y);
         y = x;
         x = 0.f;
@@ -450,7 +577,21 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     // ---- block result: exact kk best of all waves' lists, written sorted ----
     if (wl.cnt > a.kk) wl.compact(lane, idof);
     if (lane == 0) s_cnt[wid] = wl.cnt;
+    if (tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) {
+      if (!nxt_valid) {  // the prefetch ran off the end of its queue: move on (rare, synchronous)
+        if (q_tried < 8) {
+          q_cur = (q_cur + 1) & 7u;
+          ++q_tried;
+        }
+        const uint32_t gi = sk_pop_sync(a, s_q, q_cur, q_tried);
+        nxt.pair = SK_NONE;
+        if (gi != SK_NONE) nxt = a.items[gi];
+      }
+      s_rec[slot ^ 1u] = nxt;
+    }
     __syncthreads();
+    // the next item's residual operands travel while this item's lists are merged
+    if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     uint32_t total = 0;
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) total += s_cnt[w2];

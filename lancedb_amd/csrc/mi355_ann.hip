@@ -323,7 +323,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     const bool force_pair = lay && !strcmp(lay, "pair");
     // the skewed layout needs the 256 x P-dword table + residual + lists in 160 KiB of LDS
     const size_t lds_skew = (size_t)256 * sk_pitch_dwords(m) * 4 + (size_t)d->dim * 4 + 25 * 1024;
-    ix->layout = (!force_pair && sk_supported_m(m) && lds_skew <= 160u * 1024) ? MI355_SCAN_SKEW : MI355_SCAN_PAIR;
+    ix->layout = (!force_pair && sk_supported_m(m) && d->dim <= 2048 && lds_skew <= 160u * 1024) ? MI355_SCAN_SKEW : MI355_SCAN_PAIR;
   }
   const bool skew = ix->layout == MI355_SCAN_SKEW;
   for (uint32_t p = 0; p < nlist; ++p) {
@@ -705,7 +705,7 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_
                                   hipStream_t st) {
   auto lds_of = [&](int nw, int lr) {
     return (size_t)256 * sk_pitch_dwords(M) * 4 + (((size_t)dim * 4 + 15) & ~(size_t)15) +
-           (size_t)nw * lr * 64 * 8 + (size_t)(nw + 2) * 4;
+           (size_t)nw * lr * 64 * 8 + (size_t)(nw + 10) * 4 + 96;
   };
 #define LAUNCH_SK(LR, NT)                                                                       \
   {                                                                                             \
@@ -783,7 +783,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
   uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / std::max<size_t>(per_q, 1)));
   chunk = std::min(chunk, 65535u);  // grid.z limit
   if (skew) {
-    ST_TRY(ix->items.ensure(sizeof(uint32_t) * (size_t)chunk * nprobe));
+    ST_TRY(ix->items.ensure(sizeof(SkewItem) * (size_t)chunk * nprobe));
     ST_TRY(ix->qthr.ensure(sizeof(uint32_t) * chunk));
   }
   ST_TRY(ix->w_qp.ensure(sizeof(float) * (size_t)chunk * ix->dim));
@@ -839,7 +839,10 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       pa.fill = ix->p_fill.as<uint32_t>();
       pa.q_start = ix->q_start.as<uint32_t>();
       pa.heads = ix->heads.as<uint32_t>();
-      pa.items = ix->items.as<uint32_t>();
+      pa.items = ix->items.as<SkewItem>();
+      pa.lrow0 = view.lrow0;
+      pa.grow0 = view.grow0;
+      pa.code_off = view.code_off;
       pa.cand = ix->w_cand.as<Cand>();
       pa.kk = pl.kk;
       const uint32_t pb = (pa.n_pairs + 255) / 256;
@@ -853,7 +856,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       ka.cbT = ix->cbT.as<float>();
       ka.qp = ix->w_qp.as<float>();
       ka.probes = ix->w_probes.as<uint32_t>();
-      ka.items = ix->items.as<uint32_t>();
+      ka.items = ix->items.as<SkewItem>();
       ka.q_start = ix->q_start.as<uint32_t>();
       ka.heads = ix->heads.as<uint32_t>();
       ka.qthr = ix->qthr.as<uint32_t>();

@@ -25,6 +25,16 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _device_empty_like(ref, specs):
+    """Uninitialised device arrays of the same kind as `ref` (torch tensor or
+    lancedb_amd.DeviceArray)."""
+    from ._hip import DeviceArray
+    if isinstance(ref, DeviceArray):
+        return [DeviceArray(shape, dt, ref.device) for shape, dt in specs]
+    import torch
+    return [torch.empty(shape, dtype=getattr(torch, dt), device=ref.device) for shape, dt in specs]
+
+
 def _host(a, dtype):
     return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 
@@ -68,14 +78,10 @@ class _Handle:
 def _run_search(fn, handle, dim, queries, params, out=None):
     """Shared host/device marshalling of mi355_search / mi355_flat_search."""
     if _is_device(queries):
-        import torch
         q = queries.contiguous().view(-1, dim)
-        assert q.dtype == torch.float32
         nq, k = q.shape[0], params.k
         if out is None:
-            ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-            dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
-            cnt = torch.empty((nq,), dtype=torch.int32, device=q.device)
+            ids, dist, cnt = _device_empty_like(q, [((nq, k), "int64"), ((nq, k), "float32"), ((nq,), "int32")])
         else:
             ids, dist, cnt = out
         params.io_mem = _abi.MEM_DEVICE
@@ -205,15 +211,13 @@ class FlatIndex(_Handle):
 
 
 def merge_topk(in_rowids, in_dist, in_counts, k, stream=0):
-    """Device-side k-way merge of [n_lists, nq, k] candidate lists (torch CUDA
-    tensors): the reducer after the multi-GPU all-gather."""
-    import torch
+    """Device-side k-way merge of [n_lists, nq, k] candidate lists (device
+    arrays: torch tensors or DeviceArray): the reducer after the multi-GPU
+    all-gather."""
     n_lists, nq = in_counts.shape
-    dev = in_dist.device
-    ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
-    check(lib().mi355_merge_topk(C.c_int32(dev.index or 0), C.c_void_p(stream), _ptr(in_rowids),
+    ids, dist, cnt = _device_empty_like(in_dist, [((nq, k), "int64"), ((nq, k), "float32"), ((nq,), "int32")])
+    dev_index = getattr(in_dist.device, "index", in_dist.device) or 0
+    check(lib().mi355_merge_topk(C.c_int32(dev_index), C.c_void_p(stream), _ptr(in_rowids),
                                  _ptr(in_dist), _ptr(in_counts), C.c_uint32(n_lists),
                                  C.c_uint32(nq), C.c_uint32(k), _ptr(ids), _ptr(dist), _ptr(cnt)))
     return ids, dist, cnt

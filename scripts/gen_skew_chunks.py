@@ -3,49 +3,93 @@
 blocks of the skewed ADC scan (kernels_skew.h).
 
 One block = 16 steps of one wave (one global_load_dwordx4 worth of code bytes
-per lane).  All 16 LUT gathers are issued first (address = code * pitch + lane
-column origin; the step's column offset rides in the ds_read offset field), then
-the 16 f32 adds retire in step order behind counted lgkmcnt waits, so the LDS
-pipe always has >= 16 gathers of this wave in flight and the adds keep the
-j-ascending order of the arithmetic contract.
+per lane).  All 16 LUT gathers are issued first, then the 16 f32 adds retire in
+step order behind counted lgkmcnt waits, so the LDS pipe always has >= 16
+gathers of this wave in flight and the adds keep the j-ascending order of the
+arithmetic contract.  hipcc does not model anything inside an asm statement, so
+every wait is counted here (cdna_hip_programming.md §5.7).
 
-Three variants:
+Three block kinds:
   SPLIT0  steps  0..15 of a tile: every step adds into X on the lanes that are
-          already on the new row (lm <= t) and into Y on the others (EXEC mask
-          is a compile-time constant per step)
+          already on the new row and into Y on the others (compile-time EXEC mask)
   SPLIT1  steps 16..31: 16..30 split as above, step 31 is X only
   PLAIN   steps >= 32: X only
-hipcc does not model anything inside an asm statement, so every wait is counted
-here (cdna_hip_programming.md §5.7).
+
+Knobs (the defaults are what measured fastest with scripts/ubench_skew_loop.py;
+the numbers are in DESIGN.md):
+  addr  how the gather address (code << 9 | lane column origin) is formed
+        "bfe"   v_bfe_u32 + v_mad_u32_u24            (2 VOP3)
+        "vop2"  shift + and + or                     (3 VOP2)
+  il    issue-phase interleave: the address ops of `il` consecutive steps are
+        emitted stage by stage, so no VALU op directly follows its producer
+  drop  timing ablations (results are garbage): "lds" no gathers, "addr" no
+        address math, "add" no adds
+  wait  adds retire in groups of `wait` behind one s_waitcnt (1, 2, 4, 8, 16)
+  split how EXEC is set for the X/Y split
+        "lit"   two s_mov_b32 literals, lanes lm <= t in both 32-lane halves
+        "bfm"   one s_bfm_b64: needs the mirrored lane->phase map
+                (phase = l for l < 32, 63 - l above), Y lanes are contiguous
 """
 import os
+import sys
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lancedb_amd", "csrc",
                    "skew_chunks.inc")
 
+DEFAULTS = dict(addr="bfe", wait=2, split="bfm", il=16, drop="none")
 
-def body(first_step, split_until):
+
+def body(first_step, split_until, addr="bfe", wait=1, split="lit", il=1, drop="none"):
     """asm text for steps first_step .. first_step+15; steps < split_until split X/Y."""
     lines = []
-    for e in range(16):
-        w, b = e // 4, e % 4
-        if b == 3:
-            lines.append(f"v_lshrrev_b32 %[t{e}], 24, %[w{w}]")
-        else:
-            lines.append(f"v_bfe_u32 %[t{e}], %[w{w}], {8 * b}, 8")
-        lines.append(f"v_mad_u32_u24 %[t{e}], %[t{e}], %[pb], %[lb]")
-        lines.append(f"ds_read_b32 %[t{e}], %[t{e}] offset:%c[ob]+{4 * e}")
+    for e0 in range(0, 16, il):  # `il` independent steps are interleaved: no back-to-back dependent VALU
+        stages = [[], [], [], []]
+        for e in range(e0, e0 + il):
+            w, b = e // 4, e % 4
+            if addr == "bfe":
+                if b == 3:
+                    stages[0].append(f"v_lshrrev_b32 %[t{e}], 24, %[w{w}]")
+                else:
+                    stages[0].append(f"v_bfe_u32 %[t{e}], %[w{w}], {8 * b}, 8")
+                stages[1].append(f"v_mad_u32_u24 %[t{e}], %[t{e}], %[pb], %[lb]")
+            elif addr == "vop2":
+                sh = 9 - 8 * b
+                if sh > 0:
+                    stages[0].append(f"v_lshlrev_b32 %[t{e}], {sh}, %[w{w}]")
+                else:
+                    stages[0].append(f"v_lshrrev_b32 %[t{e}], {-sh}, %[w{w}]")
+                stages[1].append(f"v_and_b32 %[t{e}], %[pb], %[t{e}]")  # pb holds the mask 0x1fe00 here
+                stages[2].append(f"v_or_b32 %[t{e}], %[t{e}], %[lb]")
+            else:
+                raise ValueError(addr)
+            stages[3].append(f"ds_read_b32 %[t{e}], %[t{e}] offset:%c[ob]+{4 * e}")
+            if drop == "addr":  # ablation: gather from the lane's column origin, no address math
+                stages[0], stages[1], stages[2] = stages[0][:-1], stages[1][:-1], stages[2][: max(0, len(stages[2]) - 1)]
+                stages[3][-1] = f"ds_read_b32 %[t{e}], %[lb] offset:%c[ob]+{4 * e}"
+            if drop == "lds":  # ablation: no gather (the add consumes the address)
+                stages[3].pop()
+        for st in stages:
+            lines += st
     in_split = False
     for e in range(16):
         t = first_step + e
-        lines.append(f"s_waitcnt lgkmcnt({15 - e})")
+        if e % wait == 0 and drop != "lds":
+            lines.append(f"s_waitcnt lgkmcnt({16 - e - wait})")
+        if drop == "add":  # ablation: gathers only
+            continue
         if t < split_until:
-            mask = (2 << t) - 1
-            lines.append(f"s_mov_b32 exec_lo, 0x{mask:x}")
-            lines.append(f"s_mov_b32 exec_hi, 0x{mask:x}")
-            lines.append(f"v_add_f32 %[x], %[x], %[t{e}]")
-            lines.append("s_not_b64 exec, exec")
-            lines.append(f"v_add_f32 %[y], %[y], %[t{e}]")
+            if split == "lit":
+                mask = (2 << t) - 1
+                lines.append(f"s_mov_b32 exec_lo, 0x{mask:x}")
+                lines.append(f"s_mov_b32 exec_hi, 0x{mask:x}")
+                lines.append(f"v_add_f32 %[x], %[x], %[t{e}]")
+                lines.append("s_not_b64 exec, exec")
+                lines.append(f"v_add_f32 %[y], %[y], %[t{e}]")
+            else:  # mirrored map: lanes t+1 .. 62-t are still on the old row
+                lines.append(f"s_bfm_b64 exec, {62 - 2 * t}, {t + 1}")
+                lines.append(f"v_add_f32 %[y], %[y], %[t{e}]")
+                lines.append("s_not_b64 exec, exec")
+                lines.append(f"v_add_f32 %[x], %[x], %[t{e}]")
             in_split = True
         else:
             if in_split:
@@ -57,8 +101,8 @@ def body(first_step, split_until):
     return lines
 
 
-def emit(name, first_step, split_until, doc):
-    lines = body(first_step, split_until)
+def emit(name, first_step, split_until, doc, **kw):
+    lines = body(first_step, split_until, **kw)
     txt = "\n".join(f'      "{l}\\n\\t"' for l in lines)
     temps_decl = ", ".join(f"t{e}" for e in range(16))
     outs = ", ".join(f'[t{e}] "=&v"(t{e})' for e in range(16))
@@ -76,16 +120,30 @@ __device__ __forceinline__ void {name}(const uint4& cw, uint32_t lb, uint32_t pb
 """
 
 
-def main():
+def render(**kw):
+    cfg = dict(DEFAULTS)
+    cfg.update(kw)
+    pb_note = ("the table pitch in bytes (512)" if cfg["addr"] == "bfe" else "the code-field mask 0x1fe00")
     src = ["// GENERATED by scripts/gen_skew_chunks.py - do not edit by hand.\n"
            "// 16-step blocks of the skewed ADC scan; see the generator's docstring.\n"
-           "#pragma once\n"]
-    src.append(emit("skew_chunk_split0", 0, 16, "steps 0..15 of a tile: X on lanes lm <= t, Y on the others"))
-    src.append(emit("skew_chunk_split1", 16, 31, "steps 16..31 of a tile: 16..30 split, 31 into X"))
-    src.append(emit("skew_chunk_plain", 32, 0, "steps >= 32 of a tile: X only"))
+           f"// knobs: addr={cfg['addr']} wait={cfg['wait']} split={cfg['split']} il={cfg['il']};  `pb` is {pb_note}.\n"
+           "#pragma once\n"
+           f"#define SK_ADDR_{cfg['addr'].upper()} 1\n"
+           f"#define SK_SPLIT_{cfg['split'].upper()} 1\n"]
+    src.append(emit("skew_chunk_split0", 0, 16, "steps 0..15 of a tile: X on the lanes already on the new row, Y on the others", **cfg))
+    src.append(emit("skew_chunk_split1", 16, 31, "steps 16..31 of a tile: 16..30 split, 31 into X", **cfg))
+    src.append(emit("skew_chunk_plain", 32, 0, "steps >= 32 of a tile: X only", **cfg))
+    return "".join(src)
+
+
+def main():
+    kw = {}
+    for a in sys.argv[1:]:
+        k, v = a.split("=")
+        kw[k] = int(v) if v.isdigit() else v
     with open(OUT, "w") as f:
-        f.write("".join(src))
-    print("wrote", OUT)
+        f.write(render(**kw))
+    print("wrote", OUT, kw or DEFAULTS)
 
 
 if __name__ == "__main__":

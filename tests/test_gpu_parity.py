@@ -207,46 +207,47 @@ def test_ivfpq_errors_mirror_reference(oracle):
 
 
 def test_sharded_handles_merge_to_unsharded_result(oracle):
-    import torch
-    s = train.synthetic_index(40000, 32, 64, 8, seed=13, skew=0.9)
-    q = np.random.default_rng(6).normal(size=(33, 32)).astype(np.float32)
-    _, o = _both(oracle, s)
-    exp = o.search(q, k=10, nprobe_min=16, nprobe_max=16)
-    for shards in (2, 8):
-        parts = []
-        rows = 0
-        for r in range(shards):
-            g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"],
-                                       s["row_ids"], shard_count=shards, shard_rank=r)
-            rows += g.info()[0]
-            parts.append(g.search(q, k=10, nprobe_min=16, nprobe_max=16))
-        assert rows == 40000
-        dev = torch.device("cuda:0")
-        ids = torch.stack([torch.from_numpy(p.rowids.astype(np.int64)) for p in parts]).to(dev)
-        dist = torch.stack([torch.from_numpy(p.distances) for p in parts]).to(dev)
-        cnt = torch.stack([torch.from_numpy(p.counts.astype(np.int32)) for p in parts]).to(dev)
-        mi, md, mc = lancedb_amd.merge_topk(ids, dist, cnt, 10, stream=torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        assert (mi.cpu().numpy().astype(np.uint64) == exp[0]).all()
-        assert (md.cpu().numpy() == exp[1]).all()
-        assert (mc.cpu().numpy().astype(np.uint32) == exp[2]).all()
+    """Partition sharding: every shard scans the probed partitions
+    it owns; the k-way merge of the per-shard candidates equals the unsharded
+    result.  Device buffers come from lancedb_amd.DeviceArray (no torch)."""
+    DA = lancedb_amd.DeviceArray
+    for m, dim in ((8, 32), (32, 128)):  # generic and skewed layouts
+        s = train.synthetic_index(40000, dim, 64, m, seed=13, skew=0.9)
+        q = np.random.default_rng(6).normal(size=(33, dim)).astype(np.float32)
+        _, o = _both(oracle, s)
+        exp = o.search(q, k=10, nprobe_min=16, nprobe_max=16)
+        for shards in (2, 8):
+            parts = []
+            rows = 0
+            for r in range(shards):
+                g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"],
+                                           s["row_ids"], shard_count=shards, shard_rank=r)
+                rows += g.info()[0]
+                parts.append(g.search(q, k=10, nprobe_min=16, nprobe_max=16))
+            assert rows == 40000
+            ids = DA.from_numpy(np.stack([p.rowids.astype(np.int64) for p in parts]))
+            dist = DA.from_numpy(np.stack([p.distances for p in parts]))
+            cnt = DA.from_numpy(np.stack([p.counts.astype(np.int32) for p in parts]))
+            mi, md, mc = lancedb_amd.merge_topk(ids, dist, cnt, 10)
+            assert (mi.numpy().astype(np.uint64) == exp[0]).all()
+            assert (md.numpy() == exp[1]).all()
+            assert (mc.numpy().astype(np.uint32) == exp[2]).all()
 
 
 def test_device_resident_io_and_device_index(oracle):
-    import torch
-    dev = torch.device("cuda:0")
-    s = train.synthetic_index(30000, 64, 16, 8, seed=3)
-    _, o = _both(oracle, s)
-    g = lancedb_amd.IvfPqIndex(torch.from_numpy(s["centroids"]).to(dev), torch.from_numpy(s["codebook"]).to(dev),
-                               s["part_offsets"], torch.from_numpy(s["codes"]).to(dev),
-                               torch.from_numpy(s["row_ids"].astype(np.int64)).to(dev))
-    q = np.random.default_rng(2).normal(size=(17, 64)).astype(np.float32)
-    g.set_stream(torch.cuda.current_stream().cuda_stream)
-    r = g.search(torch.from_numpy(q).to(dev), k=10, nprobe_min=4, nprobe_max=4)
-    torch.cuda.synchronize()
-    exp = o.search(q, k=10, nprobe_min=4, nprobe_max=4)
-    assert (r.rowids.cpu().numpy().astype(np.uint64) == exp[0]).all()
-    assert (r.distances.cpu().numpy() == exp[1]).all()
+    DA = lancedb_amd.DeviceArray
+    for m, dim in ((8, 64), (48, 192)):  # generic and skewed layouts
+        s = train.synthetic_index(30000, dim, 16, m, seed=3)
+        _, o = _both(oracle, s)
+        g = lancedb_amd.IvfPqIndex(DA.from_numpy(s["centroids"]), DA.from_numpy(s["codebook"]), s["part_offsets"],
+                                   DA.from_numpy(s["codes"]), DA.from_numpy(s["row_ids"].astype(np.int64)))
+        q = np.random.default_rng(2).normal(size=(17, dim)).astype(np.float32)
+        r = g.search(DA.from_numpy(q), k=10, nprobe_min=4, nprobe_max=4)
+        g.sync()
+        exp = o.search(q, k=10, nprobe_min=4, nprobe_max=4)
+        assert (r.rowids.numpy().astype(np.uint64) == exp[0]).all()
+        assert (r.distances.numpy() == exp[1]).all()
+        assert (r.counts.numpy().astype(np.uint32) == exp[2]).all()
 
 
 # ------------------------------------------------------------------ flat ----

@@ -126,22 +126,15 @@ def main():
     B, k = a.batch, a.k
     out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
            torch.empty((B,), dtype=torch.int32, device=dev))
-    if world > 1:
-        g_ids = torch.empty((world, B, k), dtype=torch.int64, device=dev)
-        g_dist = torch.empty((world, B, k), dtype=torch.float32, device=dev)
-        g_cnt = torch.empty((world, B), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     ix.set_stream(stream)  # engine kernels, RCCL and torch share one ordered stream
     ix.configure(scan_variant=a.scan_variant, slice_rows=a.slice_rows, profile=0)
+    from lancedb_amd.distributed import ShardedSearcher
+    searcher = ShardedSearcher(ix, stream=stream)  # all-gather of [B,k] candidates + k-way merge when world > 1
 
     def step(i):
-        r = ix.search(qpool[i % P], params, out=out)
-        if world == 1:
-            return r.rowids, r.distances, r.counts
-        dist.all_gather_into_tensor(g_ids, r.rowids)
-        dist.all_gather_into_tensor(g_dist, r.distances)
-        dist.all_gather_into_tensor(g_cnt, r.counts)
-        return lancedb_amd.merge_topk(g_ids, g_dist, g_cnt, k, stream=stream)
+        r = searcher.search(qpool[i % P], params, out=out)
+        return r.rowids, r.distances, r.counts
 
     def fence():
         torch.cuda.synchronize()

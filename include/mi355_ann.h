@@ -239,6 +239,13 @@ int32_t mi355_flat_search(mi355_flat *flat, const float *queries,
                           uint64_t *out_rowids, float *out_dist,
                           uint32_t *out_counts);
 
+/* which kernels served the last mi355_flat_search: 1 = bf16 MFMA GEMM filter +
+   exact re-rank, 2 = exact scalar sweep (small columns, lower-bounded ranges);
+   out_has_filter = 1 when the handle carries the filter data (bf16 shadow / row
+   norms, built at open for columns of >= 4096 rows). */
+int32_t mi355_flat_info(const mi355_flat *flat, uint32_t *out_last_path,
+                        uint32_t *out_has_filter);
+
 /*
  * Merge n_lists candidate lists per query into one top-k (the reducer after
  * the multi-GPU all-gather).  Inputs are DEVICE pointers laid

@@ -130,6 +130,7 @@ EXPORTED_SYMBOLS = (
     "mi355_flat_set_stream",
     "mi355_flat_sync",
     "mi355_flat_search",
+    "mi355_flat_info",
     "mi355_merge_topk",
     "mi355_shard_plan",
 )

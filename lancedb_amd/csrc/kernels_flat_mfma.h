@@ -1,0 +1,422 @@
+// kernels_flat_mfma.h — exhaustive (flat) KNN as a bf16 MFMA GEMM filter followed
+// by an exact re-rank.  Replaces KNNVectorDistance + SortExec TopK
+// (/root/reference/python/python/lancedb/query.py:1365-1370).
+//
+// The contract's flat distance is a d-ascending f32 chain per (query, row)
+// (oracle/ann_oracle.c): exact, but a scalar sweep that re-reads the column for
+// every query.  Here the column is read once per 128 queries:
+//
+//   1. k_flat_gemm   S = V · Q~^T on the matrix cores (v_mfma_f32_16x16x32_bf16, f32
+//                    accumulate; Q~ = bf16(q), V = the bf16 column or a bf16 shadow of
+//                    an f32/f16 column).  The epilogue turns S into a LOWER BOUND
+//                    lo = approx - eps of every row's contract distance (eps: a rigorous
+//                    Cauchy-Schwarz bound of the bf16 rounding + accumulation error) and
+//                    keeps only the minimum per 32-row group: the B x N score matrix
+//                    never reaches HBM, N/32 x B floats do.
+//   2. k_flat_segmin / k_flat_tau   a valid upper bound tau_q of the k-th smallest
+//                    contract distance: k-th smallest of 1024 segment minima + 2 eps_max.
+//   3. k_flat_compact   the groups with lo <= tau_q (a few dozen per query).
+//   4. k_flat_rerank    the contract's exact chain on those groups' rows, range
+//                    filter, (distance, rowid) top-k: the result is bit-identical to
+//                    the exact sweep.  A query whose candidate list overflows is
+//                    re-scanned exactly by the same kernel (correct for any data).
+#pragma once
+#include "kernels_flat.h"
+
+#define FG_BM 128   // rows per workgroup tile
+#define FG_BN 128   // queries per workgroup tile
+#define FG_BK 64    // k per LDS stage (128 B per row)
+#define FG_GROUP 32 // rows per group minimum
+#define FG_TILE_BYTES (FG_BM * FG_BK * 2)
+#define FG_MAX_SEG 1024
+#define FG_CAND_CAP 1024  // candidate groups per query before the exact re-scan kicks in
+
+typedef __attribute__((ext_vector_type(8))) __bf16 fg_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float fg_f32x4;
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// ------------------------------------------------------------ open: per row ---
+// One wave per row: bf16 shadow (when the column is not bf16 or dim % 64 != 0) and
+// the row term of the filter (L2: |v|^2; cosine / dot: |v|).  Summation order is
+// free here: the term only feeds the filter's bound, never a returned distance.
+struct FlatRowPrepArgs {
+  const void* vectors;
+  uint32_t dtype, dim, dimp;
+  uint64_t n_rows;
+  uint16_t* shadow;   // [n_rows, dimp] bf16 or nullptr (column used in place)
+  float* vv;          // [n_rows] sum of squares of the values the GEMM sees
+  uint32_t* max_key;  // [1] f32 sort key of max vv (atomicMax)
+};
+
+__global__ __launch_bounds__(256) void k_flat_prep_rows(FlatRowPrepArgs a) {
+  const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.n_rows) return;
+  float acc = 0.f;
+  for (uint32_t d = lane; d < a.dimp; d += 64) {
+    float v = 0.f;
+    if (d < a.dim) v = load_elem(a.vectors, a.dtype, row * a.dim + d);
+    const uint16_t h = f32_to_bf16_rne(v);
+    if (a.shadow) a.shadow[row * a.dimp + d] = h;
+    const float vb = bf16_bits_to_f32(h);
+    acc += vb * vb;
+  }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) {
+    a.vv[row] = acc;
+    // rows whose norm is not finite always score non-finite and are always re-ranked: keep them out of the bound
+    if (acc < __builtin_huge_valf()) atomicMax(a.max_key, f32_sort_key(acc));
+  }
+}
+
+// --------------------------------------------------------- per batch: queries -
+struct FlatQueryPrepArgs {
+  const float* q;      // [nq, dim] original queries
+  uint32_t nq, nq_pad, dim, dimp, metric;
+  float c_err;         // relative error bound of the bf16 dot product
+  float vv_max;        // max row term |v|^2
+  uint16_t* qb;        // [nq_pad, dimp] bf16
+  float* qa;           // [nq_pad] additive query term of lo
+  float* qg;           // [nq_pad] multiplicative query term
+  float* qslack;       // [nq_pad] 2 * eps_max(q): added to the k-th segment minimum
+};
+
+__global__ __launch_bounds__(256) void k_flat_prep_queries(FlatQueryPrepArgs a) {
+  const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= a.nq_pad) return;
+  float acc = 0.f;
+  for (uint32_t d = lane; d < a.dimp; d += 64) {
+    float v = 0.f;
+    if (b < a.nq && d < a.dim) v = a.q[(size_t)b * a.dim + d];
+    a.qb[(size_t)b * a.dimp + d] = f32_to_bf16_rne(v);
+    acc += v * v;
+  }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane) return;
+  const float c = a.c_err;
+  const float qn = sqrtf(acc), vn_max = sqrtf(a.vv_max);
+  // values first, three unconditional stores after: hipcc (ROCm 7.2) mis-sinks the common
+  // store of a three-way branch here (the dot arm reached it with an undefined index)
+  float va, vg, vs;
+  if (a.metric == MI355_METRIC_L2) {  // lo = (1-c)(qq + vv) - 2 s
+    va = (1.f - c) * acc;
+    vg = -2.f;
+    vs = 2.f * c * (acc + a.vv_max);
+  } else if (a.metric == MI355_METRIC_COSINE) {  // lo = (1 - 2c) - s / (|q||v|)   (eps = 2c: dot + both norms)
+    va = 1.f - 2.f * c;
+    vg = -1.f / qn;
+    vs = 4.f * c;
+  } else {  // dot: lo = 1 - s - 1.01 c |q||v|   (1.01: |v| is the norm of the bf16 values)
+    va = 1.f;
+    vg = 1.01f * c * qn;  // multiplies |v| in the epilogue
+    vs = 2.02f * c * qn * vn_max;
+  }
+  if (!(vs == vs)) vs = __builtin_huge_valf();  // 0 * inf: no usable bound -> every group is a candidate
+  a.qa[b] = va;
+  a.qg[b] = vg;
+  a.qslack[b] = vs;
+}
+
+// ------------------------------------------------------------------ the GEMM ---
+struct FlatGemmArgs {
+  const uint16_t* v;     // [n_rows, dimp] bf16 (shadow or the column itself)
+  const uint16_t* qb;    // [nq_pad, dimp] bf16
+  const float* vv;       // [n_rows]
+  const float* qa;       // [nq_pad]
+  const float* qg;       // [nq_pad]
+  uint64_t n_rows;
+  uint32_t dimp, nq_pad;
+  uint32_t n_qtiles;     // nq_pad / 128
+  uint32_t n_rtiles;     // ceil(n_rows / 128)
+  float omc;             // 1 - c_err (weight of |v|^2 in the L2 bound)
+  float* gm;             // [n_rtiles * 4][nq_pad] group minima of lo
+};
+
+__device__ __forceinline__ void fg_glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// 256 threads = 4 waves as 2 (rows) x 2 (queries); each wave owns a 64 x 64 block of
+// the 128 x 128 tile = 4 x 4 MFMA tiles of 16 x 16.  LDS: 2 stages x (A 16 KiB + B
+// 16 KiB), rows of 128 B stored with the 16-B chunk index XOR (row & 7) so that the
+// ds_read_b128 fragment reads of 16 consecutive rows spread over all banks; the
+// swizzle is applied on the global source address because LDS-DMA writes lane-linear.
+template <int METRIC>
+__global__ __launch_bounds__(256, 2) void k_flat_gemm(FlatGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  // XCD-aware order: the query tiles of one row tile run back to back on ONE XCD
+  // (block b lands on XCD b % 8), so the row tile is fetched from HBM once.
+  const uint32_t b = blockIdx.x;
+  const uint32_t xcd = b & 7u, slot = b >> 3;
+  const uint32_t qt = slot % a.n_qtiles;
+  const uint32_t rt = (slot / a.n_qtiles) * 8u + xcd;
+  if (rt >= a.n_rtiles) return;
+  const uint64_t row0 = (uint64_t)rt * FG_BM;
+  const uint32_t q0 = qt * FG_BN;
+  const uint32_t KT = a.dimp / FG_BK;
+  const size_t pitch = (size_t)a.dimp * 2;  // bytes per row of v / qb
+
+  // loader: this thread's 4 slots per operand per stage (slot = i*256 + tid)
+  const unsigned char* gA[4];
+  const unsigned char* gB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t s = i * 256 + tid, r = s >> 3, c = s & 7u;
+    const uint32_t sc = c ^ (r & 7u);
+    uint64_t vr = row0 + r;
+    if (vr >= a.n_rows) vr = a.n_rows - 1;  // clamped; masked in the epilogue
+    gA[i] = (const unsigned char*)a.v + vr * pitch + sc * 16u;
+    gB[i] = (const unsigned char*)a.qb + (size_t)(q0 + r) * pitch + sc * 16u;
+  }
+  auto stage = [&](uint32_t kt, uint32_t buf) {
+    unsigned char* sA = smem + buf * (2 * FG_TILE_BYTES);
+    unsigned char* sB = sA + FG_TILE_BYTES;
+    const size_t koff = (size_t)kt * (FG_BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fg_glds16(gA[i] + koff, sA + (i * 256 + wid * 64) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fg_glds16(gB[i] + koff, sB + (i * 256 + wid * 64) * 16);
+  };
+
+  fg_f32x4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = fg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses (bytes inside a stage): row*128 + ((chunk ^ (row&7)) << 4)
+  const uint32_t fr = lane & 15, fk = lane >> 4;
+  uint32_t offA[4], offB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    offA[i] = (wr * 64 + i * 16 + fr) * 128;
+    offB[i] = (wc * 64 + i * 16 + fr) * 128;
+  }
+  const uint32_t sw = fr & 7u;  // (row & 7) is the same for A and B fragments of this lane
+
+  stage(0, 0);
+  for (uint32_t kt = 0; kt < KT; ++kt) {
+    const uint32_t buf = kt & 1u;
+    if (kt + 1 < KT) {
+      stage(kt + 1, buf ^ 1u);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage's 8 DMAs have landed, the next 8 fly on
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* sA = smem + buf * (2 * FG_TILE_BYTES);
+    const unsigned char* sB = sA + FG_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint32_t ch = ((kk * 4 + fk) ^ sw) << 4;
+      fg_bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *(const fg_bf16x8*)(sA + offA[i] + ch);
+        fb[i] = *(const fg_bf16x8*)(sB + offB[i] + ch);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
+  }
+
+  // ---- epilogue: lo = approx - eps, minimum per 32-row group ------------------
+  // D layout (16x16): col = lane & 15 -> query, row = (lane >> 4) * 4 + reg -> row of V
+  float qa[4], qg[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const uint32_t n = q0 + wc * 64 + ni * 16 + fr;
+    qa[ni] = a.qa[n];
+    qg[ni] = a.qg[n];
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {  // the wave's two groups: rows 0..31 and 32..63
+    float gmin[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) gmin[ni] = __builtin_huge_valf();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int mi = g * 2 + h;
+      const uint64_t r0 = row0 + wr * 64 + mi * 16 + fk * 4;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const uint64_t r = r0 + reg;
+        if (r >= a.n_rows) continue;
+        const float vv = a.vv[r];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const float s = acc[mi][ni][reg];
+          float lo;
+          if (METRIC == MI355_METRIC_L2)
+            lo = qa[ni] + a.omc * vv + qg[ni] * s;             // (1-c)(qq + vv) - 2 s
+          else if (METRIC == MI355_METRIC_COSINE)
+            lo = qa[ni] + qg[ni] * s * (1.0f / sqrtf(vv));     // (1-2c) - s / (|q||v|)
+          else
+            lo = qa[ni] - s - qg[ni] * sqrtf(vv);              // 1 - s - 1.01 c |q||v|
+          // non-finite scores (overflow, NaN inputs) must never be filtered out here:
+          // the exact re-rank decides what they are
+          if (!(fabsf(lo) < __builtin_huge_valf())) lo = -__builtin_huge_valf();
+          gmin[ni] = fminf(gmin[ni], lo);
+        }
+      }
+    }
+    const uint32_t grp = rt * 4 + wr * 2 + g;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float v = gmin[ni];
+      v = fminf(v, __shfl_xor(v, 16));
+      v = fminf(v, __shfl_xor(v, 32));
+      if (fk == 0) a.gm[(size_t)grp * a.nq_pad + q0 + wc * 64 + ni * 16 + fr] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------- threshold + candidates ---
+// segment minima: gm [n_groups][nq_pad] -> seg [n_seg][nq_pad]
+__global__ __launch_bounds__(256) void k_flat_segmin(const float* __restrict__ gm, uint32_t n_groups,
+                                                     uint32_t nq_pad, uint32_t groups_per_seg,
+                                                     float* __restrict__ seg) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t s = blockIdx.y;
+  if (q >= nq_pad) return;
+  const uint32_t g0 = s * groups_per_seg, g1 = min(n_groups, g0 + groups_per_seg);
+  float m = __builtin_huge_valf();
+  for (uint32_t g = g0; g < g1; ++g) m = fminf(m, gm[(size_t)g * nq_pad + q]);
+  seg[(size_t)s * nq_pad + q] = m;
+}
+
+// tau_q = (k-th smallest segment minimum) + slack_q; one wave per query
+template <int KPL>
+__global__ __launch_bounds__(64) void k_flat_tau(const float* __restrict__ seg, uint32_t n_seg, uint32_t nq_pad,
+                                                 uint32_t k, const float* __restrict__ qslack,
+                                                 float* __restrict__ tau, uint32_t* __restrict__ cand_cnt) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  WaveTopK<KPL> top;
+  top.init(k, lane);
+  for (uint32_t s0 = 0; s0 < n_seg; s0 += MI355_WAVE) {
+    const uint32_t s = s0 + lane;
+    float v = 0.f;
+    if (s < n_seg) v = seg[(size_t)s * nq_pad + q];
+    // -inf marks "score not representable": always a candidate, never evidence for the bound
+    top.offer(s < n_seg && v > -__builtin_huge_valf(), v, s, (uint64_t)s, lane);
+  }
+  // thr_d is the worst kept key = the k-th smallest once k segments were offered
+  float t = top.thr_d;
+  if (n_seg < k) t = __builtin_huge_valf();
+  if (lane == 0) {
+    tau[q] = t + qslack[q];
+    cand_cnt[q] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_flat_compact(const float* __restrict__ gm, uint32_t n_groups,
+                                                      uint32_t nq_pad, uint32_t nq, const float* __restrict__ tau,
+                                                      uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ cand) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const uint32_t per = (n_groups + gridDim.y - 1) / gridDim.y;
+  const uint32_t g0 = blockIdx.y * per, g1 = min(n_groups, g0 + per);
+  const float t = tau[q];
+  for (uint32_t g = g0; g < g1; ++g) {
+    const float v = gm[(size_t)g * nq_pad + q];
+    if (v <= t) {
+      const uint32_t i = atomicAdd(&cand_cnt[q], 1u);
+      if (i < FG_CAND_CAP) cand[(size_t)q * FG_CAND_CAP + i] = g;
+    }
+  }
+}
+
+// ----------------------------------------------------------- exact re-rank ----
+// One 256-thread workgroup per query: the contract's chain on every row of the
+// candidate groups (or on ALL rows when the list overflowed), exact top-k.
+struct FlatRerankArgs {
+  FlatArgs f;               // vectors / dtype / row_ids / n_rows / dim / metric / q / range (kk = k)
+  const uint32_t* cand_cnt; // [nq]
+  const uint32_t* cand;     // [nq][FG_CAND_CAP] group ids
+  uint64_t* out_ids;        // [nq, k]
+  float* out_dist;
+  uint32_t* out_cnt;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void k_flat_rerank(FlatRerankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const FlatArgs& f = a.f;
+  float* sq = (float*)smem;                                                      // [dim]
+  Cand* stage = (Cand*)(smem + (((size_t)f.dim * 4 + 15) & ~(size_t)15));        // [4][k]
+  __shared__ float s_qq;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  const float* q = f.q + (size_t)b * f.dim;
+  for (uint32_t d = tid; d < f.dim; d += 256) sq[d] = q[d];
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.f;
+    for (uint32_t d = 0; d < f.dim; ++d) acc = __fmaf_rn(sq[d], sq[d], acc);
+    s_qq = acc;
+  }
+  __syncthreads();
+  const float qq = s_qq;
+  const uint32_t cnt = a.cand_cnt[b];
+  const bool all = cnt > FG_CAND_CAP;
+  const uint64_t total = all ? f.n_rows : (uint64_t)cnt * FG_GROUP;
+  WaveTopK<KPL> top;
+  top.init(f.kk, lane);
+  for (uint64_t i0 = 0; i0 < total; i0 += 256) {
+    const uint64_t i = i0 + tid;
+    uint64_t row = i;
+    if (!all && i < total) row = (uint64_t)a.cand[(size_t)b * FG_CAND_CAP + (uint32_t)(i / FG_GROUP)] * FG_GROUP + (i % FG_GROUP);
+    bool ok = i < total && row < f.n_rows;
+    float d = 0.f;
+    if (ok) {
+      d = exact_distance(sq, f.vectors, f.dtype, row, f.dim, f.metric, qq);
+      ok = d <= top.thr_d && in_range(d, f.range);
+    }
+    if (__any(ok)) {
+      uint64_t id = 0;
+      if (ok) id = f.row_ids ? f.row_ids[row] : row;
+      top.offer(ok, d, (uint32_t)row, id, lane);
+    }
+  }
+  top.store(stage + (size_t)wid * f.kk, lane);
+  __syncthreads();
+  if (wid == 0) {
+    const uint32_t n = 3 * f.kk;
+    for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
+      const uint32_t t = t0 + lane;
+      Cand c;
+      c.d = 0.f;
+      c.pos = CAND_EMPTY_POS;
+      c.id = 0;
+      if (t < n) c = stage[f.kk + t];
+      top.offer(t < n && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
+    }
+    uint64_t* oi = a.out_ids + (size_t)b * f.kk;
+    float* od = a.out_dist + (size_t)b * f.kk;
+    for (uint32_t g = lane; g < f.kk; g += MI355_WAVE) {
+      oi[g] = ~0ull;
+      od[g] = __builtin_huge_valf();
+    }
+    const uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
+      oi[rk] = id;
+      od[rk] = d;
+    });
+    if (lane == 0) a.out_cnt[b] = n_out;
+  }
+}

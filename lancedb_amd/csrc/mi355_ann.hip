@@ -22,6 +22,7 @@
 
 #include "../../include/mi355_ann.h"
 #include "kernels_flat.h"
+#include "kernels_flat_mfma.h"
 #include "kernels_ivfpq.h"
 #include "kernels_skew.h"
 
@@ -134,6 +135,13 @@ struct mi355_flat {
   const uint64_t* borrowed_ids = nullptr;
   bool has_row_ids = false;
   DevBuf w_q, w_cand, w_ids, w_dist, w_cnt;
+  // MFMA filter + exact re-rank (kernels_flat_mfma.h)
+  bool mfma = false;       // built at open when the column is large enough
+  bool shadowed = false;   // GEMM reads a bf16 shadow (column is f32/f16 or dim % 64 != 0)
+  uint32_t dimp = 0;
+  float c_err = 0.f, vv_max = 0.f;
+  DevBuf shadow, vv, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand;
+  uint32_t last_path = 0;  // 1 = MFMA filter, 2 = exact sweep (reported by mi355_flat_info)
 };
 
 static int32_t drain_events(mi355_index* ix, bool discard);
@@ -1102,15 +1110,174 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
       return bail(fail(MI355_ERR_RUNTIME, "upload of row ids failed"));
     f->has_row_ids = true;
   }
+  // MFMA filter data: bf16 shadow (if needed), per-row |v|^2 and its maximum
+  {
+    const char* fm = getenv("MI355_FLAT");  // dev knob: "exact" keeps the scalar sweep only
+    const bool force_exact = fm && !strcmp(fm, "exact");
+    if (!force_exact && d->n_rows >= env_u32("MI355_FLAT_MFMA_MIN_ROWS", 4096)) {
+      f->dimp = (d->dim + 63u) & ~63u;
+      f->shadowed = d->dtype != MI355_DTYPE_BF16 || f->dimp != d->dim;
+      if (f->shadowed) {
+        s = f->shadow.ensure((size_t)d->n_rows * f->dimp * 2);
+        if (s) return bail(s);
+      }
+      s = f->vv.ensure(sizeof(float) * d->n_rows);
+      if (s) return bail(s);
+      s = f->vmax.ensure(64);
+      if (s) return bail(s);
+      if (hipMemsetAsync(f->vmax.p, 0, 64, f->stream) != hipSuccess) return bail(fail(MI355_ERR_RUNTIME, "memset failed"));
+      FlatRowPrepArgs ra;
+      ra.vectors = f->vectors.p;
+      ra.dtype = d->dtype;
+      ra.dim = d->dim;
+      ra.dimp = f->dimp;
+      ra.n_rows = d->n_rows;
+      ra.shadow = f->shadowed ? f->shadow.as<uint16_t>() : nullptr;
+      ra.vv = f->vv.as<float>();
+      ra.max_key = f->vmax.as<uint32_t>();
+      hipLaunchKernelGGL(k_flat_prep_rows, dim3((uint32_t)((d->n_rows + 3) / 4)), dim3(256), 0, f->stream, ra);
+      uint32_t key = 0;
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(&key, f->vmax.p, 4, hipMemcpyDeviceToHost, f->stream) != hipSuccess ||
+          hipStreamSynchronize(f->stream) != hipSuccess)
+        return bail(fail(MI355_ERR_RUNTIME, "building the flat filter data failed"));
+      // inverse of f32_sort_key for non-negative values
+      uint32_t u = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+      memcpy(&f->vv_max, &u, 4);
+      if (key == 0) f->vv_max = 0.f;
+      // relative error of the bf16 dot product the filter must absorb: query rounding 2^-9,
+      // row rounding (value + its norm) 3 * 2^-9 when the column was converted, accumulation
+      f->c_err = ldexpf(1.f, -9) * (d->dtype != MI355_DTYPE_BF16 ? 4.f : 1.f) + (float)f->dimp * ldexpf(1.f, -22);
+      f->mfma = true;
+    }
+  }
   if (hipStreamSynchronize(f->stream) != hipSuccess) return bail(fail(MI355_ERR_RUNTIME, "sync failed"));
   *out = f;
+  return MI355_OK;
+}
+
+// The MFMA filter + exact re-rank over queries [d_q, d_q + n) (device), results in d_ids/d_dist/d_cnt
+static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint32_t metric, uint32_t k,
+                             const RangeFilter& range, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt) {
+  hipStream_t st = f->stream;
+  const uint32_t n_rtiles = (uint32_t)((f->n_rows + FG_BM - 1) / FG_BM);
+  const uint32_t n_groups = n_rtiles * 4;
+  uint32_t groups_per_seg = (n_groups + FG_MAX_SEG - 1) / FG_MAX_SEG;
+  const uint32_t n_seg = (n_groups + groups_per_seg - 1) / groups_per_seg;
+  // bound the group-minimum matrix (n_groups x queries f32) to ~2 GiB per pass
+  const size_t budget = (size_t)env_u32("MI355_WORKSPACE_MB", 2048) << 20;
+  uint32_t chunk = (uint32_t)std::min<size_t>(((size_t)nq + 127) & ~(size_t)127,
+                                              std::max<size_t>(128, (budget / ((size_t)n_groups * 4)) & ~(size_t)127));
+  const int kpl = kpl_for(k);
+  const bool dbg_sync = env_u32("MI355_FLAT_SYNC", 0) != 0;  // dev: synchronise after every stage to localise a fault
+  auto stage_ok = [&](const char* what) -> int32_t {
+    if (!dbg_sync) return MI355_OK;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(MI355_ERR_RUNTIME, "flat stage %s failed: %s", what, hipGetErrorString(e));
+    fprintf(stderr, "[mi355] flat stage %s ok\n", what);
+    return MI355_OK;
+  };
+  ST_TRY(f->g_qb.ensure((size_t)chunk * f->dimp * 2));
+  ST_TRY(f->g_qa.ensure(sizeof(float) * chunk));
+  ST_TRY(f->g_qg.ensure(sizeof(float) * chunk));
+  ST_TRY(f->g_slack.ensure(sizeof(float) * chunk));
+  ST_TRY(f->g_tau.ensure(sizeof(float) * chunk));
+  ST_TRY(f->g_gm.ensure(sizeof(float) * (size_t)n_groups * chunk));
+  ST_TRY(f->g_seg.ensure(sizeof(float) * (size_t)n_seg * chunk));
+  ST_TRY(f->g_cnt.ensure(sizeof(uint32_t) * chunk));
+  ST_TRY(f->g_cand.ensure(sizeof(uint32_t) * (size_t)chunk * FG_CAND_CAP));
+  for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
+    const uint32_t n = std::min(chunk, nq - q0);
+    const uint32_t n_pad = (n + 127u) & ~127u;
+    FlatQueryPrepArgs qa;
+    qa.q = d_q + (size_t)q0 * f->dim;
+    qa.nq = n;
+    qa.nq_pad = n_pad;
+    qa.dim = f->dim;
+    qa.dimp = f->dimp;
+    qa.metric = metric;
+    qa.c_err = f->c_err;
+    qa.vv_max = f->vv_max;
+    qa.qb = f->g_qb.as<uint16_t>();
+    qa.qa = f->g_qa.as<float>();
+    qa.qg = f->g_qg.as<float>();
+    qa.qslack = f->g_slack.as<float>();
+    hipLaunchKernelGGL(k_flat_prep_queries, dim3((n_pad + 3) / 4), dim3(256), 0, st, qa);
+    ST_TRY(stage_ok("prep_queries"));
+    FlatGemmArgs ga;
+    ga.v = f->shadowed ? f->shadow.as<uint16_t>() : (const uint16_t*)f->vectors.p;
+    ga.qb = qa.qb;
+    ga.vv = f->vv.as<float>();
+    ga.qa = qa.qa;
+    ga.qg = qa.qg;
+    ga.n_rows = f->n_rows;
+    ga.dimp = f->dimp;
+    ga.nq_pad = n_pad;
+    ga.n_qtiles = n_pad / FG_BN;
+    ga.n_rtiles = n_rtiles;
+    ga.omc = 1.f - f->c_err;
+    ga.gm = f->g_gm.as<float>();
+    const uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;
+    const size_t gemm_lds = 4 * FG_TILE_BYTES;
+#define LAUNCH_FG(MET)                                                                              \
+  {                                                                                                 \
+    auto kern = k_flat_gemm<MET>;                                                                   \
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)gemm_lds));                                                    \
+    hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(256), gemm_lds, st, ga);                       \
+  }
+    if (metric == MI355_METRIC_L2) LAUNCH_FG(MI355_METRIC_L2)
+    else if (metric == MI355_METRIC_COSINE) LAUNCH_FG(MI355_METRIC_COSINE)
+    else LAUNCH_FG(MI355_METRIC_DOT)
+#undef LAUNCH_FG
+    HIP_TRY(hipGetLastError());
+    ST_TRY(stage_ok("gemm"));
+    hipLaunchKernelGGL(k_flat_segmin, dim3((n_pad + 255) / 256, n_seg), dim3(256), 0, st, ga.gm, n_groups, n_pad,
+                       groups_per_seg, f->g_seg.as<float>());
+    if (kpl == 1)
+      hipLaunchKernelGGL(k_flat_tau<1>, dim3(n), dim3(64), 0, st, f->g_seg.as<float>(), n_seg, n_pad, k, qa.qslack, f->g_tau.as<float>(), f->g_cnt.as<uint32_t>());
+    else if (kpl == 2)
+      hipLaunchKernelGGL(k_flat_tau<2>, dim3(n), dim3(64), 0, st, f->g_seg.as<float>(), n_seg, n_pad, k, qa.qslack, f->g_tau.as<float>(), f->g_cnt.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(k_flat_tau<4>, dim3(n), dim3(64), 0, st, f->g_seg.as<float>(), n_seg, n_pad, k, qa.qslack, f->g_tau.as<float>(), f->g_cnt.as<uint32_t>());
+    ST_TRY(stage_ok("segmin+tau"));
+    const uint32_t ysplit = std::min<uint32_t>(256, std::max<uint32_t>(1, n_groups / 512));
+    hipLaunchKernelGGL(k_flat_compact, dim3((n + 255) / 256, ysplit), dim3(256), 0, st, ga.gm, n_groups, n_pad, n,
+                       f->g_tau.as<float>(), f->g_cnt.as<uint32_t>(), f->g_cand.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    ST_TRY(stage_ok("compact"));
+    FlatRerankArgs ra;
+    ra.f.vectors = f->vectors.p;
+    ra.f.dtype = f->dtype;
+    ra.f.row_ids = f->has_row_ids ? f->row_ids.as<uint64_t>() : nullptr;
+    ra.f.n_rows = f->n_rows;
+    ra.f.dim = f->dim;
+    ra.f.metric = metric;
+    ra.f.q = d_q + (size_t)q0 * f->dim;
+    ra.f.slice_rows = 0;
+    ra.f.n_slices = 1;
+    ra.f.kk = k;
+    ra.f.range = range;
+    ra.f.cand = nullptr;
+    ra.cand_cnt = f->g_cnt.as<uint32_t>();
+    ra.cand = f->g_cand.as<uint32_t>();
+    ra.out_ids = d_ids + (size_t)q0 * k;
+    ra.out_dist = d_dist + (size_t)q0 * k;
+    ra.out_cnt = d_cnt + q0;
+    const size_t rl = (((size_t)f->dim * 4 + 15) & ~(size_t)15) + sizeof(Cand) * 4 * k;
+    launch_by_kpl(kpl, k_flat_rerank<1>, k_flat_rerank<2>, k_flat_rerank<4>, dim3(n), dim3(256), rl, st, ra);
+    HIP_TRY(hipGetLastError());
+    ST_TRY(stage_ok("rerank"));
+  }
   return MI355_OK;
 }
 
 extern "C" int32_t mi355_flat_close(mi355_flat* f) {
   if (!f) return MI355_OK;
   (void)hipSetDevice(f->device);
-  DevBuf* bufs[] = {&f->vectors, &f->row_ids, &f->w_q, &f->w_cand, &f->w_ids, &f->w_dist, &f->w_cnt};
+  DevBuf* bufs[] = {&f->vectors, &f->row_ids, &f->w_q,  &f->w_cand, &f->w_ids,  &f->w_dist, &f->w_cnt,
+                    &f->shadow,  &f->vv,      &f->vmax, &f->g_qb,   &f->g_qa,   &f->g_qg,   &f->g_slack,
+                    &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand};
   for (DevBuf* b : bufs) b->release();
   if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
@@ -1169,6 +1336,18 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
     d_dist = f->w_dist.as<float>();
     d_cnt = f->w_cnt.as<uint32_t>();
   }
+  RangeFilter rng;
+  rng.has_lower = p->has_lower_bound;
+  rng.has_upper = p->has_upper_bound;
+  rng.lower = p->lower_bound;
+  rng.upper = p->upper_bound;
+  // MFMA filter + exact re-rank whenever the column carries the filter data.  A lower
+  // bound makes "the k best" and "the k best in range" different sets: exact sweep.
+  const bool use_mfma = f->mfma && !p->has_lower_bound;
+  f->last_path = use_mfma ? 1 : 2;
+  if (use_mfma) {
+    ST_TRY(run_flat_mfma(f, d_q, n_queries, metric, k, rng, d_ids, d_dist, d_cnt));
+  } else {
   // enough work items to fill 256 CUs, at least 1024 rows each
   uint32_t slice = (uint32_t)std::max<uint64_t>(1024, (f->n_rows + 2047) / 2048);
   slice = (slice + 255u) & ~255u;
@@ -1208,6 +1387,7 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
     launch_by_kpl(kpl, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
     HIP_TRY(hipGetLastError());
   }
+  }  // exact sweep
   if (host_io) {
     HIP_TRY(hipMemcpyAsync(out_rowids, d_ids, sizeof(uint64_t) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
@@ -1219,6 +1399,13 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
         return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms", (long long)ms, p->timeout_ms);
     }
   }
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_flat_info(const mi355_flat* f, uint32_t* out_last_path, uint32_t* out_has_filter) {
+  if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
+  if (out_last_path) *out_last_path = f->last_path;
+  if (out_has_filter) *out_has_filter = f->mfma ? 1u : 0u;
   return MI355_OK;
 }
 

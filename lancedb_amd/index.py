@@ -203,6 +203,12 @@ class FlatIndex(_Handle):
     def sync(self):
         check(lib().mi355_flat_sync(self._h))
 
+    def info(self):
+        """-> (last_path, has_filter): 1 = MFMA filter + exact re-rank, 2 = exact sweep."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        check(lib().mi355_flat_info(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def search(self, queries, params=None, out=None, **kw):
         kw.setdefault("nprobe_min", 1)
         kw.setdefault("nprobe_max", 1)

@@ -273,6 +273,54 @@ def test_flat_matches_oracle(oracle, metric):
     _assert_same(fh.search(q, k=10, metric=mt), oracle.flat_search(h, q, k=10, dtype=_abi.DTYPE_F16, metric=mt))
 
 
+def test_flat_mfma_filter_is_exact_on_adversarial_columns(oracle):
+    """The bf16 MFMA filter + exact re-rank must return exactly the exact sweep's
+    rows: duplicates (every score ties -> candidate overflow -> exact re-scan),
+    near-duplicates inside the bf16 rounding error, zero / NaN / huge rows, ragged
+    batch sizes and dims that need padding."""
+    rng = np.random.default_rng(17)
+    n, dim = 20000, 80
+    v = rng.normal(size=(n, dim)).astype(np.float32)
+    v[100:4100] = v[100]                                  # 4000 exact duplicates
+    v[5000:5200] = v[5000] + rng.normal(0, 1e-4, size=(200, dim)).astype(np.float32)  # inside bf16 eps
+    v[6000] = 0.0                                         # zero norm (cosine -> NaN -> dropped)
+    v[6001, 3] = np.nan
+    v[6002] = 3e38                                        # squares overflow
+    q = np.concatenate([v[[100, 5000, 6000, 6002]], rng.normal(size=(127, dim)).astype(np.float32)])
+    f = lancedb_amd.FlatIndex(v)
+    assert f.info()[1] == 1
+    for metric in ("l2", "cosine", "dot"):
+        mt = _abi.METRIC_NAMES[metric]
+        for k in (1, 10, 200):
+            _assert_same(f.search(q, k=k, metric=mt), oracle.flat_search(v, q, k=k, metric=mt))
+            assert f.info()[0] == 1
+    # upper bound only stays on the filter path; a lower bound takes the exact sweep
+    ids, dist, _, _ = oracle.flat_search(v, q, k=10)
+    kw = dict(k=10, upper_bound=float(dist[5, 6]))
+    _assert_same(f.search(q, **kw), oracle.flat_search(v, q, **kw))
+    assert f.info()[0] == 1
+    kw = dict(k=10, lower_bound=float(dist[5, 2]))
+    _assert_same(f.search(q, **kw), oracle.flat_search(v, q, **kw))
+    assert f.info()[0] == 2
+
+
+def test_flat_mfma_bf16_column_c2_shape(oracle):
+    """BASELINE.json configs[1] shape at reduced N: 768-d bf16 column, L2 and cosine,
+    a 256-query batch; row ids permuted."""
+    rng = np.random.default_rng(0x1A2CE)
+    n, dim = 50000, 768
+    v = rng.normal(size=(n, dim)).astype(np.float32)
+    bf = (v.view(np.uint32) >> 16).astype(np.uint16)
+    rid = rng.permutation(n).astype(np.uint64)
+    q = rng.normal(size=(256, dim)).astype(np.float32)
+    f = lancedb_amd.FlatIndex(bf, rid, dtype=_abi.DTYPE_BF16)
+    for metric in ("l2", "cosine"):
+        mt = _abi.METRIC_NAMES[metric]
+        _assert_same(f.search(q, k=10, metric=mt),
+                     oracle.flat_search(bf, q, k=10, row_ids=rid, dtype=_abi.DTYPE_BF16, metric=mt))
+    assert f.info() == (1, 1)
+
+
 def test_flat_reference_goldens_on_gpu():
     """The reference's own flat-search expectations, run through the HIP path."""
     import json

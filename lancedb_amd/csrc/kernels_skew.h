@@ -40,10 +40,18 @@
 // partition's codes are read from HBM once and then served by that XCD's 4 MiB
 // L2.  Placement only affects speed; any CU may steal from any queue.
 #pragma once
+#include <type_traits>
+
 #include "kernels_ivfpq.h"
 #include "skew_chunks.inc"  // generated inner blocks; defines SK_ADDR_* / SK_SPLIT_*
 
-#define SK_STREAMS 16u
+#ifdef SK_DUAL
+#define SK_CHAINS 2u  // rows in flight per lane (streams per wave)
+#else
+#define SK_CHAINS 1u
+#endif
+#define SK_UNITS 16u                        // units per partition = waves of the 1024-thread scan workgroup
+#define SK_STREAMS (SK_UNITS * SK_CHAINS)   // tile g belongs to stream g % SK_STREAMS
 #define SK_TILE 64u
 #define SK_TAIL_CHUNKS 2u  // 32 skew steps / 16 steps per chunk
 #define SK_NONE 0xFFFFFFFFu
@@ -71,21 +79,39 @@ __host__ __device__ __forceinline__ uint32_t sk_phase(uint32_t l) {
 #endif
 }
 
-// tiles of stream w of a partition with n_tiles tiles
-__host__ __device__ __forceinline__ uint32_t sk_stream_tiles(uint32_t n_tiles, uint32_t w) {
-  return n_tiles / SK_STREAMS + (w < n_tiles % SK_STREAMS ? 1u : 0u);
+// Unit w of a partition = the SK_CHAINS streams w*SK_CHAINS .. scanned together by
+// one wave.  Its chains are padded to the tile count of its first stream.
+__host__ __device__ __forceinline__ uint32_t sk_unit_tiles(uint32_t n_tiles, uint32_t w) {
+  return n_tiles / SK_STREAMS + (w * SK_CHAINS < n_tiles % SK_STREAMS ? 1u : 0u);
 }
-// first 1-KiB chunk of stream w inside the partition block (cpt = M/16 chunks per tile)
-__host__ __device__ __forceinline__ uint32_t sk_stream_chunk0(uint32_t n_tiles, uint32_t w, uint32_t cpt) {
+// first 1-KiB chunk of unit w inside the partition block (cpt = M/16 chunks per tile);
+// a unit stores (cpt * tiles + 2 tail) groups of SK_CHAINS chunks (one per chain)
+__host__ __device__ __forceinline__ uint32_t sk_unit_chunk0(uint32_t n_tiles, uint32_t w, uint32_t cpt) {
   const uint32_t q = n_tiles / SK_STREAMS, r = n_tiles % SK_STREAMS;
-  const uint32_t tiles_before = q * w + sk_min_u32(w, r);
-  const uint32_t nonempty_before = q ? w : sk_min_u32(w, r);
-  return cpt * tiles_before + SK_TAIL_CHUNKS * nonempty_before;
+  const uint32_t longer = (r + SK_CHAINS - 1) / SK_CHAINS;  // units holding one tile more
+  const uint32_t tiles_before = q * w + sk_min_u32(w, longer);
+  const uint32_t nonempty_before = q ? w : sk_min_u32(w, longer);
+  return SK_CHAINS * (cpt * tiles_before + SK_TAIL_CHUNKS * nonempty_before);
 }
 // 1-KiB chunks of a whole partition block
 __host__ __device__ __forceinline__ uint64_t sk_part_chunks(uint32_t n_tiles, uint32_t cpt) {
-  return (uint64_t)cpt * n_tiles + SK_TAIL_CHUNKS * sk_min_u32(SK_STREAMS, n_tiles);
+  const uint32_t q = n_tiles / SK_STREAMS, r = n_tiles % SK_STREAMS;
+  const uint32_t longer = (r + SK_CHAINS - 1) / SK_CHAINS;
+  const uint64_t unit_tiles = (uint64_t)q * SK_UNITS + longer;
+  const uint32_t nonempty = q ? SK_UNITS : longer;
+  return (uint64_t)SK_CHAINS * (cpt * unit_tiles + SK_TAIL_CHUNKS * nonempty);
 }
+// grid.x of k_pack_skew for partitions of up to max_rows rows
+__host__ __device__ __forceinline__ uint32_t sk_pack_slots(uint32_t max_rows) {
+  const uint32_t n_tiles = (max_rows + SK_TILE - 1) / SK_TILE;
+  return ((n_tiles + SK_STREAMS - 1) / SK_STREAMS + 1u) * SK_STREAMS;
+}
+// LDS bytes of the distance table: 256 codes x 128 columns (dual: slab 1 starts one row late)
+#ifdef SK_DUAL
+#define SK_TABLE_BYTES (131072u + 256u)
+#else
+#define SK_TABLE_BYTES 131072u
+#endif
 __host__ __device__ __forceinline__ bool sk_supported_m(uint32_t m) {
   return m == 32 || m == 48 || m == 64 || m == 80 || m == 96;
 }
@@ -116,20 +142,21 @@ __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
   const uint32_t p = a.part_ids[blockIdx.y];
   const uint32_t len = a.plen[p];
   const uint32_t n_tiles = (len + SK_TILE - 1) / SK_TILE;
-  const uint32_t n_slots = n_tiles + sk_min_u32(SK_STREAMS, n_tiles);
-  const uint32_t g = blockIdx.x;
-  if (g >= n_slots) return;
+  // slot -> (position n inside the unit, unit w, chain ch); n == unit tiles is the tail
+  const uint32_t slot = blockIdx.x;
+  const uint32_t st = slot % SK_STREAMS, n = slot / SK_STREAMS;
+  const uint32_t w = st / SK_CHAINS, ch = st % SK_CHAINS;
+  const uint32_t nt_w = sk_unit_tiles(n_tiles, w);
+  if (nt_w == 0 || n > nt_w) return;
   const uint32_t m = a.m, pitch = m + 1, cpt = m / 16;
-  const bool tail = g >= n_tiles;
-  const uint32_t w = tail ? g - n_tiles : g % SK_STREAMS;
-  const uint32_t nt_w = sk_stream_tiles(n_tiles, w);
-  const uint32_t n = tail ? nt_w : g / SK_STREAMS;  // tile position inside the stream
+  const bool tail = n == nt_w;
   const uint8_t* src = a.src + a.src_off[blockIdx.y];
-  // stage tile n (slot 0) and tile n-1 (slot 1) of stream w
+  // stage tile position n (slot 0) and n-1 (slot 1) of this chain's stream; positions past
+  // the stream's end (chains padded to the unit's tile count) are all padding rows
   for (uint32_t which = 0; which < 2; ++which) {
     if (which == 0 && tail) continue;
     if (which == 1 && n == 0) continue;
-    const uint32_t tg = w + SK_STREAMS * (n - which);  // global tile index
+    const uint32_t tg = st + SK_STREAMS * (n - which);  // global tile index
     const uint32_t r0 = tg * SK_TILE;
     unsigned char* t = tile + (size_t)which * 64u * pitch;
     for (uint32_t e = threadIdx.x; e < 64u * m; e += 256) {
@@ -148,7 +175,7 @@ __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
   }
   __syncthreads();
   const uint32_t n_chunks = tail ? SK_TAIL_CHUNKS : cpt;
-  uint8_t* dst = a.dst + a.code_off[p] + ((size_t)sk_stream_chunk0(n_tiles, w, cpt) + (size_t)cpt * n) * 1024u;
+  uint8_t* dst = a.dst + a.code_off[p] + (size_t)sk_unit_chunk0(n_tiles, w, cpt) * 1024u;
   for (uint32_t e = threadIdx.x; e < n_chunks * 64u; e += 256) {
     const uint32_t cc = e / 64u, l = e % 64u, lm = sk_phase(l);
     uint32_t wds[4];
@@ -168,7 +195,9 @@ __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
       }
       wds[k4] = word;
     }
-    *(uint4*)(dst + (size_t)cc * 1024u + l * 16u) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+    // chunk (n, cc) of the unit: SK_CHAINS consecutive 1-KiB chunks, one per chain
+    const size_t chunk = ((size_t)n * cpt + cc) * SK_CHAINS + ch;
+    *(uint4*)(dst + chunk * 1024u + l * 16u) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
   }
 }
 
@@ -333,11 +362,13 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   constexpr int CPT = M / 16;  // 1-KiB chunks per tile
   static_assert(M + 32 <= P, "table columns exceed the pitch");
   const IndexView& ix = a.ix;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction; tell the compiler so that per-wave loops are scalar loops
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lm = sk_phase(lane);
-  float* lut = (float*)smem;                                  // [256][P]
-  float* res = (float*)(smem + 256 * PB);                     // [dim]
-  ListEnt* lists = (ListEnt*)(smem + 256 * PB + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
+  float* lut = (float*)smem;                                  // [256][P] (dual: two slabs)
+  float* res = (float*)(smem + SK_TABLE_BYTES);               // [dim]
+  ListEnt* lists = (ListEnt*)(smem + SK_TABLE_BYTES + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
   uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);  // [NW]
   uint32_t* s_thr = s_cnt + NW;                               // [1] block threshold (sort key)
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
@@ -345,7 +376,9 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   // the gather address is (code << 9) | column bytes: the table must start at LDS address 0
   if ((uint32_t)(size_t)smem != 0u) __builtin_trap();
   const uint32_t lb = 4u * (32u - lm);  // this lane's column origin (bytes)
-#ifdef SK_ADDR_BFE
+#ifdef SK_DUAL
+  const uint32_t slab_bit = 0x10000u;
+#elif defined(SK_ADDR_BFE)
   const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane(PB);        // table pitch
 #else
   const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane(0x1fe00);   // code field of the address
@@ -421,8 +454,15 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       auto put = [&](uint32_t e, float acc) {
         const uint32_t c = e / (uint32_t)M, j = e % (uint32_t)M;
         if (dotm) acc = 1.0f - acc;
+#ifdef SK_DUAL
+        // two slabs of 256-B rows; byte address slab*65536 + c*256 + 4u (u >= 64 spills one row on)
+        const uint32_t u = j + 32;
+        lut[(u >= 64u ? 16384u : 0u) + c * 64u + u] = acc;
+        if (j >= (uint32_t)(M - 31)) lut[c * 64u + j - (M - 32)] = acc;
+#else
         lut[c * P + j + 32] = acc;
         if (j >= (uint32_t)(M - 31)) lut[c * P + j - (M - 32)] = acc;
+#endif
       };
       if (dsub == 8) {
         // 4 entries per thread per round: 8 independent 16-B loads in flight
@@ -508,7 +548,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     // a finished row: tile position tp of stream w, this lane's row
     float published = __builtin_huge_valf();
     auto consume = [&](float acc, uint32_t w, uint32_t tp) {
-      const uint32_t row = (w + SK_STREAMS * tp) * SK_TILE + lane;
+      const uint32_t row = (w + SK_STREAMS * tp) * SK_TILE + lane;  // w = stream index
       const float d = finalize_dist(acc, ix.metric, ix.m);
       bool ok = row < len && (ranged ? in_range(d, a.range) : d == d);
       // tightened by the other waves' compactions
@@ -524,10 +564,63 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       }
     };
 
-    for (uint32_t w = wid; w < SK_STREAMS && !(a.dbg & 2u); w += NW) {
-      const uint32_t nt = sk_stream_tiles(n_tiles, w);
+#ifdef SK_DUAL
+    // two streams (chains A = 2u, B = 2u + 1) per wave; codes arrive chunk by chunk through a
+    // ring of RING register slots per chain (prefetch distance RING - 1 chunks)
+    for (uint32_t u = wid; u < SK_UNITS && !(a.dbg & 2u); u += NW) {
+      const uint32_t nt = sk_unit_tiles(n_tiles, u);
       if (!nt) continue;
-      const uint4* src = (const uint4*)(pcodes + (size_t)sk_stream_chunk0(n_tiles, w, CPT) * 1024u) + lane;
+      constexpr int RING = (CPT % 3 == 0) ? 3 : (CPT % 2 == 0 ? 2 : CPT);
+      const uint32_t n_chunks = nt * CPT + SK_TAIL_CHUNKS;  // dual chunks of the unit
+      const uint4* src = (const uint4*)(pcodes + (size_t)sk_unit_chunk0(n_tiles, u, CPT) * 1024u) + lane;
+      sk_u32x4 ra[RING], rb[RING];
+      auto fetch = [&](int slot, uint32_t c) {  // dual chunk c -> ring slot (clamped: the load count per chunk is fixed)
+        c = sk_min_u32(c, n_chunks - 1);
+        sk_load2(ra[slot], rb[slot], src + (size_t)c * 128);
+      };
+#pragma unroll
+      for (int g = 0; g < RING; ++g) fetch(g, g);
+      sk_f32x2 x = {0.f, 0.f}, y = {0.f, 0.f};
+      uint32_t r = lb;  // [bit 16: slab][byte 1: code][byte 0: column origin]
+      const uint32_t sa = u * SK_CHAINS, sb = sa + 1;
+      for (uint32_t n = 0; n < nt; ++n) {
+        const uint32_t c0 = n * CPT;
+        auto chunks = [&](auto self, auto gtag) -> void {
+          constexpr int G = decltype(gtag)::value;
+          if constexpr (G < CPT) {
+            sk_wait_codes<2 * (RING - 1)>(ra[G % RING], rb[G % RING]);  // RING-1 younger chunks stay in flight
+            skew_dchunk<G>(ra[G % RING], rb[G % RING], r, slab_bit, x, y);
+            fetch(G % RING, c0 + G + RING);
+            if constexpr (G == 1) {
+              if (n > 0) {  // rows of tile position n-1 are complete on every lane after step 30
+                consume(y.x, sa, n - 1);
+                consume(y.y, sb, n - 1);
+              }
+              if (n == 0 && tid == 0 && nxt_valid) s_rec[slot ^ 1u] = nxt;
+            }
+            self(self, std::integral_constant<int, G + 1>{});
+          }
+        };
+        chunks(chunks, std::integral_constant<int, 0>{});
+        y = x;
+        x = sk_f32x2{0.f, 0.f};
+        r &= 0xffffu;  // every lane is back in slab 0 at step 0
+      }
+      {  // 31 more steps finish the last tile's rows (CPT % RING == 0: the tail sits in slots 0, 1)
+        sk_f32x2 dummy = {0.f, 0.f};
+        sk_wait_codes<0>(ra[0], rb[0]);  // also drains the clamped prefetches: the ring registers die here
+        sk_wait_codes<0>(ra[1 % RING], rb[1 % RING]);
+        skew_dchunk<0>(ra[0], rb[0], r, slab_bit, dummy, y);
+        skew_dchunk<1>(ra[1 % RING], rb[1 % RING], r, slab_bit, dummy, y);
+        consume(y.x, sa, nt - 1);
+        consume(y.y, sb, nt - 1);
+      }
+    }
+#else
+    for (uint32_t w = wid; w < SK_STREAMS && !(a.dbg & 2u); w += NW) {
+      const uint32_t nt = sk_unit_tiles(n_tiles, w);
+      if (!nt) continue;
+      const uint4* src = (const uint4*)(pcodes + (size_t)sk_unit_chunk0(n_tiles, w, CPT) * 1024u) + lane;
       // two register sets, ping-pong: tile n is scanned from one while tile n+1
       // (or the 2 tail chunks) streams into the other
       uint4 ca[CPT], cb[CPT];
@@ -573,6 +666,8 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         }
       }
     }
+
+#endif
 
     // ---- block result: exact kk best of all waves' lists, written sorted ----
     if (wl.cnt > a.kk) wl.compact(lane, idof);

@@ -330,7 +330,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     const char* lay = getenv("MI355_LAYOUT");  // dev knob: "pair" forces the generic layout
     const bool force_pair = lay && !strcmp(lay, "pair");
     // the skewed layout needs the 256 x P-dword table + residual + lists in 160 KiB of LDS
-    const size_t lds_skew = (size_t)256 * sk_pitch_dwords(m) * 4 + (size_t)d->dim * 4 + 25 * 1024;
+    const size_t lds_skew = (size_t)SK_TABLE_BYTES + (size_t)d->dim * 4 + 25 * 1024;
     ix->layout = (!force_pair && sk_supported_m(m) && d->dim <= 2048 && lds_skew <= 160u * 1024) ? MI355_SCAN_SKEW : MI355_SCAN_PAIR;
   }
   const bool skew = ix->layout == MI355_SCAN_SKEW;
@@ -416,7 +416,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
           SkewPackArgs sb = sp;
           sb.src_off += y0;
           sb.part_ids += y0;
-          hipLaunchKernelGGL(k_pack_skew, dim3((batch_max_stride + 63) / 64 + SK_STREAMS, ny), dim3(256),
+          hipLaunchKernelGGL(k_pack_skew, dim3(sk_pack_slots(batch_max_stride), ny), dim3(256),
                              2 * 64 * (m + 1), st, sb);
         } else {
           RepackArgs rb = ra;
@@ -712,7 +712,7 @@ template <int M>
 static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_t dim, uint32_t kk,
                                   hipStream_t st) {
   auto lds_of = [&](int nw, int lr) {
-    return (size_t)256 * sk_pitch_dwords(M) * 4 + (((size_t)dim * 4 + 15) & ~(size_t)15) +
+    return (size_t)SK_TABLE_BYTES + (((size_t)dim * 4 + 15) & ~(size_t)15) +
            (size_t)nw * lr * 64 * 8 + (size_t)(nw + 10) * 4 + 96;
   };
 #define LAUNCH_SK(LR, NT)                                                                       \

@@ -120,6 +120,113 @@ __device__ __forceinline__ void {name}(const uint4& cw, uint32_t lb, uint32_t pb
 """
 
 
+# --------------------------------------------------------------------------
+# dual mode: two rows per lane (chains A and B = two streams of the partition)
+# --------------------------------------------------------------------------
+# One block = 8 steps of BOTH chains: 16 gathers in flight, the adds of the two
+# chains pair up in v_pk_add_f32 (half the add instructions, and consecutive adds
+# no longer depend on each other).  The gather address is built by ONE SDWA
+# byte insert into a per-lane address register R:
+#     R = [bit 16: slab][byte 1: code][byte 0: 4 * (32 - phase)],  ds_read R offset:4t
+# i.e. address = slab*65536 + code*256 + 4u with u = t + 32 - phase the table
+# column.  The table is two 64 KiB slabs of 256-B rows: columns u < 64 in slab 0,
+# columns u >= 64 in slab 1, where the carry of 4u into the code byte simply lands
+# one row further (the LUT builder stores slab 1 with that formula).  A lane
+# crosses from slab 0 to slab 1 at step 32 + phase, so steps 32..63 set bit 16
+# under an EXEC mask for the lanes that have crossed; the bit is cleared once per
+# tile.  Temps are the fixed registers v[112:127] (pairs: even = A, odd = B).
+T0 = 112
+
+
+def dblock(k, sdwa=True):
+    """asm lines for steps 8k .. 8k+7 of both chains."""
+    lines = []
+    for e in range(8):
+        t = 8 * k + e
+        w, b = e // 4, e % 4
+        if 32 <= t < 64:  # lanes with phase <= t - 32 are in slab 1 from this step on
+            p = t - 32
+            if p < 31:
+                lines.append(f"s_bfm_b64 exec, {62 - 2 * p}, {p + 1}")  # lanes that have NOT crossed (mirrored map)
+                lines.append("s_not_b64 exec, exec")
+            lines.append("v_or_b32 %[r], %[slab], %[r]")
+            lines.append("s_mov_b64 exec, -1")
+        for ch, wn in ((0, "a"), (1, "b")):
+            lines.append(f"v_mov_b32_sdwa %[r], %[w{wn}{w}] dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_{b}")
+            lines.append(f"ds_read_b32 v{T0 + 2 * e + ch}, %[r] offset:{4 * t}")
+    in_split = False
+    for e in range(8):
+        t = 8 * k + e
+        lines.append(f"s_waitcnt lgkmcnt({14 - 2 * e})")
+        pair = f"v[{T0 + 2 * e}:{T0 + 2 * e + 1}]"
+        if t < 31:  # lanes t+1 .. 62-t (mirrored map) are still on the old row
+            lines.append(f"s_bfm_b64 exec, {62 - 2 * t}, {t + 1}")
+            lines.append(f"v_pk_add_f32 %[y], %[y], {pair}")
+            lines.append("s_not_b64 exec, exec")
+            lines.append(f"v_pk_add_f32 %[x], %[x], {pair}")
+            in_split = True
+        else:
+            if in_split:
+                lines.append("s_mov_b64 exec, -1")
+                in_split = False
+            lines.append(f"v_pk_add_f32 %[x], %[x], {pair}")
+    if in_split:
+        lines.append("s_mov_b64 exec, -1")
+    return lines
+
+
+def emit_dblock(k):
+    lines = dblock(k)
+    txt = "\n".join(f'      "{l}\\n\\t"' for l in lines)
+    clob = ", ".join(f'"v{T0 + i}"' for i in range(16))
+    return f"""
+// steps {8 * k}..{8 * k + 7} of both chains
+__device__ __forceinline__ void skew_dblock_{k}(uint32_t wa0, uint32_t wa1, uint32_t wb0, uint32_t wb1, uint32_t& r,
+                                               uint32_t slab, sk_f32x2& x, sk_f32x2& y) {{
+  asm volatile(
+{txt}
+      : [x] "+v"(x), [y] "+v"(y), [r] "+v"(r)
+      : [wa0] "v"(wa0), [wa1] "v"(wa1), [wb0] "v"(wb0), [wb1] "v"(wb1), [slab] "v"(slab)
+      : "scc", {clob});
+}}
+"""
+
+
+def render_dual():
+    src = ["// GENERATED by scripts/gen_skew_chunks.py dual=1 - do not edit by hand.\n"
+           "// 8-step x 2-chain blocks of the skewed ADC scan; see the generator's docstring.\n"
+           "#pragma once\n#define SK_DUAL 1\n#define SK_SPLIT_BFM 1\n"
+           "typedef __attribute__((ext_vector_type(2))) float sk_f32x2;\n"
+           "typedef __attribute__((ext_vector_type(4))) unsigned int sk_u32x4;  // a native vector: valid asm operand\n"]
+    for k in range(12):
+        src.append(emit_dblock(k))
+    src.append("""
+// The code stream is loaded by asm (hipcc would drain every prefetch at the loop head:
+// it cannot count them across the selection's rare row-id loads).  sk_load2 issues the
+// two 16-B loads of one dual chunk; sk_wait_codes<N> waits until at most N of the
+// loads issued after this chunk's are outstanding and names the registers "+v" so that
+// no compiler copy of them can be scheduled above the wait (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void sk_load2(sk_u32x4& a, sk_u32x4& b, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %2, off\\n\\tglobal_load_dwordx4 %1, %2, off offset:1024"
+               : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void sk_wait_codes(sk_u32x4& a, sk_u32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%c2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
+
+// blocks of chunk G (steps 16G .. 16G+15) of both chains; ca / cb = the 16 code bytes of each chain
+template <int G>
+__device__ __forceinline__ void skew_dchunk(const sk_u32x4& ca, const sk_u32x4& cb, uint32_t& r, uint32_t slab, sk_f32x2& x,
+                                            sk_f32x2& y) {
+""")
+    for g in range(6):
+        src.append(f"  if constexpr (G == {g}) {{\n    skew_dblock_{2 * g}(ca.x, ca.y, cb.x, cb.y, r, slab, x, y);\n"
+                   f"    skew_dblock_{2 * g + 1}(ca.z, ca.w, cb.z, cb.w, r, slab, x, y);\n  }}\n")
+    src.append("}\n")
+    return "".join(src)
+
+
 def render(**kw):
     cfg = dict(DEFAULTS)
     cfg.update(kw)
@@ -141,8 +248,9 @@ def main():
     for a in sys.argv[1:]:
         k, v = a.split("=")
         kw[k] = int(v) if v.isdigit() else v
+    dual = kw.pop("dual", 1)  # the committed skew_chunks.inc is the dual form; dual=0 gives the one-row blocks
     with open(OUT, "w") as f:
-        f.write(render(**kw))
+        f.write(render_dual() if dual else render(**kw))
     print("wrote", OUT, kw or DEFAULTS)
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MI355_ANN_ABI_VERSION 1u
+#define MI355_ANN_ABI_VERSION 2u
 
 /* ---- status codes (rust/lancedb/src/error.rs:55-145) -------------------- */
 enum {
@@ -140,7 +140,23 @@ typedef struct mi355_search_params {
                              = enqueue on the handle's stream and return
                              without waiting (see mi355_*_set_stream) */
   uint32_t timeout_ms;    /* 0 = none (QueryExecutionOptions.timeout, query.rs:641) */
+  /* Prefilter (QueryRequest.filter with prefilter = true, the reference's default:
+     rust/lancedb/src/query.rs:489-507, :899; table/query.rs:251-262): the rows a
+     filter kept or dropped, as the caller's evaluation of the predicate, in the
+     form lance passes to its ANN nodes (RowIdMask allow / block list [EXT]).
+     `filter_rowids` is sorted ascending, lives where io_mem says, and is applied
+     BEFORE the top-k: the result is the k nearest among the permitted rows. */
+  uint32_t filter_mode;   /* MI355_FILTER_* */
+  uint32_t reserved0;
+  const uint64_t *filter_rowids; /* [n_filter] sorted ascending, unique */
+  uint64_t n_filter;
 } mi355_search_params;
+
+enum {
+  MI355_FILTER_NONE = 0,
+  MI355_FILTER_ALLOW = 1, /* only rows whose _rowid is listed */
+  MI355_FILTER_BLOCK = 2  /* every row except the listed ones */
+};
 
 typedef struct mi355_flat_desc {
   uint32_t struct_size;

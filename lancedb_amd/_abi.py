@@ -6,7 +6,7 @@ exactly; `struct_size` guards against drift at run time.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_INVALID_INPUT = 1
@@ -32,6 +32,10 @@ CODES_PART_TRANSPOSED = 1
 SCAN_AUTO = 0
 SCAN_PAIR = 1
 SCAN_SKEW = 2
+
+FILTER_NONE = 0
+FILTER_ALLOW = 1
+FILTER_BLOCK = 2
 
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
@@ -74,6 +78,10 @@ class SearchParams(C.Structure):
         ("upper_bound", C.c_float),
         ("io_mem", C.c_uint32),
         ("timeout_ms", C.c_uint32),
+        ("filter_mode", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("filter_rowids", C.c_void_p),
+        ("n_filter", C.c_uint64),
     ]
 
 
@@ -140,7 +148,7 @@ METRIC_NAMES = {"l2": METRIC_L2, "cosine": METRIC_COSINE, "dot": METRIC_DOT}
 
 def make_params(k=10, nprobe_min=20, nprobe_max=20, refine_factor=0,
                 metric=METRIC_DEFAULT, lower_bound=None, upper_bound=None,
-                io_mem=MEM_HOST, timeout_ms=0):
+                io_mem=MEM_HOST, timeout_ms=0, allow_rowids=None, block_rowids=None):
     """Fill a SearchParams with VectorQueryRequest defaults
     (rust/lancedb/src/query.rs:1097-1114: nprobes 20/20, k 10, no refine)."""
     p = SearchParams()
@@ -156,4 +164,20 @@ def make_params(k=10, nprobe_min=20, nprobe_max=20, refine_factor=0,
     p.upper_bound = 0.0 if upper_bound is None else float(upper_bound)
     p.io_mem = io_mem
     p.timeout_ms = timeout_ms
+    # prefilter: a sorted, unique u64 array (numpy for host I/O, a device array for device I/O);
+    # the array is kept alive on the params object
+    flt = allow_rowids if allow_rowids is not None else block_rowids
+    p.filter_mode = FILTER_NONE
+    if flt is not None:
+        if allow_rowids is not None and block_rowids is not None:
+            raise ValueError("give either allow_rowids or block_rowids")
+        if hasattr(flt, "data_ptr"):
+            p._keep, ptr, n = flt, flt.data_ptr(), int(flt.shape[0])
+        else:
+            import numpy as np
+            arr = np.unique(np.ascontiguousarray(flt, dtype=np.uint64))
+            p._keep, ptr, n = arr, arr.ctypes.data, int(arr.size)
+        p.filter_mode = FILTER_ALLOW if allow_rowids is not None else FILTER_BLOCK
+        p.filter_rowids = ptr
+        p.n_filter = n
     return p

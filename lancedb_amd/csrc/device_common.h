@@ -64,6 +64,26 @@ __device__ __forceinline__ bool in_range(float d, const RangeFilter& r) {
   return true;
 }
 
+// prefilter (mi355_search_params.filter_*): sorted unique row ids, allow or block list.
+// Evaluated lazily, only for rows that already beat the running distance threshold.
+struct RowFilter {
+  uint32_t mode;  // MI355_FILTER_*
+  uint32_t pad;
+  const uint64_t* ids;
+  uint64_t n;
+};
+
+__device__ __forceinline__ bool row_permitted(uint64_t id, const RowFilter& f) {
+  if (f.mode == MI355_FILTER_NONE) return true;
+  uint64_t lo = 0, hi = f.n;
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (f.ids[mid] < id) lo = mid + 1; else hi = mid;
+  }
+  const bool found = lo < f.n && f.ids[lo] == id;
+  return f.mode == MI355_FILTER_ALLOW ? found : !found;
+}
+
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
 }

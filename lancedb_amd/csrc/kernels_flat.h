@@ -15,6 +15,7 @@ struct FlatArgs {
   uint32_t n_slices;
   uint32_t kk;
   RangeFilter range;
+  RowFilter filter;
   Cand* cand;               // [nq, n_slices, kk]
 };
 
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void k_flat_scan(FlatArgs a) {
     if (__any(ok)) {
       uint64_t id = 0;
       if (ok) id = a.row_ids ? a.row_ids[i] : i;
+      if (a.filter.mode != MI355_FILTER_NONE && ok) ok = row_permitted(id, a.filter);
       top.offer(ok, d, (uint32_t)i, id, lane);
     }
   }

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256) void k_flat_rerank(FlatRerankArgs a) {
     if (__any(ok)) {
       uint64_t id = 0;
       if (ok) id = f.row_ids ? f.row_ids[row] : row;
+      if (f.filter.mode != MI355_FILTER_NONE && ok) ok = row_permitted(id, f.filter);
       top.offer(ok, d, (uint32_t)row, id, lane);
     }
   }

@@ -258,6 +258,7 @@ struct ScanArgs {
   uint32_t n_slices;        // grid.x
   uint32_t kk;
   RangeFilter range;
+  RowFilter filter;
   Cand* cand;               // [nq, nprobe, n_slices, kk]
   uint32_t dbg;             // dev ablation mask (MI355_DBG_SKIP): 1 LUT build, 2 ADC loop, 4 top-k
 };
@@ -375,7 +376,9 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
     }
     // threshold: kk-th smallest lane minimum (>= kk rows of this wave are below it)
     float thr = wl.t_run;
-    if (a.kk <= MI355_WAVE) {
+    // (with a prefilter the lane minima include rows the filter may drop: only the list's own
+    //  running threshold, built from permitted rows, is a valid bound)
+    if (a.kk <= MI355_WAVE && a.filter.mode == MI355_FILTER_NONE) {
       uint32_t tk = wave_kth_smallest_key(elig ? f32_sort_key(lmin) : 0xFFFFFFFFu, a.kk);
       if (tk < 0xFF800000u) thr = fminf(thr, f32_from_sort_key(tk));  // below +inf's key
     }
@@ -384,8 +387,11 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
     for (int e = 0; e < VPT; ++e) any |= ((elig >> e) & 1u) && acc[e] <= thr;
     if (__any(any)) {
 #pragma unroll
-      for (int e = 0; e < VPT; ++e)
-        wl.append(((elig >> e) & 1u) && acc[e] <= thr, acc[e], lrow0 + i0r + e, thr, lane, idof);
+      for (int e = 0; e < VPT; ++e) {
+        bool take = ((elig >> e) & 1u) && acc[e] <= thr;
+        if (a.filter.mode != MI355_FILTER_NONE && take) take = row_permitted(idof(lrow0 + i0r + e), a.filter);
+        wl.append(take, acc[e], lrow0 + i0r + e, thr, lane, idof);
+      }
     }
   }
 

@@ -316,6 +316,7 @@ struct SkewArgs {
   uint32_t* qthr;           // [nq] running per-query threshold (f32 sort key)
   uint32_t nprobe, kk;
   RangeFilter range;
+  RowFilter filter;
   Cand* cand;               // [nq * nprobe][kk]
   uint32_t dbg;
 };
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       if (bk != 0xFFFFFFFFu) thr = fminf(thr, f32_from_sort_key(bk));
       ok = ok && d <= thr;
       if (__any(ok)) {
+        if (a.filter.mode != MI355_FILTER_NONE && ok) ok = row_permitted(idof(lrow0 + row), a.filter);
         wl.append(ok, d, lrow0 + row, thr, lane, idof);
         if (wl.t_run < published) {  // a compaction tightened this wave's kk-th best: share it
           published = wl.t_run;
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
 #pragma unroll
       for (int g = 0; g < RING; ++g) fetch(g, g);
       sk_f32x2 x = {0.f, 0.f}, y = {0.f, 0.f};
-      uint32_t r = lb;  // [bit 16: slab][byte 1: code][byte 0: column origin]
+      uint32_t r = lb, r2 = lb;  // [bit 16: slab][byte 1: code][byte 0: column origin]; r2: chain B's copy (nreg=2)
       const uint32_t sa = u * SK_CHAINS, sb = sa + 1;
       for (uint32_t n = 0; n < nt; ++n) {
         const uint32_t c0 = n * CPT;
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
           constexpr int G = decltype(gtag)::value;
           if constexpr (G < CPT) {
             sk_wait_codes<2 * (RING - 1)>(ra[G % RING], rb[G % RING]);  // RING-1 younger chunks stay in flight
-            skew_dchunk<G>(ra[G % RING], rb[G % RING], r, slab_bit, x, y);
+            skew_dchunk<G>(ra[G % RING], rb[G % RING], r, r2, slab_bit, x, y);
             fetch(G % RING, c0 + G + RING);
             if constexpr (G == 1) {
               if (n > 0) {  // rows of tile position n-1 are complete on every lane after step 30
@@ -605,13 +607,14 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         y = x;
         x = sk_f32x2{0.f, 0.f};
         r &= 0xffffu;  // every lane is back in slab 0 at step 0
+        r2 &= 0xffffu;
       }
       {  // 31 more steps finish the last tile's rows (CPT % RING == 0: the tail sits in slots 0, 1)
         sk_f32x2 dummy = {0.f, 0.f};
         sk_wait_codes<0>(ra[0], rb[0]);  // also drains the clamped prefetches: the ring registers die here
         sk_wait_codes<0>(ra[1 % RING], rb[1 % RING]);
-        skew_dchunk<0>(ra[0], rb[0], r, slab_bit, dummy, y);
-        skew_dchunk<1>(ra[1 % RING], rb[1 % RING], r, slab_bit, dummy, y);
+        skew_dchunk<0>(ra[0], rb[0], r, r2, slab_bit, dummy, y);
+        skew_dchunk<1>(ra[1 % RING], rb[1 % RING], r, r2, slab_bit, dummy, y);
         consume(y.x, sa, nt - 1);
         consume(y.y, sb, nt - 1);
       }

@@ -113,7 +113,7 @@ struct mi355_index {
   // code layout: MI355_SCAN_PAIR = [m][pstride] blocks, MI355_SCAN_SKEW = pre-skewed streams
   uint32_t layout = MI355_SCAN_PAIR;
   uint32_t n_cus = 256;
-  DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr;
+  DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter;
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2,
       w_dist2, w_cnt2, w_stat;
@@ -140,7 +140,7 @@ struct mi355_flat {
   bool shadowed = false;   // GEMM reads a bf16 shadow (column is f32/f16 or dim % 64 != 0)
   uint32_t dimp = 0;
   float c_err = 0.f, vv_max = 0.f;
-  DevBuf shadow, vv, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand;
+  DevBuf shadow, vv, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand, w_filter;
   uint32_t last_path = 0;  // 1 = MFMA filter, 2 = exact sweep (reported by mi355_flat_info)
 };
 
@@ -295,7 +295,8 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->w_probes,  &ix->w_cand, &ix->w_ids,    &ix->w_dist,  &ix->w_pos,
                     &ix->w_cnt,     &ix->w_ids2, &ix->w_dist2,  &ix->w_cnt2,  &ix->w_stat,
                     &ix->cbT,       &ix->order,  &ix->xcd_first, &ix->p_cnt,  &ix->p_off,
-                    &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr};
+                    &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
+                    &ix->w_filter};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -663,6 +664,26 @@ static int32_t validate_params(const mi355_search_params* p) {
     return fail(MI355_ERR_INVALID_INPUT, "mi355_search_params.struct_size %u != %zu (ABI mismatch)",
                 p->struct_size, sizeof(mi355_search_params));
   if (p->io_mem > MI355_MEM_DEVICE) return fail(MI355_ERR_INVALID_INPUT, "bad io_mem");
+  if (p->filter_mode > MI355_FILTER_BLOCK) return fail(MI355_ERR_INVALID_INPUT, "unknown filter_mode %u", p->filter_mode);
+  if (p->filter_mode != MI355_FILTER_NONE && p->n_filter && !p->filter_rowids)
+    return fail(MI355_ERR_INVALID_INPUT, "filter_rowids is NULL");
+  return MI355_OK;
+}
+
+// device view of the prefilter; a host array is staged into `stage`
+static int32_t make_row_filter(const mi355_search_params* p, DevBuf& stage, hipStream_t st, RowFilter* out) {
+  out->mode = p->filter_mode;
+  out->pad = 0;
+  out->ids = nullptr;
+  out->n = p->filter_mode == MI355_FILTER_NONE ? 0 : p->n_filter;
+  if (out->mode == MI355_FILTER_NONE || out->n == 0) return MI355_OK;
+  if (p->io_mem == MI355_MEM_DEVICE) {
+    out->ids = p->filter_rowids;
+    return MI355_OK;
+  }
+  ST_TRY(stage.ensure(sizeof(uint64_t) * out->n));
+  HIP_TRY(hipMemcpyAsync(stage.p, p->filter_rowids, sizeof(uint64_t) * out->n, hipMemcpyHostToDevice, st));
+  out->ids = stage.as<uint64_t>();
   return MI355_OK;
 }
 
@@ -749,6 +770,7 @@ struct SearchPlan {
   uint32_t k, kk, nprobe;
   bool refine;
   RangeFilter range;
+  RowFilter filter;
 };
 
 // one pass of the pipeline over `nq` queries already resident at d_q;
@@ -871,6 +893,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       ka.nprobe = nprobe;
       ka.kk = pl.kk;
       ka.range = pl.range;
+      ka.filter = pl.filter;
       ka.cand = ix->w_cand.as<Cand>();
       ka.dbg = env_u32("MI355_DBG_SKIP", 0);
       const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(ix->n_cus, (uint64_t)n * nprobe);
@@ -885,6 +908,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       sa.n_slices = n_slices;
       sa.kk = pl.kk;
       sa.range = pl.range;
+      sa.filter = pl.filter;
       sa.cand = ix->w_cand.as<Cand>();
       sa.dbg = env_u32("MI355_DBG_SKIP", 0);
       ST_TRY(launch_scan_pair(sa, dim3(n_slices, nprobe, n), lds, st, kpl_kk, vpt, nt));
@@ -1014,6 +1038,7 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
   pl.range.has_upper = p->has_upper_bound;
   pl.range.lower = p->lower_bound;
   pl.range.upper = p->upper_bound;
+  ST_TRY(make_row_filter(p, ix->w_filter, st, &pl.filter));
   ST_TRY(run_ivfpq(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt));
 
   if (np_max > np_min) {
@@ -1258,6 +1283,10 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ra.f.n_slices = 1;
     ra.f.kk = k;
     ra.f.range = range;
+    ra.f.filter.mode = MI355_FILTER_NONE;
+    ra.f.filter.pad = 0;
+    ra.f.filter.ids = nullptr;
+    ra.f.filter.n = 0;
     ra.f.cand = nullptr;
     ra.cand_cnt = f->g_cnt.as<uint32_t>();
     ra.cand = f->g_cand.as<uint32_t>();
@@ -1277,7 +1306,7 @@ extern "C" int32_t mi355_flat_close(mi355_flat* f) {
   (void)hipSetDevice(f->device);
   DevBuf* bufs[] = {&f->vectors, &f->row_ids, &f->w_q,  &f->w_cand, &f->w_ids,  &f->w_dist, &f->w_cnt,
                     &f->shadow,  &f->vv,      &f->vmax, &f->g_qb,   &f->g_qa,   &f->g_qg,   &f->g_slack,
-                    &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand};
+                    &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand, &f->w_filter};
   for (DevBuf* b : bufs) b->release();
   if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
@@ -1343,7 +1372,10 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
   rng.upper = p->upper_bound;
   // MFMA filter + exact re-rank whenever the column carries the filter data.  A lower
   // bound makes "the k best" and "the k best in range" different sets: exact sweep.
-  const bool use_mfma = f->mfma && !p->has_lower_bound;
+  RowFilter flt;
+  ST_TRY(make_row_filter(p, f->w_filter, st, &flt));
+  // (the filter's k-th-best bound assumes every row is eligible: prefiltered searches sweep exactly)
+  const bool use_mfma = f->mfma && !p->has_lower_bound && flt.mode == MI355_FILTER_NONE;
   f->last_path = use_mfma ? 1 : 2;
   if (use_mfma) {
     ST_TRY(run_flat_mfma(f, d_q, n_queries, metric, k, rng, d_ids, d_dist, d_cnt));
@@ -1371,6 +1403,7 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
     fa.range.has_upper = p->has_upper_bound;
     fa.range.lower = p->lower_bound;
     fa.range.upper = p->upper_bound;
+    fa.filter = flt;
     fa.cand = f->w_cand.as<Cand>();
     size_t lds = (((size_t)f->dim * 4 + 15) & ~(size_t)15) + sizeof(Cand) * 4 * k;
     launch_by_kpl(kpl, k_flat_scan<1>, k_flat_scan<2>, k_flat_scan<4>, dim3(n_slices, 1, n), dim3(256), lds, st, fa);

@@ -37,6 +37,12 @@ class VectorQueryRequest:
     refine_factor: Optional[int] = None
     distance_type: Optional[str] = None
     use_index: bool = True
+    # QueryRequest.filter / prefilter (query.rs:489-507, :899).  The predicate itself is
+    # evaluated by the table layer (out of scope); what reaches the ANN nodes is the set of
+    # permitted / dropped _rowids (lance RowIdMask [EXT]).
+    allow_rowids: Optional[np.ndarray] = None
+    block_rowids: Optional[np.ndarray] = None
+    prefilter: bool = True  # default in the reference; False = postfilter (query.rs:496-507)
 
 
 def _to_query_vector(v):
@@ -134,6 +140,21 @@ class VectorQuery:
         q.request.distance_type = distance_type
         return q
 
+    def only_if_rowids(self, allow=None, block=None):
+        """The evaluated form of `only_if(filter)` (query.rs:440-455): the _rowids the
+        predicate keeps (`allow`) or drops (`block`)."""
+        if (allow is None) == (block is None):
+            raise InvalidInput(1, "give exactly one of allow / block")
+        q = self._clone()
+        q.request.allow_rowids = None if allow is None else np.unique(np.asarray(allow, dtype=np.uint64))
+        q.request.block_rowids = None if block is None else np.unique(np.asarray(block, dtype=np.uint64))
+        return q
+
+    def postfilter(self):  # query.rs:496-507: filter applied to the k results of the search
+        q = self._clone()
+        q.request.prefilter = False
+        return q
+
     def bypass_vector_index(self):  # query.rs:1367-1370
         q = self._clone()
         q.request.use_index = False
@@ -188,10 +209,13 @@ class VectorTable:
         offset = req.offset or 0
         k = limit + offset  # table/query.rs:231
         metric = _abi.METRIC_DEFAULT if req.distance_type is None else _abi.METRIC_NAMES[req.distance_type]
+        filtered = req.allow_rowids is not None or req.block_rowids is not None
+        pre = filtered and req.prefilter
         params = _abi.make_params(
             k=k, nprobe_min=req.minimum_nprobes, nprobe_max=req.maximum_nprobes,
             refine_factor=req.refine_factor or 0, metric=metric,
-            lower_bound=req.lower_bound, upper_bound=req.upper_bound)
+            lower_bound=req.lower_bound, upper_bound=req.upper_bound,
+            allow_rowids=req.allow_rowids if pre else None, block_rowids=req.block_rowids if pre else None)
         q = np.stack(req.query_vector)
         use_index = req.use_index and self.index is not None
         if use_index:
@@ -203,9 +227,13 @@ class VectorTable:
         rid, dist, qidx = [], [], []
         for i in range(q.shape[0]):
             n = int(res.counts[i])
-            rid.append(res.rowids[i, offset:n])
-            dist.append(res.distances[i, offset:n])
-            qidx.append(np.full(max(n - offset, 0), i, dtype=np.int32))
+            r, d = res.rowids[i, :n], res.distances[i, :n]
+            if filtered and not pre:  # postfilter: the predicate thins out the k results
+                keep = np.isin(r, req.allow_rowids) if req.allow_rowids is not None else ~np.isin(r, req.block_rowids)
+                r, d = r[keep], d[keep]
+            rid.append(r[offset:])
+            dist.append(d[offset:])
+            qidx.append(np.full(max(len(r) - offset, 0), i, dtype=np.int32))
         out = {"_rowid": np.concatenate(rid), "_distance": np.concatenate(dist)}
         if q.shape[0] > 1:
             out["query_index"] = np.concatenate(qidx)

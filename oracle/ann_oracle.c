@@ -215,6 +215,19 @@ static inline int in_range(float d, const mi355_search_params *p) {
   return 1;
 }
 
+/* prefilter (query.rs:489-507: prefilter = true is the default): the row must be
+   on the allow list / off the block list; sorted u64 array, binary search */
+static inline int row_permitted(uint64_t id, const mi355_search_params *p) {
+  if (p->filter_mode == MI355_FILTER_NONE) return 1;
+  uint64_t lo = 0, hi = p->n_filter;
+  while (lo < hi) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    if (p->filter_rowids[mid] < id) lo = mid + 1; else hi = mid;
+  }
+  int found = lo < p->n_filter && p->filter_rowids[lo] == id;
+  return p->filter_mode == MI355_FILTER_ALLOW ? found : !found;
+}
+
 /* -------------------------------------------------------------- lifecycle */
 int32_t orc_index_close(orc_index *ix) {
   if (!ix) return MI355_OK;
@@ -411,6 +424,7 @@ static void search_one(const orc_index *ix, const float *q,
     for (uint64_t i = 0; i < len; ++i) {
       float d = scratch_dist[i];
       if (!in_range(d, prm)) continue;
+      if (!row_permitted(ix->row_ids[o + i], prm)) continue;
       cand_t c = {d, ix->row_ids[o + i], o + i};
       heap_push(hp, c);
     }
@@ -561,6 +575,7 @@ int32_t orc_flat_search(const mi355_flat_desc *fd, const float *queries,
         load_row(fd->vectors, fd->dtype, i, fd->dim, row);
         float d = orc_exact_distance(q, row, fd->dim, metric);
         if (!in_range(d, prm)) continue;
+        if (!row_permitted(fd->row_ids ? fd->row_ids[i] : i, prm)) continue;
         cand_t c = {d, fd->row_ids ? fd->row_ids[i] : i, i};
         heap_push(&hp, c);
       }

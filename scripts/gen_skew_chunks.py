@@ -138,8 +138,13 @@ __device__ __forceinline__ void {name}(const uint4& cw, uint32_t lb, uint32_t pb
 T0 = 112
 
 
+DUAL = dict(nreg=1, wait=1)
+
+
 def dblock(k, sdwa=True):
     """asm lines for steps 8k .. 8k+7 of both chains."""
+    nreg, wait = DUAL["nreg"], DUAL["wait"]
+    regs = ["%[r]", "%[r]"] if nreg == 1 else ["%[r]", "%[r2]"]
     lines = []
     for e in range(8):
         t = 8 * k + e
@@ -150,14 +155,23 @@ def dblock(k, sdwa=True):
                 lines.append(f"s_bfm_b64 exec, {62 - 2 * p}, {p + 1}")  # lanes that have NOT crossed (mirrored map)
                 lines.append("s_not_b64 exec, exec")
             lines.append("v_or_b32 %[r], %[slab], %[r]")
+            if nreg == 2:
+                lines.append("v_or_b32 %[r2], %[slab], %[r2]")
             lines.append("s_mov_b64 exec, -1")
-        for ch, wn in ((0, "a"), (1, "b")):
-            lines.append(f"v_mov_b32_sdwa %[r], %[w{wn}{w}] dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_{b}")
-            lines.append(f"ds_read_b32 v{T0 + 2 * e + ch}, %[r] offset:{4 * t}")
+        if nreg == 1:
+            for ch, wn in ((0, "a"), (1, "b")):
+                lines.append(f"v_mov_b32_sdwa %[r], %[w{wn}{w}] dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_{b}")
+                lines.append(f"ds_read_b32 v{T0 + 2 * e + ch}, %[r] offset:{4 * t}")
+        else:  # both inserts first: neither gather directly follows its producer
+            for ch, wn in ((0, "a"), (1, "b")):
+                lines.append(f"v_mov_b32_sdwa {regs[ch]}, %[w{wn}{w}] dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_{b}")
+            for ch in (0, 1):
+                lines.append(f"ds_read_b32 v{T0 + 2 * e + ch}, {regs[ch]} offset:{4 * t}")
     in_split = False
     for e in range(8):
         t = 8 * k + e
-        lines.append(f"s_waitcnt lgkmcnt({14 - 2 * e})")
+        if e % wait == 0:
+            lines.append(f"s_waitcnt lgkmcnt({16 - 2 * (e + wait)})")
         pair = f"v[{T0 + 2 * e}:{T0 + 2 * e + 1}]"
         if t < 31:  # lanes t+1 .. 62-t (mirrored map) are still on the old row
             lines.append(f"s_bfm_b64 exec, {62 - 2 * t}, {t + 1}")
@@ -182,10 +196,10 @@ def emit_dblock(k):
     return f"""
 // steps {8 * k}..{8 * k + 7} of both chains
 __device__ __forceinline__ void skew_dblock_{k}(uint32_t wa0, uint32_t wa1, uint32_t wb0, uint32_t wb1, uint32_t& r,
-                                               uint32_t slab, sk_f32x2& x, sk_f32x2& y) {{
+                                               uint32_t& r2, uint32_t slab, sk_f32x2& x, sk_f32x2& y) {{
   asm volatile(
 {txt}
-      : [x] "+v"(x), [y] "+v"(y), [r] "+v"(r)
+      : [x] "+v"(x), [y] "+v"(y), [r] "+v"(r), [r2] "+v"(r2)
       : [wa0] "v"(wa0), [wa1] "v"(wa1), [wb0] "v"(wb0), [wb1] "v"(wb1), [slab] "v"(slab)
       : "scc", {clob});
 }}
@@ -217,12 +231,12 @@ __device__ __forceinline__ void sk_wait_codes(sk_u32x4& a, sk_u32x4& b) {
 
 // blocks of chunk G (steps 16G .. 16G+15) of both chains; ca / cb = the 16 code bytes of each chain
 template <int G>
-__device__ __forceinline__ void skew_dchunk(const sk_u32x4& ca, const sk_u32x4& cb, uint32_t& r, uint32_t slab, sk_f32x2& x,
-                                            sk_f32x2& y) {
+__device__ __forceinline__ void skew_dchunk(const sk_u32x4& ca, const sk_u32x4& cb, uint32_t& r, uint32_t& r2, uint32_t slab,
+                                            sk_f32x2& x, sk_f32x2& y) {
 """)
     for g in range(6):
-        src.append(f"  if constexpr (G == {g}) {{\n    skew_dblock_{2 * g}(ca.x, ca.y, cb.x, cb.y, r, slab, x, y);\n"
-                   f"    skew_dblock_{2 * g + 1}(ca.z, ca.w, cb.z, cb.w, r, slab, x, y);\n  }}\n")
+        src.append(f"  if constexpr (G == {g}) {{\n    skew_dblock_{2 * g}(ca.x, ca.y, cb.x, cb.y, r, r2, slab, x, y);\n"
+                   f"    skew_dblock_{2 * g + 1}(ca.z, ca.w, cb.z, cb.w, r, r2, slab, x, y);\n  }}\n")
     src.append("}\n")
     return "".join(src)
 
@@ -249,6 +263,9 @@ def main():
         k, v = a.split("=")
         kw[k] = int(v) if v.isdigit() else v
     dual = kw.pop("dual", 1)  # the committed skew_chunks.inc is the dual form; dual=0 gives the one-row blocks
+    for kk in ("nreg", "dwait"):
+        if kk in kw:
+            DUAL["wait" if kk == "dwait" else kk] = kw.pop(kk)
     with open(OUT, "w") as f:
         f.write(render_dual() if dual else render(**kw))
     print("wrote", OUT, kw or DEFAULTS)

@@ -190,6 +190,44 @@ def test_generic_layout_still_serves_m96(oracle, monkeypatch):
     assert g.stats()["scan_variant"] == _abi.SCAN_PAIR
 
 
+def test_prefilter_allow_and_block_lists(oracle):
+    """Prefilter (the reference's default for filtered vector queries,
+    rust/lancedb/src/query.rs:489-507; row counts pinned at :1759-1812): the k nearest
+    among the permitted rows, on both scan kernels, with refine, with maximum_nprobes
+    expansion, on the flat path and through the query mirror (pre- and post-filter)."""
+    rng = np.random.default_rng(31)
+    for m, dim in ((8, 32), (48, 192)):  # generic and skewed layouts
+        s = train.synthetic_index(40000, dim, 32, m, seed=m, skew=0.6)
+        raw = rng.normal(size=(40000, dim)).astype(np.float32)
+        g, o = _both(oracle, s, raw=raw)
+        q = (s["centroids"][rng.integers(0, 32, size=40)] + rng.normal(0, 0.5, size=(40, dim))).astype(np.float32)
+        ids = s["row_ids"]
+        allow_few = rng.choice(ids, size=37, replace=False)        # fewer permitted rows than k in most partitions
+        allow_many = rng.choice(ids, size=30000, replace=False)
+        block = rng.choice(ids, size=39000, replace=False)
+        for kw in (dict(allow_rowids=allow_many), dict(allow_rowids=allow_few), dict(block_rowids=block)):
+            for extra in (dict(nprobe_min=8, nprobe_max=8), dict(nprobe_min=2, nprobe_max=32),
+                          dict(nprobe_min=8, nprobe_max=8, refine_factor=4)):
+                got = g.search(q, k=10, **extra, **kw)
+                exp = o.search(q, k=10, **extra, **kw)
+                _assert_same(got, exp)
+                flt = np.asarray(list(kw.values())[0], dtype=np.uint64)
+                valid = got.rowids[got.rowids != _abi.UINT64_MAX]
+                assert np.isin(valid, flt).all() if "allow_rowids" in kw else not np.isin(valid, flt).any()
+        # flat path
+        f = lancedb_amd.FlatIndex(raw)
+        _assert_same(f.search(q, k=10, allow_rowids=np.arange(0, 40000, 7)),
+                     oracle.flat_search(raw, q, k=10, allow_rowids=np.arange(0, 40000, 7)))
+        assert f.info()[0] == 2  # prefiltered flat searches take the exact sweep
+        # mirror: prefilter returns 10 permitted rows, postfilter thins the unfiltered top 10
+        t = lancedb_amd.VectorTable(index=g, flat=f)
+        pre = t.vector_search(q[0]).nprobes(8).limit(10).only_if_rowids(block=block).execute()
+        assert len(pre["_rowid"]) == 10 and not np.isin(pre["_rowid"], block).any()
+        post = t.vector_search(q[0]).nprobes(8).limit(10).only_if_rowids(block=block).postfilter().execute()
+        plain = t.vector_search(q[0]).nprobes(8).limit(10).execute()
+        assert post["_rowid"].tolist() == [r for r in plain["_rowid"].tolist() if r not in set(block.tolist())]
+
+
 def test_ivfpq_errors_mirror_reference(oracle):
     s = train.synthetic_index(500, 8, 4, 2, seed=1)
     g, _ = _both(oracle, s)

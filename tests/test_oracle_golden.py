@@ -268,3 +268,23 @@ def test_merge_and_shard_plan(oracle):
     loads = [lens[own == s].sum() for s in range(2)]
     # greedy LPT: 55->s0, 30->s1, 30->s1, 10->s0, 5->s0 (tie 65/60 -> lower load), 0->s1
     assert sorted(loads) == [65, 65] and own[4] == 0 and own[2] == 1 and own[5] == 1
+
+
+def test_prefilter_postfilter_row_counts_like_the_reference(oracle):
+    """rust/lancedb/src/query.rs:1759-1812 (test_execute): limit 10 with
+    `only_if("id % 2 == 0")`: the prefilter (default) returns 10 rows, also with
+    offset 1 (k = limit + offset rows are fetched, table/query.rs:231); the
+    postfilter thins the unfiltered top 10, so fewer than 10 remain."""
+    rng = np.random.default_rng(7)
+    v = rng.random(size=(512, 4), dtype=np.float32)
+    q = np.full((1, 4), 0.1, np.float32)
+    even = np.arange(0, 512, 2, dtype=np.uint64)
+    ids, dist, cnt, st = oracle.flat_search(v, q, k=10, allow_rowids=even)
+    assert st == 0 and cnt[0] == 10 and (ids[0] % 2 == 0).all()
+    ids11, _, cnt11, _ = oracle.flat_search(v, q, k=11, allow_rowids=even)  # limit 10, offset 1
+    assert cnt11[0] == 11 and len(ids11[0][1:]) == 10
+    plain, _, _, _ = oracle.flat_search(v, q, k=10)
+    assert (plain[0] % 2 == 0).sum() < 10  # postfilter removes some of the 10
+    # block list = complement of the allow list
+    ids_b, dist_b, _, _ = oracle.flat_search(v, q, k=10, block_rowids=np.arange(1, 512, 2, dtype=np.uint64))
+    assert (ids_b == ids).all() and (dist_b == dist).all()

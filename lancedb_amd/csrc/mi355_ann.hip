@@ -775,8 +775,10 @@ struct SearchPlan {
 
 // one pass of the pipeline over `nq` queries already resident at d_q;
 // results land in d_ids/d_dist/d_cnt (device, [nq,k])
+// d_cnt_ann [nq]: rows the ANN stage found per query, BEFORE the refine re-rank (what
+// maximum_nprobes compares with k * refine_factor); may alias d_cnt when there is no refine
 static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl,
-                         uint64_t* d_ids, float* d_dist, uint32_t* d_cnt) {
+                         uint64_t* d_ids, float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann) {
   hipStream_t st = ix->stream;
   const IndexView view = make_view(ix);
   const uint32_t nprobe = pl.nprobe;
@@ -825,7 +827,6 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
     ST_TRY(ix->w_ids2.ensure(sizeof(uint64_t) * (size_t)chunk * pl.kk));
     ST_TRY(ix->w_dist2.ensure(sizeof(float) * (size_t)chunk * pl.kk));
     ST_TRY(ix->w_pos.ensure(sizeof(uint32_t) * (size_t)chunk * pl.kk));
-    ST_TRY(ix->w_cnt2.ensure(sizeof(uint32_t) * chunk));
   }
   unsigned long long* d_stat = ix->w_stat.as<unsigned long long>();
   const bool prof = ix->profile != 0;
@@ -933,7 +934,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       ma.out_ids = ix->w_ids2.as<uint64_t>();
       ma.out_dist = ix->w_dist2.as<float>();
       ma.out_pos = ix->w_pos.as<uint32_t>();
-      ma.out_cnt = ix->w_cnt2.as<uint32_t>();
+      ma.out_cnt = d_cnt_ann + q0;
       launch_by_kpl(kpl_kk, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
@@ -942,7 +943,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       ra.q = q;
       ra.in_ids = ix->w_ids2.as<uint64_t>();
       ra.in_pos = ix->w_pos.as<uint32_t>();
-      ra.in_cnt = ix->w_cnt2.as<uint32_t>();
+      ra.in_cnt = d_cnt_ann + q0;
       ra.kk = pl.kk;
       ra.k = pl.k;
       ra.range = pl.range;
@@ -1039,30 +1040,38 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
   pl.range.lower = p->lower_bound;
   pl.range.upper = p->upper_bound;
   ST_TRY(make_row_filter(p, ix->w_filter, st, &pl.filter));
-  ST_TRY(run_ivfpq(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt));
+  uint32_t* d_cnt_ann = d_cnt;
+  if (pl.refine) {
+    ST_TRY(ix->w_cnt2.ensure(sizeof(uint32_t) * n_queries));
+    d_cnt_ann = ix->w_cnt2.as<uint32_t>();
+  }
+  ST_TRY(run_ivfpq(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt, d_cnt_ann));
 
   if (np_max > np_min) {
-    // maximum_nprobes (query.rs:1246-1262): queries that came back short are
-    // searched again over the first np_max partitions.
+    // maximum_nprobes (query.rs:1246-1262): queries whose ANN stage found fewer than the
+    // k * refine_factor rows it was asked for are searched again over the first np_max
+    // partitions (the decision is taken before the refine re-rank, as in the oracle).
     std::vector<uint32_t> cnt(n_queries);
-    HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt_ann, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<uint32_t> shortq;
     for (uint32_t i = 0; i < n_queries; ++i)
-      if (cnt[i] < k) shortq.push_back(i);
+      if (cnt[i] < pl.kk) shortq.push_back(i);
     if (!shortq.empty()) {
       const uint32_t ns = (uint32_t)shortq.size();
-      DevBuf sq, sids, sdist, scnt;
+      DevBuf sq, sids, sdist, scnt, scnt_ann;
       ST_TRY(sq.ensure(sizeof(float) * (size_t)ns * ix->dim));
       ST_TRY(sids.ensure(sizeof(uint64_t) * (size_t)ns * k));
       ST_TRY(sdist.ensure(sizeof(float) * (size_t)ns * k));
       ST_TRY(scnt.ensure(sizeof(uint32_t) * ns));
+      ST_TRY(scnt_ann.ensure(sizeof(uint32_t) * ns));
       for (uint32_t i = 0; i < ns; ++i)
         HIP_TRY(hipMemcpyAsync(sq.as<float>() + (size_t)i * ix->dim, d_q + (size_t)shortq[i] * ix->dim,
                                sizeof(float) * ix->dim, hipMemcpyDeviceToDevice, st));
       SearchPlan p2 = pl;
       p2.nprobe = np_max;
-      int32_t s2 = run_ivfpq(ix, sq.as<float>(), ns, p2, sids.as<uint64_t>(), sdist.as<float>(), scnt.as<uint32_t>());
+      int32_t s2 = run_ivfpq(ix, sq.as<float>(), ns, p2, sids.as<uint64_t>(), sdist.as<float>(), scnt.as<uint32_t>(),
+                             pl.refine ? scnt_ann.as<uint32_t>() : scnt.as<uint32_t>());
       if (s2 == MI355_OK) {
         for (uint32_t i = 0; i < ns && s2 == MI355_OK; ++i) {
           size_t o = (size_t)shortq[i] * k;
@@ -1077,6 +1086,7 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
       sids.release();
       sdist.release();
       scnt.release();
+      scnt_ann.release();
       if (s2 != MI355_OK) return s2;
     }
   }

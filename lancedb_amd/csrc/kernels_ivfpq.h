@@ -32,28 +32,54 @@ struct IndexView {
 };
 
 // ------------------------------------------------------------------ K0 -----
-// One thread per query: sequential chains (768 fmas) — B is small, this is noise.
-__global__ void k_prep_queries(const float* __restrict__ q, uint32_t nq, uint32_t dim,
-                               uint32_t metric, float* __restrict__ qp,
-                               float* __restrict__ qq) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nq) return;
+// One wave per query.  The chains of the contract are sequential in d, so one lane
+// runs them — but from LDS in 16-B reads, after the wave has copied the query in
+// coalesced (one thread per query with scalar global loads was latency-bound: 149 us
+// per 2048-query batch, a visible slice of a multi-GPU step).
+__global__ __launch_bounds__(256) void k_prep_queries(const float* __restrict__ q, uint32_t nq, uint32_t dim,
+                                                      uint32_t metric, float* __restrict__ qp,
+                                                      float* __restrict__ qq) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t b = blockIdx.x * 4 + wid;
+  const uint32_t dimp = (dim + 3u) & ~3u;
+  float* sq = (float*)smem + (size_t)wid * dimp;
+  if (b >= nq) return;  // whole waves leave together; no block barrier below
   const float* src = q + (size_t)b * dim;
   float* dst = qp + (size_t)b * dim;
-  float acc = 0.f;
-  for (uint32_t d = 0; d < dim; ++d) acc = __fmaf_rn(src[d], src[d], acc);
-  if (metric == MI355_METRIC_COSINE) {
-    float nrm = ieee_sqrtf(acc);
-    float acc2 = 0.f;
-    for (uint32_t d = 0; d < dim; ++d) {
-      float v = ieee_divf(src[d], nrm);
-      dst[d] = v;
-      acc2 = __fmaf_rn(v, v, acc2);
+  for (uint32_t d = lane; d < dimp; d += 64) sq[d] = d < dim ? src[d] : 0.f;
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  auto chain_sq = [&]() -> float {  // sum of squares, d ascending (fma(0,0,acc) of the padding is exact)
+    float acc = 0.f;
+    for (uint32_t d = 0; d < dimp; d += 4) {
+      const float4 v = *(const float4*)(sq + d);
+      acc = __fmaf_rn(v.x, v.x, acc);
+      acc = __fmaf_rn(v.y, v.y, acc);
+      acc = __fmaf_rn(v.z, v.z, acc);
+      acc = __fmaf_rn(v.w, v.w, acc);
     }
-    qq[b] = acc2;
+    return acc;
+  };
+  float acc = 0.f;
+  if (lane == 0) acc = chain_sq();
+  acc = readlane_f(acc, 0);
+  if (metric == MI355_METRIC_COSINE) {
+    const float nrm = ieee_sqrtf(acc);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t d = lane; d < dim; d += 64) {
+      const float v = ieee_divf(sq[d], nrm);
+      sq[d] = v;
+      dst[d] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    float acc2 = 0.f;
+    if (lane == 0) acc2 = chain_sq();
+    if (lane == 0) qq[b] = acc2;
   } else {
-    for (uint32_t d = 0; d < dim; ++d) dst[d] = src[d];
-    qq[b] = acc;
+    for (uint32_t d = lane; d < dim; d += 64) dst[d] = sq[d];
+    if (lane == 0) qq[b] = acc;
   }
 }
 
@@ -135,6 +161,103 @@ __global__ __launch_bounds__(256) void k_coarse_tile(
         v = __fmaf_rn(-2.0f, acc[i][j], qn + cn[ci]);
       out[(size_t)qi * nlist + ci] = v;
     }
+  }
+}
+
+// ------------------------------------------------------------------ K1 (MFMA)
+// The same q x centroid products on the matrix cores: v_mfma_f32_32x32x2_f32 takes
+// f32 inputs and accumulates D = C + a0*b0 + a1*b1 as two chained fmas, i.e. it IS
+// the contract's d-ascending fmaf chain (bit-identical to k_coarse_tile and to the
+// oracle; tests compare the distances with ==), at the f32 matrix rate (157 TFLOP/s,
+// 1/16 of bf16).  256 threads = 4 waves as 2 x 2, each wave one 32 x 32 tile of a
+// 64 queries x 64 centroids block; K staged 32 at a time through LDS (rows padded to
+// 33 floats: the per-lane reads of one column hit 32 different banks).
+#define CM_T 64
+#define CM_K 32
+typedef __attribute__((ext_vector_type(16))) float cm_f32x16;
+__global__ __launch_bounds__(256) void k_coarse_mfma(
+    const float* __restrict__ qp, const float* __restrict__ qq, uint32_t nq,
+    const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist, uint32_t dim,
+    uint32_t metric, float* __restrict__ out /*[nq, nlist]*/) {
+  __shared__ float sa[CM_T][CM_K + 1];
+  __shared__ float sb[CM_T][CM_K + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const uint32_t q0 = blockIdx.y * CM_T, c0 = blockIdx.x * CM_T;
+  cm_f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int fi = lane & 31, fk = lane >> 5;
+  // staging: 64 rows x 32 k per operand = 512 float4, 2 per thread per operand; the next
+  // stage's loads are issued before this stage's MFMAs (register prefetch)
+  const bool vec = (dim & 3u) == 0;
+  float4 ra[2], rb[2];
+  auto fetch = [&](uint32_t k0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + e * 256;
+      const int r = idx >> 3, k4 = (idx & 7) * 4;
+      const uint32_t k = k0 + k4;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (vec) {
+        if (k < dim) {
+          if (q0 + r < nq) va = *(const float4*)(qp + (size_t)(q0 + r) * dim + k);
+          if (c0 + r < nlist) vb = *(const float4*)(cen + (size_t)(c0 + r) * dim + k);
+        }
+      } else {
+        float* pa = (float*)&va;
+        float* pb = (float*)&vb;
+        for (int t = 0; t < 4; ++t)
+          if (k + t < dim) {
+            if (q0 + r < nq) pa[t] = qp[(size_t)(q0 + r) * dim + k + t];
+            if (c0 + r < nlist) pb[t] = cen[(size_t)(c0 + r) * dim + k + t];
+          }
+      }
+      ra[e] = va;
+      rb[e] = vb;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + e * 256;
+      const int r = idx >> 3, k4 = (idx & 7) * 4;
+      sa[r][k4 + 0] = ra[e].x;
+      sa[r][k4 + 1] = ra[e].y;
+      sa[r][k4 + 2] = ra[e].z;
+      sa[r][k4 + 3] = ra[e].w;
+      sb[r][k4 + 0] = rb[e].x;
+      sb[r][k4 + 1] = rb[e].y;
+      sb[r][k4 + 2] = rb[e].z;
+      sb[r][k4 + 3] = rb[e].w;
+    }
+  };
+  fetch(0);
+  for (uint32_t k0 = 0; k0 < dim; k0 += CM_K) {
+    stash();
+    __syncthreads();
+    if (k0 + CM_K < dim) fetch(k0 + CM_K);
+#pragma unroll
+    for (int kk = 0; kk < CM_K; kk += 2) {
+      const float a = sa[wr * 32 + fi][kk + fk];
+      const float b = sb[wc * 32 + fi][kk + fk];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D: col = lane & 31 (centroid), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
+  const uint32_t ci = c0 + wc * 32 + fi;
+  const float cnv = ci < nlist ? cn[ci] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const uint32_t qi = q0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fk;
+    if (qi >= nq || ci >= nlist) continue;
+    float v;
+    if (metric == MI355_METRIC_DOT)
+      v = 1.0f - acc[reg];
+    else
+      v = __fmaf_rn(-2.0f, acc[reg], qq[qi] + cnv);
+    out[(size_t)qi * nlist + ci] = v;
   }
 }
 

@@ -844,12 +844,18 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
       }
       HIP_TRY(hipEventRecord(es.ev[0], st));
     }
-    hipLaunchKernelGGL(k_prep_queries, dim3((n + 63) / 64), dim3(64), 0, st, q, n, ix->dim,
-                       ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
-    hipLaunchKernelGGL(k_coarse_tile, dim3((ix->nlist + CO_T - 1) / CO_T, (n + CO_T - 1) / CO_T),
-                       dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
-                       view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
-                       ix->w_coarse.as<float>());
+    hipLaunchKernelGGL(k_prep_queries, dim3((n + 3) / 4), dim3(256), 4 * (((size_t)ix->dim + 3) & ~(size_t)3) * 4, st,
+                       q, n, ix->dim, ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
+    if (env_u32("MI355_COARSE_VALU", 0))  // dev knob: the register-tiled VALU kernel (same bits)
+      hipLaunchKernelGGL(k_coarse_tile, dim3((ix->nlist + CO_T - 1) / CO_T, (n + CO_T - 1) / CO_T),
+                         dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
+                         view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
+                         ix->w_coarse.as<float>());
+    else
+      hipLaunchKernelGGL(k_coarse_mfma, dim3((ix->nlist + CM_T - 1) / CM_T, (n + CM_T - 1) / CM_T),
+                         dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
+                         view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
+                         ix->w_coarse.as<float>());
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
     hipLaunchKernelGGL(k_select_probes, dim3(n), dim3(256), 0, st, ix->w_coarse.as<float>(),

@@ -45,6 +45,9 @@
 #include "kernels_ivfpq.h"
 #include "skew_chunks.inc"  // generated inner blocks; defines SK_ADDR_* / SK_SPLIT_*
 
+#ifndef SK_RING_FULL
+#define SK_RING_FULL 0  // dev knob: 1 = ring of a whole tile's chunks (prefetch distance CPT-1 chunks)
+#endif
 #ifdef SK_DUAL
 #define SK_CHAINS 2u  // rows in flight per lane (streams per wave)
 #else
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     for (uint32_t u = wid; u < SK_UNITS && !(a.dbg & 2u); u += NW) {
       const uint32_t nt = sk_unit_tiles(n_tiles, u);
       if (!nt) continue;
-      constexpr int RING = (CPT % 3 == 0) ? 3 : (CPT % 2 == 0 ? 2 : CPT);
+      constexpr int RING = SK_RING_FULL ? CPT : ((CPT % 3 == 0) ? 3 : (CPT % 2 == 0 ? 2 : CPT));
       const uint32_t n_chunks = nt * CPT + SK_TAIL_CHUNKS;  // dual chunks of the unit
       const uint4* src = (const uint4*)(pcodes + (size_t)sk_unit_chunk0(n_tiles, u, CPT) * 1024u) + lane;
       sk_u32x4 ra[RING], rb[RING];

@@ -138,7 +138,7 @@ __device__ __forceinline__ void {name}(const uint4& cw, uint32_t lb, uint32_t pb
 T0 = 112
 
 
-DUAL = dict(nreg=1, wait=1)
+DUAL = dict(nreg=1, wait=1, nomask=0)  # nomask: timing ablation (wrong results): no EXEC games at all
 
 
 def dblock(k, sdwa=True):
@@ -149,7 +149,7 @@ def dblock(k, sdwa=True):
     for e in range(8):
         t = 8 * k + e
         w, b = e // 4, e % 4
-        if 32 <= t < 64:  # lanes with phase <= t - 32 are in slab 1 from this step on
+        if 32 <= t < 64 and not DUAL["nomask"]:  # lanes with phase <= t - 32 are in slab 1 from this step on
             p = t - 32
             if p < 31:
                 lines.append(f"s_bfm_b64 exec, {62 - 2 * p}, {p + 1}")  # lanes that have NOT crossed (mirrored map)
@@ -173,7 +173,7 @@ def dblock(k, sdwa=True):
         if e % wait == 0:
             lines.append(f"s_waitcnt lgkmcnt({16 - 2 * (e + wait)})")
         pair = f"v[{T0 + 2 * e}:{T0 + 2 * e + 1}]"
-        if t < 31:  # lanes t+1 .. 62-t (mirrored map) are still on the old row
+        if t < 31 and not DUAL["nomask"]:  # lanes t+1 .. 62-t (mirrored map) are still on the old row
             lines.append(f"s_bfm_b64 exec, {62 - 2 * t}, {t + 1}")
             lines.append(f"v_pk_add_f32 %[y], %[y], {pair}")
             lines.append("s_not_b64 exec, exec")
@@ -263,7 +263,7 @@ def main():
         k, v = a.split("=")
         kw[k] = int(v) if v.isdigit() else v
     dual = kw.pop("dual", 1)  # the committed skew_chunks.inc is the dual form; dual=0 gives the one-row blocks
-    for kk in ("nreg", "dwait"):
+    for kk in ("nreg", "dwait", "nomask"):
         if kk in kw:
             DUAL["wait" if kk == "dwait" else kk] = kw.pop(kk)
     with open(OUT, "w") as f:

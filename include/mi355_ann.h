@@ -239,6 +239,29 @@ int32_t mi355_search(mi355_index *index, const float *queries,
                      uint32_t n_queries, const mi355_search_params *params,
                      uint64_t *out_rowids, float *out_dist,
                      uint32_t *out_counts);
+/*
+ * Two-phase search for indexes whose coarse stage is worth sharding (C4: nlist =
+ * 65536 -> 201 MB of centroids and 100 MFLOP per query; SURVEY.md §8e "sharded
+ * coarse").  Phase 1: every rank scores a slice [cent_lo, cent_hi) of the centroids
+ * and returns its best min(nprobe, slice) partitions as (partition id, coarse
+ * distance) lists in mi355_merge_topk's layout; after an all-gather,
+ * mi355_merge_topk(k = nprobe) orders them by (distance, partition id) = the probe
+ * list of the unsharded search.  Phase 2: mi355_search_probes scans the partitions
+ * of that list this handle owns (nprobe_min / nprobe_max of `params` are ignored).
+ */
+int32_t mi355_coarse_topn(mi355_index *index, const float *queries,
+                          uint32_t n_queries, uint32_t nprobe, uint32_t cent_lo,
+                          uint32_t cent_hi, uint32_t io_mem,
+                          uint64_t *out_part_ids /*[n_q, nprobe]*/,
+                          float *out_dist /*[n_q, nprobe]*/,
+                          uint32_t *out_counts /*[n_q]*/);
+int32_t mi355_search_probes(mi355_index *index, const float *queries,
+                            uint32_t n_queries,
+                            const mi355_search_params *params,
+                            const uint64_t *probes /*[n_q, nprobe]*/,
+                            uint32_t nprobe, uint64_t *out_rowids,
+                            float *out_dist, uint32_t *out_counts);
+
 /* waits for the handle's stream, then returns the counters (see profile modes) */
 int32_t mi355_last_stats(mi355_index *index, mi355_stats *out);
 

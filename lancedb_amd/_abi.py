@@ -132,6 +132,8 @@ EXPORTED_SYMBOLS = (
     "mi355_index_configure",
     "mi355_index_info",
     "mi355_search",
+    "mi355_coarse_topn",
+    "mi355_search_probes",
     "mi355_last_stats",
     "mi355_flat_open",
     "mi355_flat_close",

@@ -339,6 +339,42 @@ __global__ __launch_bounds__(256) void k_select_probes(
   if (tid == 0 && stat_rows) atomicAdd(stat_rows, s_rows);
 }
 
+// two-phase search helpers (mi355_coarse_topn / mi355_search_probes)
+// (partition id, distance) pairs of a slice's selected probes, in merge_topk's layout
+__global__ void k_emit_coarse_pairs(const uint32_t* __restrict__ probes, const float* __restrict__ coarse,
+                                    uint32_t nq, uint32_t n_sel, uint32_t n_slice, uint32_t nprobe, uint32_t cent_lo,
+                                    uint64_t* __restrict__ out_ids, float* __restrict__ out_dist,
+                                    uint32_t* __restrict__ out_cnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * nprobe) return;
+  const uint32_t b = i / nprobe, r = i % nprobe;
+  if (r < n_sel) {
+    const uint32_t p = probes[(size_t)b * n_sel + r];
+    out_ids[i] = (uint64_t)cent_lo + p;
+    out_dist[i] = coarse[(size_t)b * n_slice + p];
+  } else {
+    out_ids[i] = ~0ull;
+    out_dist[i] = __builtin_huge_valf();
+  }
+  if (r == 0) out_cnt[b] = n_sel;
+}
+
+// external probe list (u64 ids) -> the u32 list the scan reads, plus the row counter
+__global__ void k_take_probes(const uint64_t* __restrict__ in, uint32_t n, uint32_t nlist,
+                              const uint32_t* __restrict__ plen, uint32_t* __restrict__ out,
+                              unsigned long long* __restrict__ stat_rows, uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t p = in[i];
+  if (p >= nlist) {  // not a partition of this index: flagged, scanned as partition 0 would be wrong -> reported
+    atomicAdd(bad, 1u);
+    out[i] = 0;
+    return;
+  }
+  out[i] = (uint32_t)p;
+  if (stat_rows && plen[p]) atomicAdd(stat_rows, (unsigned long long)plen[p]);
+}
+
 // ------------------------------------------------------------ K2+K3+K4 -----
 // SCAN_PAIR: one workgroup per (query, probe rank, slice of the partition).
 //   1. residual r = q - c_p and the m x 256 f32 distance table, built straight

@@ -113,7 +113,7 @@ struct mi355_index {
   // code layout: MI355_SCAN_PAIR = [m][pstride] blocks, MI355_SCAN_SKEW = pre-skewed streams
   uint32_t layout = MI355_SCAN_PAIR;
   uint32_t n_cus = 256;
-  DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter;
+  DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_bad, w_probes64;
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2,
       w_dist2, w_cnt2, w_stat;
@@ -296,7 +296,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->w_cnt,     &ix->w_ids2, &ix->w_dist2,  &ix->w_cnt2,  &ix->w_stat,
                     &ix->cbT,       &ix->order,  &ix->xcd_first, &ix->p_cnt,  &ix->p_off,
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
-                    &ix->w_filter};
+                    &ix->w_filter,  &ix->w_bad,    &ix->w_probes64};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -546,6 +546,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     ix->raw_dtype = d->raw_dtype;
   }
   ST_TRY(ix->w_stat.ensure(64));
+  ST_TRY(ix->w_bad.ensure(64));
   HIP_TRY(hipStreamSynchronize(st));
   return MI355_OK;
 }
@@ -771,6 +772,7 @@ struct SearchPlan {
   bool refine;
   RangeFilter range;
   RowFilter filter;
+  const uint64_t* ext_probes = nullptr;  // device [nq, nprobe]: skip the coarse stage (mi355_search_probes)
 };
 
 // one pass of the pipeline over `nq` queries already resident at d_q;
@@ -846,6 +848,15 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
     }
     hipLaunchKernelGGL(k_prep_queries, dim3((n + 3) / 4), dim3(256), 4 * (((size_t)ix->dim + 3) & ~(size_t)3) * 4, st,
                        q, n, ix->dim, ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
+    if (pl.ext_probes) {
+      // the probe list came from the two-phase coarse stage
+      HIP_TRY(hipMemsetAsync(ix->w_bad.p, 0, 4, st));
+      const uint32_t np = n * nprobe;
+      hipLaunchKernelGGL(k_take_probes, dim3((np + 255) / 256), dim3(256), 0, st, pl.ext_probes + (size_t)q0 * nprobe, np,
+                         ix->nlist, view.plen, ix->w_probes.as<uint32_t>(), d_stat, ix->w_bad.as<uint32_t>());
+      HIP_TRY(hipGetLastError());
+      if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
+    } else {
     if (env_u32("MI355_COARSE_VALU", 0))  // dev knob: the register-tiled VALU kernel (same bits)
       hipLaunchKernelGGL(k_coarse_tile, dim3((ix->nlist + CO_T - 1) / CO_T, (n + CO_T - 1) / CO_T),
                          dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
@@ -861,6 +872,7 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
     hipLaunchKernelGGL(k_select_probes, dim3(n), dim3(256), 0, st, ix->w_coarse.as<float>(),
                        ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat);
     HIP_TRY(hipGetLastError());
+    }
     if (prof) HIP_TRY(hipEventRecord(es.ev[2], st));
 
     if (skew) {
@@ -972,15 +984,20 @@ static int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const S
   return MI355_OK;
 }
 
-extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t n_queries,
-                                const mi355_search_params* p, uint64_t* out_rowids,
-                                float* out_dist, uint32_t* out_counts) {
+// ext_probes != NULL: mi355_search_probes (the probe list replaces the coarse stage)
+static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_queries,
+                           const mi355_search_params* p, const uint64_t* ext_probes, uint32_t ext_nprobe,
+                           uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   ST_TRY(validate_params(p));
   // nprobes validation: rust/lancedb/src/query.rs:1232-1275
-  if (p->nprobe_min == 0) return fail(MI355_ERR_INVALID_INPUT, "minimum_nprobes must be greater than 0");
-  if (p->nprobe_max != 0 && p->nprobe_max < p->nprobe_min)
-    return fail(MI355_ERR_INVALID_INPUT, "maximum_nprobes must be greater than or equal to minimum_nprobes");
+  if (!ext_probes) {
+    if (p->nprobe_min == 0) return fail(MI355_ERR_INVALID_INPUT, "minimum_nprobes must be greater than 0");
+    if (p->nprobe_max != 0 && p->nprobe_max < p->nprobe_min)
+      return fail(MI355_ERR_INVALID_INPUT, "maximum_nprobes must be greater than or equal to minimum_nprobes");
+  } else if (ext_nprobe == 0 || ext_nprobe > ix->nlist) {
+    return fail(MI355_ERR_INVALID_INPUT, "probe list length %u must be in 1..nlist (%u)", ext_nprobe, ix->nlist);
+  }
   if (p->metric != MI355_METRIC_DEFAULT && p->metric != ix->metric)
     return fail(MI355_ERR_INVALID_INPUT,
                 "distance type %u does not match the metric the index was trained with (%u)",
@@ -1005,6 +1022,7 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
                 (unsigned long long)kk64);
   uint32_t np_min = std::min(p->nprobe_min, ix->nlist);
   uint32_t np_max = (p->nprobe_max == 0 || p->nprobe_max > ix->nlist) ? ix->nlist : p->nprobe_max;
+  if (ext_probes) np_min = np_max = ext_nprobe;
   if (ix->shard_count > 1 && np_max != np_min)
     return fail(MI355_ERR_NOT_SUPPORTED,
                 "maximum_nprobes expansion on a sharded handle must be driven by the caller after "
@@ -1046,6 +1064,15 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
   pl.range.lower = p->lower_bound;
   pl.range.upper = p->upper_bound;
   ST_TRY(make_row_filter(p, ix->w_filter, st, &pl.filter));
+  if (ext_probes) {
+    pl.ext_probes = ext_probes;
+    if (host_io) {
+      const size_t pb = sizeof(uint64_t) * (size_t)n_queries * ext_nprobe;
+      ST_TRY(ix->w_probes64.ensure(pb));
+      HIP_TRY(hipMemcpyAsync(ix->w_probes64.p, ext_probes, pb, hipMemcpyHostToDevice, st));
+      pl.ext_probes = ix->w_probes64.as<uint64_t>();
+    }
+  }
   uint32_t* d_cnt_ann = d_cnt;
   if (pl.refine) {
     ST_TRY(ix->w_cnt2.ensure(sizeof(uint32_t) * n_queries));
@@ -1097,6 +1124,12 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
     }
   }
 
+  if (ext_probes && host_io) {  // ids outside 0..nlist-1 are a caller error: report instead of scanning garbage
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, ix->w_bad.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad) return fail(MI355_ERR_INVALID_INPUT, "%u probe ids are not partitions of this index", bad);
+  }
   if (host_io) {
     HIP_TRY(hipMemcpyAsync(out_rowids, d_ids, sizeof(uint64_t) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
@@ -1107,6 +1140,79 @@ extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t 
       if (ms > (long long)p->timeout_ms)
         return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms", (long long)ms, p->timeout_ms);
     }
+  }
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t n_queries,
+                                const mi355_search_params* p, uint64_t* out_rowids,
+                                float* out_dist, uint32_t* out_counts) {
+  return search_impl(ix, queries, n_queries, p, nullptr, 0, out_rowids, out_dist, out_counts);
+}
+
+extern "C" int32_t mi355_search_probes(mi355_index* ix, const float* queries, uint32_t n_queries,
+                                       const mi355_search_params* p, const uint64_t* probes, uint32_t nprobe,
+                                       uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) {
+  if (!probes) return fail(MI355_ERR_INVALID_INPUT, "probes is NULL");
+  return search_impl(ix, queries, n_queries, p, probes, nprobe, out_rowids, out_dist, out_counts);
+}
+
+extern "C" int32_t mi355_coarse_topn(mi355_index* ix, const float* queries, uint32_t n_queries, uint32_t nprobe,
+                                     uint32_t cent_lo, uint32_t cent_hi, uint32_t io_mem, uint64_t* out_part_ids,
+                                     float* out_dist, uint32_t* out_counts) {
+  if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
+  if (io_mem > MI355_MEM_DEVICE) return fail(MI355_ERR_INVALID_INPUT, "bad io_mem");
+  if (cent_lo >= cent_hi || cent_hi > ix->nlist)
+    return fail(MI355_ERR_INVALID_INPUT, "centroid slice [%u, %u) is not inside 0..%u", cent_lo, cent_hi, ix->nlist);
+  if (nprobe == 0 || nprobe > 256) return fail(MI355_ERR_INVALID_INPUT, "nprobe must be in 1..256 for the two-phase search");
+  if (n_queries == 0) return MI355_OK;
+  if (!queries || !out_part_ids || !out_dist || !out_counts) return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t st = ix->stream;
+  const bool host_io = io_mem == MI355_MEM_HOST;
+  const uint32_t n_slice = cent_hi - cent_lo, n_sel = std::min(nprobe, n_slice), nq = n_queries;
+  const float* d_q = queries;
+  uint64_t* d_ids = out_part_ids;
+  float* d_dist = out_dist;
+  uint32_t* d_cnt = out_counts;
+  if (host_io) {
+    ST_TRY(ix->w_q.ensure(sizeof(float) * (size_t)nq * ix->dim));
+    ST_TRY(ix->w_ids.ensure(sizeof(uint64_t) * (size_t)nq * nprobe));
+    ST_TRY(ix->w_dist.ensure(sizeof(float) * (size_t)nq * nprobe));
+    ST_TRY(ix->w_cnt.ensure(sizeof(uint32_t) * nq));
+    HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)nq * ix->dim, hipMemcpyHostToDevice, st));
+    d_q = ix->w_q.as<float>();
+    d_ids = ix->w_ids.as<uint64_t>();
+    d_dist = ix->w_dist.as<float>();
+    d_cnt = ix->w_cnt.as<uint32_t>();
+  }
+  ST_TRY(ix->w_qp.ensure(sizeof(float) * (size_t)nq * ix->dim));
+  ST_TRY(ix->w_qq.ensure(sizeof(float) * nq));
+  ST_TRY(ix->w_coarse.ensure(sizeof(float) * (size_t)nq * n_slice));
+  ST_TRY(ix->w_probes.ensure(sizeof(uint32_t) * (size_t)nq * std::max(n_sel, 1u)));
+  hipLaunchKernelGGL(k_prep_queries, dim3((nq + 3) / 4), dim3(256), 4 * (((size_t)ix->dim + 3) & ~(size_t)3) * 4, st,
+                     d_q, nq, ix->dim, ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
+  // the slice's centroids, norms and partition lengths are contiguous sub-ranges of the handle's arrays
+  const float* cen = ix->centroids.as<float>() + (size_t)cent_lo * ix->dim;
+  const float* cn = ix->cnorm.as<float>() + cent_lo;
+  for (uint32_t y0 = 0; y0 < nq; y0 += 65535u * CM_T) {  // grid.y limit
+    const uint32_t ny = std::min(nq - y0, 65535u * CM_T);
+    hipLaunchKernelGGL(k_coarse_mfma, dim3((n_slice + CM_T - 1) / CM_T, (ny + CM_T - 1) / CM_T), dim3(256), 0, st,
+                       ix->w_qp.as<float>() + (size_t)y0 * ix->dim, ix->w_qq.as<float>() + y0, ny, cen, cn, n_slice,
+                       ix->dim, ix->metric, ix->w_coarse.as<float>() + (size_t)y0 * n_slice);
+  }
+  hipLaunchKernelGGL(k_select_probes, dim3(nq), dim3(256), 0, st, ix->w_coarse.as<float>(), n_slice, n_sel,
+                     ix->plen.as<uint32_t>() + cent_lo, ix->w_probes.as<uint32_t>(), (unsigned long long*)nullptr);
+  const uint32_t np = nq * nprobe;
+  hipLaunchKernelGGL(k_emit_coarse_pairs, dim3((np + 255) / 256), dim3(256), 0, st, ix->w_probes.as<uint32_t>(),
+                     ix->w_coarse.as<float>(), nq, n_sel, n_slice, nprobe, cent_lo, d_ids, d_dist, d_cnt);
+  HIP_TRY(hipGetLastError());
+  if (host_io) {
+    HIP_TRY(hipMemcpyAsync(out_part_ids, d_ids, sizeof(uint64_t) * (size_t)nq * nprobe, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)nq * nprobe, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(uint32_t) * nq, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
   }
   return MI355_OK;
 }

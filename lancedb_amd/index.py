@@ -172,6 +172,40 @@ class IvfPqIndex(_Handle):
         p = params if params is not None else _abi.make_params(**kw)
         return _run_search(lib().mi355_search, self._h, self.dim, queries, p, out)
 
+    # ---- two-phase search (sharded coarse stage) ----------
+    def coarse_topn(self, queries, nprobe, cent_lo=0, cent_hi=None):
+        """Best min(nprobe, slice) partitions of centroid slice [cent_lo, cent_hi) per query
+        -> (part_ids [nq, nprobe] u64 / int64, dist [nq, nprobe] f32, counts [nq]) in
+        merge_topk's list layout (padding: UINT64_MAX / +inf)."""
+        cent_hi = self.nlist if cent_hi is None else cent_hi
+        if _is_device(queries):
+            q = queries.contiguous().view(-1, self.dim)
+            nq = q.shape[0]
+            ids, dist, cnt = _device_empty_like(q, [((nq, nprobe), "int64"), ((nq, nprobe), "float32"), ((nq,), "int32")])
+            mem = _abi.MEM_DEVICE
+        else:
+            q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+            nq = q.shape[0]
+            ids = np.empty((nq, nprobe), dtype=np.uint64)
+            dist = np.empty((nq, nprobe), dtype=np.float32)
+            cnt = np.zeros(nq, dtype=np.uint32)
+            mem = _abi.MEM_HOST
+        check(lib().mi355_coarse_topn(self._h, _ptr(q), C.c_uint32(nq), C.c_uint32(nprobe), C.c_uint32(cent_lo),
+                                      C.c_uint32(cent_hi), C.c_uint32(mem), _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
+    def search_probes(self, queries, probes, params=None, out=None, **kw):
+        """Scan the partitions of `probes` [nq, nprobe] (u64 ids, e.g. merge_topk of the
+        gathered coarse_topn lists) that this handle owns."""
+        p = params if params is not None else _abi.make_params(**kw)
+        nprobe = int(probes.shape[1])
+        if not _is_device(queries):
+            probes = np.ascontiguousarray(probes, dtype=np.uint64)
+
+        def fn(handle, q, nq, params_ref, ids, dist, cnt):
+            return lib().mi355_search_probes(handle, q, nq, params_ref, _ptr(probes), C.c_uint32(nprobe), ids, dist, cnt)
+        return _run_search(fn, self._h, self.dim, queries, p, out)
+
 
 class FlatIndex(_Handle):
     """A raw vector column on the GPU for exhaustive search

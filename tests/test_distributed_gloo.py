@@ -59,6 +59,41 @@ class _OracleShard:
         return SearchResult(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d),
                             torch.from_numpy(c.astype(np.int32)))
 
+    # two-phase search, restated with the oracle's stage-wise entry points
+    nlist = property(lambda self: self.ox.nlist)
+
+    def coarse_topn(self, queries, nprobe, lo, hi):
+        nq = len(queries)
+        ids = np.full((nq, nprobe), np.iinfo(np.int64).max, np.int64)
+        ids[:] = -1  # UINT64_MAX as int64
+        d = np.full((nq, nprobe), np.inf, np.float32)
+        n_sel = min(nprobe, hi - lo)
+        for i, q in enumerate(queries):
+            co = self.ox.coarse(q)[lo:hi]
+            order = np.lexsort((np.arange(lo, hi), co))[:n_sel]
+            ids[i, :n_sel] = lo + order
+            d[i, :n_sel] = co[order]
+        return torch.from_numpy(ids), torch.from_numpy(d), torch.full((nq,), n_sel, dtype=torch.int32)
+
+    def search_probes(self, queries, probes, params, out=None):
+        k, nq = params.k, len(queries)
+        ids = np.full((nq, k), -1, np.int64)
+        d = np.full((nq, k), np.inf, np.float32)
+        cnt = np.zeros(nq, np.int32)
+        po = self.ox.part_offsets.astype(np.int64)
+        for i, q in enumerate(queries):
+            cd, ci = [], []
+            for p in probes[i].numpy().astype(np.int64):
+                if po[p + 1] > po[p]:
+                    cd.append(self.ox.adc_partition(self.ox.build_lut(q, int(p)), int(p)))
+                    ci.append(self.ox.row_ids[po[p]:po[p + 1]])
+            if cd:
+                cd, ci = np.concatenate(cd), np.concatenate(ci)
+                order = np.lexsort((ci, cd))[:k]
+                n = len(order)
+                ids[i, :n], d[i, :n], cnt[i] = ci[order].astype(np.int64), cd[order], n
+        return SearchResult(torch.from_numpy(ids), torch.from_numpy(d), torch.from_numpy(cnt))
+
 
 def _oracle_merge(g_ids, g_dist, g_cnt, k, stream=0):
     from oracle import oracle as orc
@@ -77,6 +112,7 @@ def _worker(rank, world, port, ret):
         q = np.random.default_rng(5).normal(size=(19, 32)).astype(np.float32)
         shard = _OracleShard(s, world, rank)
         searcher = ShardedSearcher(shard, merge=_oracle_merge)
+        two_phase = ShardedSearcher(shard, merge=_oracle_merge, shard_coarse=True)
         total = torch.tensor([shard.rows])
         dist.all_reduce(total)
         assert int(total) == 20000  # the plan is a partition of the rows
@@ -88,6 +124,10 @@ def _worker(rank, world, port, ret):
             assert (got.rowids.numpy().astype(np.uint64) == ids).all()
             assert (got.distances.numpy() == d).all()
             assert (got.counts.numpy().astype(np.uint32) == c).all()
+            if nprobe <= 24:  # two-phase: sharded coarse stage + one more all-gather, same result
+                got2 = two_phase.search(q, p)
+                assert (got2.rowids.numpy().astype(np.uint64) == ids).all()
+                assert (got2.distances.numpy() == d).all()
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

@@ -272,6 +272,41 @@ def test_sharded_handles_merge_to_unsharded_result(oracle):
             assert (mc.numpy().astype(np.uint32) == exp[2]).all()
 
 
+def test_two_phase_search_with_sharded_coarse_stage(oracle):
+    """every shard scores a slice of the centroids; the merged
+    (distance, partition id) lists are the probe list of the unsharded search, and the
+    merged per-shard scans of those probes equal the unsharded result."""
+    from lancedb_amd.distributed import coarse_slice
+    DA = lancedb_amd.DeviceArray
+    for m, dim, metric in ((8, 32, "l2"), (32, 128, "cosine"), (48, 96, "dot")):
+        s = train.synthetic_index(50000, dim, 96, m, seed=17, skew=0.8, empty_parts=5)
+        q = (s["centroids"][np.random.default_rng(6).integers(0, 96, size=41)]
+             + np.random.default_rng(7).normal(0, 0.5, size=(41, dim))).astype(np.float32)
+        _, o = _both(oracle, s, metric)
+        for shards, nprobe in ((2, 16), (5, 7), (8, 40)):
+            exp = o.search(q, k=10, nprobe_min=nprobe, nprobe_max=nprobe)
+            hs = [lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                                         metric=metric, shard_count=shards, shard_rank=r) for r in range(shards)]
+            lists = [h.coarse_topn(q, nprobe, *coarse_slice(96, shards, r)) for r, h in enumerate(hs)]
+            ids = DA.from_numpy(np.stack([l[0].astype(np.int64) for l in lists]))
+            dist = DA.from_numpy(np.stack([l[1] for l in lists]))
+            cnt = DA.from_numpy(np.stack([l[2].astype(np.int32) for l in lists]))
+            pr, pd, pc = lancedb_amd.merge_topk(ids, dist, cnt, nprobe)
+            probes = pr.numpy().astype(np.uint64)
+            # the merged list IS the oracle's probe list (same coarse arithmetic, ties by partition id)
+            co = o.coarse(q[0])
+            assert sorted(probes[0].tolist()) == sorted(o.select_probes(co, nprobe).tolist())
+            parts = [h.search_probes(q, probes, k=10) for h in hs]
+            rid = DA.from_numpy(np.stack([p.rowids.astype(np.int64) for p in parts]))
+            rd = DA.from_numpy(np.stack([p.distances for p in parts]))
+            rc = DA.from_numpy(np.stack([p.counts.astype(np.int32) for p in parts]))
+            mi, md, mc = lancedb_amd.merge_topk(rid, rd, rc, 10)
+            assert (mi.numpy().astype(np.uint64) == exp[0]).all() and (md.numpy() == exp[1]).all()
+            assert (mc.numpy().astype(np.uint32) == exp[2]).all()
+        with pytest.raises(lancedb_amd.InvalidInput, match="not partitions"):
+            hs[0].search_probes(q, np.full((41, 4), 1000, dtype=np.uint64), k=10)
+
+
 def test_device_resident_io_and_device_index(oracle):
     DA = lancedb_amd.DeviceArray
     for m, dim in ((8, 64), (48, 192)):  # generic and skewed layouts

@@ -25,7 +25,11 @@
 
 #define FG_BM 128   // rows per workgroup tile
 #define FG_BN 128   // queries per workgroup tile
-#define FG_BK 64    // k per LDS stage (128 B per row)
+#ifndef FG_BK
+#define FG_BK 64    // k per LDS stage (128 B per row); 32 = dev variant: 32 KiB of LDS, 4 workgroups per CU
+#endif
+#define FG_CHUNKS (FG_BK / 8)              // 16-B chunks per staged row (8 or 4)
+#define FG_SLOTS (FG_BM * FG_CHUNKS / 256) // 16-B slots per thread per operand per stage (4 or 2)
 #define FG_GROUP 32 // rows per group minimum
 #define FG_TILE_BYTES (FG_BM * FG_BK * 2)
 #define FG_MAX_SEG 1024
@@ -150,7 +154,7 @@ __device__ __forceinline__ void fg_glds16(const void* g, void* lds_wave_base) {
 // ds_read_b128 fragment reads of 16 consecutive rows spread over all banks; the
 // swizzle is applied on the global source address because LDS-DMA writes lane-linear.
 template <int METRIC>
-__global__ __launch_bounds__(256, 2) void k_flat_gemm(FlatGemmArgs a) {
+__global__ __launch_bounds__(256, FG_BK == 64 ? 2 : 4) void k_flat_gemm(FlatGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
@@ -167,12 +171,15 @@ __global__ __launch_bounds__(256, 2) void k_flat_gemm(FlatGemmArgs a) {
   const size_t pitch = (size_t)a.dimp * 2;  // bytes per row of v / qb
 
   // loader: this thread's 4 slots per operand per stage (slot = i*256 + tid)
-  const unsigned char* gA[4];
-  const unsigned char* gB[4];
+  // LDS rows are FG_BK * 2 bytes; the chunk index is XOR-swizzled so that the 16 rows of one
+  // ds_read_b128 fragment read cover all 64 banks: by (row & 7) for 128-B rows, by
+  // ((row >> 2) & 3) for 64-B rows (rows 4 apart are 256 B apart = the same banks)
+  const unsigned char* gA[FG_SLOTS];
+  const unsigned char* gB[FG_SLOTS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t s = i * 256 + tid, r = s >> 3, c = s & 7u;
-    const uint32_t sc = c ^ (r & 7u);
+  for (int i = 0; i < FG_SLOTS; ++i) {
+    const uint32_t s = i * 256 + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
+    const uint32_t sc = FG_BK == 64 ? (c ^ (r & 7u)) : (c ^ ((r >> 2) & 3u));
     uint64_t vr = row0 + r;
     if (vr >= a.n_rows) vr = a.n_rows - 1;  // clamped; masked in the epilogue
     gA[i] = (const unsigned char*)a.v + vr * pitch + sc * 16u;
@@ -183,9 +190,9 @@ __global__ __launch_bounds__(256, 2) void k_flat_gemm(FlatGemmArgs a) {
     unsigned char* sB = sA + FG_TILE_BYTES;
     const size_t koff = (size_t)kt * (FG_BK * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fg_glds16(gA[i] + koff, sA + (i * 256 + wid * 64) * 16);
+    for (int i = 0; i < FG_SLOTS; ++i) fg_glds16(gA[i] + koff, sA + (i * 256 + wid * 64) * 16);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fg_glds16(gB[i] + koff, sB + (i * 256 + wid * 64) * 16);
+    for (int i = 0; i < FG_SLOTS; ++i) fg_glds16(gB[i] + koff, sB + (i * 256 + wid * 64) * 16);
   };
 
   fg_f32x4 acc[4][4];
@@ -199,17 +206,22 @@ __global__ __launch_bounds__(256, 2) void k_flat_gemm(FlatGemmArgs a) {
   uint32_t offA[4], offB[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    offA[i] = (wr * 64 + i * 16 + fr) * 128;
-    offB[i] = (wc * 64 + i * 16 + fr) * 128;
+    offA[i] = (wr * 64 + i * 16 + fr) * (FG_BK * 2);
+    offB[i] = (wc * 64 + i * 16 + fr) * (FG_BK * 2);
   }
-  const uint32_t sw = fr & 7u;  // (row & 7) is the same for A and B fragments of this lane
+  // the swizzle term depends on the row modulo 16 only, so it is the same for every fragment of this lane
+  const uint32_t sw = FG_BK == 64 ? (fr & 7u) : ((fr >> 2) & 3u);
 
   stage(0, 0);
   for (uint32_t kt = 0; kt < KT; ++kt) {
     const uint32_t buf = kt & 1u;
     if (kt + 1 < KT) {
       stage(kt + 1, buf ^ 1u);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this stage's 8 DMAs have landed, the next 8 fly on
+      // this stage's DMAs have landed, the next stage's (2 * FG_SLOTS) fly on
+      if (FG_SLOTS == 4)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_flat_gemm(FlatGemmArgs a) {
     const unsigned char* sA = smem + buf * (2 * FG_TILE_BYTES);
     const unsigned char* sB = sA + FG_TILE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < FG_BK / 32; ++kk) {
       const uint32_t ch = ((kk * 4 + fk) ^ sw) << 4;
       fg_bf16x8 fa[4], fb[4];
 #pragma unroll

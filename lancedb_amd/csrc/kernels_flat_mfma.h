@@ -23,15 +23,9 @@
 #pragma once
 #include "kernels_flat.h"
 
-#define FG_BM 128   // rows per workgroup tile
-#define FG_BN 128   // queries per workgroup tile
-#ifndef FG_BK
-#define FG_BK 64    // k per LDS stage (128 B per row); 32 = dev variant: 32 KiB of LDS, 4 workgroups per CU
-#endif
-#define FG_CHUNKS (FG_BK / 8)              // 16-B chunks per staged row (8 or 4)
-#define FG_SLOTS (FG_BM * FG_CHUNKS / 256) // 16-B slots per thread per operand per stage (4 or 2)
+#define FG_BK 64                // k per LDS stage (128 B per row)
+#define FG_CHUNKS (FG_BK / 8)   // 16-B chunks per staged row
 #define FG_GROUP 32 // rows per group minimum
-#define FG_TILE_BYTES (FG_BM * FG_BK * 2)
 #define FG_MAX_SEG 1024
 #define FG_CAND_CAP 1024  // candidate groups per query before the exact re-scan kicks in
 
@@ -153,11 +147,22 @@ __device__ __forceinline__ void fg_glds16(const void* g, void* lds_wave_base) {
 // 16 KiB), rows of 128 B stored with the 16-B chunk index XOR (row & 7) so that the
 // ds_read_b128 fragment reads of 16 consecutive rows spread over all banks; the
 // swizzle is applied on the global source address because LDS-DMA writes lane-linear.
-template <int METRIC>
-__global__ __launch_bounds__(256, FG_BK == 64 ? 2 : 4) void k_flat_gemm(FlatGemmArgs a) {
+// Tile shapes: WM x WN waves, each owning MI x NI MFMA tiles of 16 x 16.
+//   <2,2,4,4>: 128 rows x 128 queries, 256 threads, 64 KiB of LDS, 2 workgroups per CU
+//   <2,4,8,4>: 256 x 256, 512 threads, 128 KiB, 1 workgroup per CU.  Per k-step a wave
+//     reads (MI + NI) x 1 KiB of fragments for MI x NI MFMAs: 24 KiB per 64 MFMAs instead
+//     of 16 KiB per 32 - with the small tile the LDS read bandwidth (256 B/clk) is as
+//     loaded as the matrix pipe.
+template <int METRIC, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+  constexpr int A_BYTES = BM * FG_BK * 2, B_BYTES = BN * FG_BK * 2;
+  constexpr int SA = BM * FG_CHUNKS / NT, SB = BN * FG_CHUNKS / NT;  // 16-B slots per thread per stage
+  static_assert(FG_BK == 64, "the swizzle below is written for 128-B LDS rows");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = wid / WN, wc = wid % WN;
   // XCD-aware order: the query tiles of one row tile run back to back on ONE XCD
   // (block b lands on XCD b % 8), so the row tile is fetched from HBM once.
   const uint32_t b = blockIdx.x;
@@ -165,82 +170,74 @@ __global__ __launch_bounds__(256, FG_BK == 64 ? 2 : 4) void k_flat_gemm(FlatGemm
   const uint32_t qt = slot % a.n_qtiles;
   const uint32_t rt = (slot / a.n_qtiles) * 8u + xcd;
   if (rt >= a.n_rtiles) return;
-  const uint64_t row0 = (uint64_t)rt * FG_BM;
-  const uint32_t q0 = qt * FG_BN;
+  const uint64_t row0 = (uint64_t)rt * BM;
+  const uint32_t q0 = qt * BN;
   const uint32_t KT = a.dimp / FG_BK;
   const size_t pitch = (size_t)a.dimp * 2;  // bytes per row of v / qb
 
-  // loader: this thread's 4 slots per operand per stage (slot = i*256 + tid)
-  // LDS rows are FG_BK * 2 bytes; the chunk index is XOR-swizzled so that the 16 rows of one
-  // ds_read_b128 fragment read cover all 64 banks: by (row & 7) for 128-B rows, by
-  // ((row >> 2) & 3) for 64-B rows (rows 4 apart are 256 B apart = the same banks)
-  const unsigned char* gA[FG_SLOTS];
-  const unsigned char* gB[FG_SLOTS];
+  // loader: slot s = i * NT + tid of a stage holds (row s / 8, chunk s % 8); the chunk index is
+  // XOR-swizzled with (row & 7) on the SOURCE side (LDS-DMA writes lane-linear) so that the 16
+  // rows of one ds_read_b128 fragment read cover all 64 banks
+  const unsigned char* gA[SA];
+  const unsigned char* gB[SB];
 #pragma unroll
-  for (int i = 0; i < FG_SLOTS; ++i) {
-    const uint32_t s = i * 256 + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
-    const uint32_t sc = FG_BK == 64 ? (c ^ (r & 7u)) : (c ^ ((r >> 2) & 3u));
+  for (int i = 0; i < SA; ++i) {
+    const uint32_t s = i * NT + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
     uint64_t vr = row0 + r;
     if (vr >= a.n_rows) vr = a.n_rows - 1;  // clamped; masked in the epilogue
-    gA[i] = (const unsigned char*)a.v + vr * pitch + sc * 16u;
-    gB[i] = (const unsigned char*)a.qb + (size_t)(q0 + r) * pitch + sc * 16u;
+    gA[i] = (const unsigned char*)a.v + vr * pitch + (c ^ (r & 7u)) * 16u;
+  }
+#pragma unroll
+  for (int i = 0; i < SB; ++i) {
+    const uint32_t s = i * NT + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
+    gB[i] = (const unsigned char*)a.qb + (size_t)(q0 + r) * pitch + (c ^ (r & 7u)) * 16u;
   }
   auto stage = [&](uint32_t kt, uint32_t buf) {
-    unsigned char* sA = smem + buf * (2 * FG_TILE_BYTES);
-    unsigned char* sB = sA + FG_TILE_BYTES;
+    unsigned char* sA = smem + buf * (A_BYTES + B_BYTES);
+    unsigned char* sB = sA + A_BYTES;
     const size_t koff = (size_t)kt * (FG_BK * 2);
 #pragma unroll
-    for (int i = 0; i < FG_SLOTS; ++i) fg_glds16(gA[i] + koff, sA + (i * 256 + wid * 64) * 16);
+    for (int i = 0; i < SA; ++i) fg_glds16(gA[i] + koff, sA + (i * NT + wid * 64) * 16);
 #pragma unroll
-    for (int i = 0; i < FG_SLOTS; ++i) fg_glds16(gB[i] + koff, sB + (i * 256 + wid * 64) * 16);
+    for (int i = 0; i < SB; ++i) fg_glds16(gB[i] + koff, sB + (i * NT + wid * 64) * 16);
   };
 
-  fg_f32x4 acc[4][4];
+  fg_f32x4 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = fg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = fg_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses (bytes inside a stage): row*128 + ((chunk ^ (row&7)) << 4)
   const uint32_t fr = lane & 15, fk = lane >> 4;
-  uint32_t offA[4], offB[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    offA[i] = (wr * 64 + i * 16 + fr) * (FG_BK * 2);
-    offB[i] = (wc * 64 + i * 16 + fr) * (FG_BK * 2);
-  }
-  // the swizzle term depends on the row modulo 16 only, so it is the same for every fragment of this lane
-  const uint32_t sw = FG_BK == 64 ? (fr & 7u) : ((fr >> 2) & 3u);
+  const uint32_t offA0 = (wr * MI * 16 + fr) * 128, offB0 = (wc * NI * 16 + fr) * 128;
+  const uint32_t sw = fr & 7u;  // (row & 7): tiles start at multiples of 16 rows
 
   stage(0, 0);
   for (uint32_t kt = 0; kt < KT; ++kt) {
     const uint32_t buf = kt & 1u;
     if (kt + 1 < KT) {
       stage(kt + 1, buf ^ 1u);
-      // this stage's DMAs have landed, the next stage's (2 * FG_SLOTS) fly on
-      if (FG_SLOTS == 4)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // this stage's DMAs have landed, the next stage's SA + SB fly on
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    const unsigned char* sA = smem + buf * (2 * FG_TILE_BYTES);
-    const unsigned char* sB = sA + FG_TILE_BYTES;
+    const unsigned char* sA = smem + buf * (A_BYTES + B_BYTES);
+    const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < FG_BK / 32; ++kk) {
       const uint32_t ch = ((kk * 4 + fk) ^ sw) << 4;
-      fg_bf16x8 fa[4], fb[4];
+      fg_bf16x8 fa[MI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *(const fg_bf16x8*)(sA + offA[i] + ch);
-        fb[i] = *(const fg_bf16x8*)(sB + offB[i] + ch);
-      }
+      for (int i = 0; i < NI; ++i) fb[i] = *(const fg_bf16x8*)(sB + offB0 + i * 2048 + ch);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int i = 0; i < MI; ++i) fa[i] = *(const fg_bf16x8*)(sA + offA0 + i * 2048 + ch);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -249,29 +246,29 @@ __global__ __launch_bounds__(256, FG_BK == 64 ? 2 : 4) void k_flat_gemm(FlatGemm
 
   // ---- epilogue: lo = approx - eps, minimum per 32-row group ------------------
   // D layout (16x16): col = lane & 15 -> query, row = (lane >> 4) * 4 + reg -> row of V
-  float qa[4], qg[4];
+  float qa[NI], qg[NI];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const uint32_t n = q0 + wc * 64 + ni * 16 + fr;
+  for (int ni = 0; ni < NI; ++ni) {
+    const uint32_t n = q0 + wc * NI * 16 + ni * 16 + fr;
     qa[ni] = a.qa[n];
     qg[ni] = a.qg[n];
   }
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {  // the wave's two groups: rows 0..31 and 32..63
-    float gmin[4];
+  for (int g = 0; g < MI / 2; ++g) {  // the wave's groups of 32 rows (two MFMA row tiles each)
+    float gmin[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) gmin[ni] = __builtin_huge_valf();
+    for (int ni = 0; ni < NI; ++ni) gmin[ni] = __builtin_huge_valf();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int mi = g * 2 + h;
-      const uint64_t r0 = row0 + wr * 64 + mi * 16 + fk * 4;
+      const uint64_t r0 = row0 + wr * MI * 16 + mi * 16 + fk * 4;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const uint64_t r = r0 + reg;
         if (r >= a.n_rows) continue;
         const float vv = a.vv[r];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           const float s = acc[mi][ni][reg];
           float lo;
           if (METRIC == MI355_METRIC_L2)
@@ -287,13 +284,13 @@ __global__ __launch_bounds__(256, FG_BK == 64 ? 2 : 4) void k_flat_gemm(FlatGemm
         }
       }
     }
-    const uint32_t grp = rt * 4 + wr * 2 + g;
+    const uint32_t grp = rt * (BM / 32) + wr * (MI / 2) + g;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       float v = gmin[ni];
       v = fminf(v, __shfl_xor(v, 16));
       v = fminf(v, __shfl_xor(v, 32));
-      if (fk == 0) a.gm[(size_t)grp * a.nq_pad + q0 + wc * 64 + ni * 16 + fr] = v;
+      if (fk == 0) a.gm[(size_t)grp * a.nq_pad + q0 + wc * NI * 16 + ni * 16 + fr] = v;
     }
   }
 }

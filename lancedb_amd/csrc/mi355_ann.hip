@@ -1307,14 +1307,17 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
 static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint32_t metric, uint32_t k,
                              const RangeFilter& range, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt) {
   hipStream_t st = f->stream;
-  const uint32_t n_rtiles = (uint32_t)((f->n_rows + FG_BM - 1) / FG_BM);
-  const uint32_t n_groups = n_rtiles * 4;
+  // tile shape: 256 x 256 (8 waves) for real batches, 128 x 128 (4 waves, 2 workgroups per CU) for small ones
+  const bool big = nq > 128 && env_u32("MI355_FLAT_TILE", 256) == 256;
+  const uint32_t BM = big ? 256 : 128, BN = BM;
+  const uint32_t n_rtiles = (uint32_t)((f->n_rows + BM - 1) / BM);
+  const uint32_t n_groups = n_rtiles * (BM / FG_GROUP);
   uint32_t groups_per_seg = (n_groups + FG_MAX_SEG - 1) / FG_MAX_SEG;
   const uint32_t n_seg = (n_groups + groups_per_seg - 1) / groups_per_seg;
   // bound the group-minimum matrix (n_groups x queries f32) to ~2 GiB per pass
   const size_t budget = (size_t)env_u32("MI355_WORKSPACE_MB", 2048) << 20;
-  uint32_t chunk = (uint32_t)std::min<size_t>(((size_t)nq + 127) & ~(size_t)127,
-                                              std::max<size_t>(128, (budget / ((size_t)n_groups * 4)) & ~(size_t)127));
+  uint32_t chunk = (uint32_t)std::min<size_t>(((size_t)nq + BN - 1) / BN * BN,
+                                              std::max<size_t>(BN, (budget / ((size_t)n_groups * 4)) / BN * BN));
   const int kpl = kpl_for(k);
   const bool dbg_sync = env_u32("MI355_FLAT_SYNC", 0) != 0;  // dev: synchronise after every stage to localise a fault
   auto stage_ok = [&](const char* what) -> int32_t {
@@ -1335,7 +1338,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
   ST_TRY(f->g_cand.ensure(sizeof(uint32_t) * (size_t)chunk * FG_CAND_CAP));
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t n = std::min(chunk, nq - q0);
-    const uint32_t n_pad = (n + 127u) & ~127u;
+    const uint32_t n_pad = (n + BN - 1) / BN * BN;
     FlatQueryPrepArgs qa;
     qa.q = d_q + (size_t)q0 * f->dim;
     qa.nq = n;
@@ -1360,18 +1363,25 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ga.n_rows = f->n_rows;
     ga.dimp = f->dimp;
     ga.nq_pad = n_pad;
-    ga.n_qtiles = n_pad / FG_BN;
+    ga.n_qtiles = n_pad / BN;
     ga.n_rtiles = n_rtiles;
     ga.omc = 1.f - f->c_err;
     ga.gm = f->g_gm.as<float>();
     const uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;
-    const size_t gemm_lds = 4 * FG_TILE_BYTES;
+    const size_t gemm_lds = (size_t)2 * (BM + BN) * FG_BK * 2;
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \
-    auto kern = k_flat_gemm<MET>;                                                                   \
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                (int)gemm_lds));                                                    \
-    hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(256), gemm_lds, st, ga);                       \
+    if (big) {                                                                                      \
+      auto kern = k_flat_gemm<MET, 2, 4, 8, 4>;                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)gemm_lds));                                                  \
+      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
+    } else {                                                                                        \
+      auto kern = k_flat_gemm<MET, 2, 2, 4, 4>;                                                     \
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)gemm_lds));                                                  \
+      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(256), gemm_lds, st, ga);                     \
+    }                                                                                               \
   }
     if (metric == MI355_METRIC_L2) LAUNCH_FG(MI355_METRIC_L2)
     else if (metric == MI355_METRIC_COSINE) LAUNCH_FG(MI355_METRIC_COSINE)

@@ -153,7 +153,7 @@ __device__ __forceinline__ void fg_glds16(const void* g, void* lds_wave_base) {
 //     reads (MI + NI) x 1 KiB of fragments for MI x NI MFMAs: 24 KiB per 64 MFMAs instead
 //     of 16 KiB per 32 - with the small tile the LDS read bandwidth (256 B/clk) is as
 //     loaded as the matrix pipe.
-template <int METRIC, int WM, int WN, int MI, int NI>
+template <int METRIC, int WM, int WN, int MI, int NI, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = WM * WN * 64;
@@ -213,17 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
   const uint32_t offA0 = (wr * MI * 16 + fr) * 128, offB0 = (wc * NI * 16 + fr) * 128;
   const uint32_t sw = fr & 7u;  // (row & 7): tiles start at multiples of 16 rows
 
-  stage(0, 0);
-  for (uint32_t kt = 0; kt < KT; ++kt) {
-    const uint32_t buf = kt & 1u;
-    if (kt + 1 < KT) {
-      stage(kt + 1, buf ^ 1u);
-      // this stage's DMAs have landed, the next stage's SA + SB fly on
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+  auto compute = [&](uint32_t buf) {
     const unsigned char* sA = smem + buf * (A_BYTES + B_BYTES);
     const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
@@ -240,8 +230,41 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
+  };
+  if constexpr (STAGES == 2) {
+    // two stages, two barriers per k-step
+    stage(0, 0);
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+      const uint32_t buf = kt & 1u;
+      if (kt + 1 < KT) {
+        stage(kt + 1, buf ^ 1u);
+        // this stage's DMAs have landed, the next stage's SA + SB fly on
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      compute(buf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
+    }
+  } else {
+    // three stages, ONE barrier per k-step: stage kt+2 is issued after the barrier of step kt,
+    // i.e. when every wave has finished reading the buffer it overwrites (that of step kt-1)
+    stage(0, 0);
+    if (KT > 1) stage(1, 1);
+    uint32_t buf = 0;
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+      if (kt + 1 < KT)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");  // stage kt landed, stage kt+1 may fly
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < KT) stage(kt + 2, buf == 0 ? 2 : buf - 1);
+      compute(buf);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
   }
 
   // ---- epilogue: lo = approx - eps, minimum per 32-row group ------------------

@@ -1308,8 +1308,9 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
                              const RangeFilter& range, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt) {
   hipStream_t st = f->stream;
   // tile shape: 256 x 256 (8 waves) for real batches, 128 x 128 (4 waves, 2 workgroups per CU) for small ones
-  const bool big = nq > 128 && env_u32("MI355_FLAT_TILE", 256) == 256;
-  const uint32_t BM = big ? 256 : 128, BN = BM;
+  const uint32_t tile = nq > 128 ? env_u32("MI355_FLAT_TILE", 256) : 128;  // dev knob: 128, 256, 3 (= 256 x 128, 3 stages)
+  const bool big = tile == 256, tri = tile == 3;
+  const uint32_t BM = (big || tri) ? 256 : 128, BN = big ? 256 : 128;
   const uint32_t n_rtiles = (uint32_t)((f->n_rows + BM - 1) / BM);
   const uint32_t n_groups = n_rtiles * (BM / FG_GROUP);
   uint32_t groups_per_seg = (n_groups + FG_MAX_SEG - 1) / FG_MAX_SEG;
@@ -1368,16 +1369,21 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ga.omc = 1.f - f->c_err;
     ga.gm = f->g_gm.as<float>();
     const uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;
-    const size_t gemm_lds = (size_t)2 * (BM + BN) * FG_BK * 2;
+    const size_t gemm_lds = (size_t)(tri ? 3 : 2) * (BM + BN) * FG_BK * 2;
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \
-    if (big) {                                                                                      \
-      auto kern = k_flat_gemm<MET, 2, 4, 8, 4>;                                                     \
+    if (tri) {                                                                                      \
+      auto kern = k_flat_gemm<MET, 4, 2, 4, 4, 3>;                                                  \
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)gemm_lds));                                                  \
+      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
+    } else if (big) {                                                                               \
+      auto kern = k_flat_gemm<MET, 2, 4, 8, 4, 2>;                                                  \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
     } else {                                                                                        \
-      auto kern = k_flat_gemm<MET, 2, 2, 4, 4>;                                                     \
+      auto kern = k_flat_gemm<MET, 2, 2, 4, 4, 2>;                                                     \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(256), gemm_lds, st, ga);                     \

@@ -297,6 +297,35 @@ int32_t mi355_merge_topk(int32_t device, void *hip_stream,
                          uint32_t n_queries, uint32_t k, uint64_t *out_rowids,
                          float *out_dist, uint32_t *out_counts);
 
+/*
+ * Index population (first half): the O(N) transform stage of
+ * the reference's index build — given TRAINED IVF centroids and a PQ codebook
+ * (IvfBuildParams / PQBuildParams, rust/lancedb/src/table/create_index.rs:283-303),
+ * assign every row to its partition, PQ-encode its residual and lay the rows out
+ * partition by partition: exactly the arrays mi355_index_open takes
+ * (MI355_CODES_ROW_MAJOR).  k-means training itself runs on samples and is not part
+ * of this entry point.  Definitions (oracle/ann_oracle.c orc_ivfpq_encode):
+ *   cosine: rows are normalised first (x / sqrt(chain_dot(x,x)))
+ *   partition(x) = argmin_p coarse(x, c_p), ties to the lower p (the search's coarse formula)
+ *   code_j(x)    = argmin_c chain_l2(r_j, codebook[j][c]) with r = x - c_partition
+ *                  (dot: r = x, argmin_c 1 - chain_dot(x_j, codebook[j][c])), ties to the lower c
+ *   order        = rows sorted by (partition, source row): stable
+ */
+typedef struct mi355_encode_desc {
+  uint32_t struct_size;
+  uint32_t dim, nlist, m, nbits, metric;
+  uint32_t mem;       /* MI355_MEM_*: where vectors and the outputs live */
+  int32_t device;
+  const float *centroids; /* [nlist, dim], same memory as `mem` */
+  const float *codebook;  /* [m, 256, dim/m] */
+} mi355_encode_desc;
+
+int32_t mi355_ivfpq_encode(const mi355_encode_desc *desc, const float *vectors /*[n_rows, dim] f32*/,
+                           uint64_t n_rows, uint64_t *out_part_offsets /*[nlist+1], ALWAYS host*/,
+                           uint8_t *out_codes /*[n_rows, m], index order*/,
+                           uint64_t *out_order /*[n_rows]: source row at each index position*/,
+                           uint32_t *out_assign /*[n_rows] partition of each SOURCE row, or NULL*/);
+
 /* Deterministic partition -> shard assignment used by mi355_index_open
    (greedy: partitions by descending length, each to the least loaded shard;
    ties to the lower shard id).  out_owner is [nlist]. */

@@ -99,6 +99,21 @@ class FlatDesc(C.Structure):
     ]
 
 
+class EncodeDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("dim", C.c_uint32),
+        ("nlist", C.c_uint32),
+        ("m", C.c_uint32),
+        ("nbits", C.c_uint32),
+        ("metric", C.c_uint32),
+        ("mem", C.c_uint32),
+        ("device", C.c_int32),
+        ("centroids", C.c_void_p),
+        ("codebook", C.c_void_p),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -141,6 +156,7 @@ EXPORTED_SYMBOLS = (
     "mi355_flat_sync",
     "mi355_flat_search",
     "mi355_flat_info",
+    "mi355_ivfpq_encode",
     "mi355_merge_topk",
     "mi355_shard_plan",
 )

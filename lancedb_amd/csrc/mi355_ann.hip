@@ -25,6 +25,7 @@
 #include "kernels_flat_mfma.h"
 #include "kernels_ivfpq.h"
 #include "kernels_skew.h"
+#include "kernels_encode.h"
 
 // ------------------------------------------------------------------ errors --
 static thread_local std::string g_last_error;
@@ -1214,6 +1215,164 @@ extern "C" int32_t mi355_coarse_topn(mi355_index* ix, const float* queries, uint
     HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(uint32_t) * nq, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------ encode --
+namespace {
+struct EncodeScratch {  // released on every exit path
+  DevBuf cen, cb, cn, x, qp, qq, coarse, assign, hist, codes_src, codes_dst, order, cntB, lrank, run[2];
+  hipStream_t st = nullptr;
+  ~EncodeScratch() {
+    for (DevBuf* b : {&cen, &cb, &cn, &x, &qp, &qq, &coarse, &assign, &hist, &codes_src, &codes_dst, &order, &cntB,
+                      &lrank, &run[0], &run[1]})
+      b->release();
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+}  // namespace
+
+extern "C" int32_t mi355_ivfpq_encode(const mi355_encode_desc* d, const float* vectors, uint64_t n_rows,
+                                      uint64_t* out_part_offsets, uint8_t* out_codes, uint64_t* out_order,
+                                      uint32_t* out_assign) {
+  if (!d) return fail(MI355_ERR_INVALID_INPUT, "desc is NULL");
+  if (d->struct_size != sizeof(mi355_encode_desc))
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_encode_desc.struct_size %u != %zu (ABI mismatch)", d->struct_size,
+                sizeof(mi355_encode_desc));
+  if (d->dim == 0 || d->nlist == 0 || d->m == 0) return fail(MI355_ERR_INVALID_INPUT, "dim, nlist and m must be > 0");
+  if (d->dim % d->m) return fail(MI355_ERR_INVALID_INPUT, "dim %u is not a multiple of m %u", d->dim, d->m);
+  if (d->nbits != 8) return fail(MI355_ERR_NOT_SUPPORTED, "only 8-bit PQ codes (nbits = %u)", d->nbits);
+  if (d->metric > MI355_METRIC_DOT || d->mem > MI355_MEM_DEVICE) return fail(MI355_ERR_INVALID_INPUT, "bad metric / mem enum");
+  if (!d->centroids || !d->codebook || !out_part_offsets) return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
+  if (n_rows && (!vectors || !out_codes || !out_order)) return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
+  const uint32_t dim = d->dim, nlist = d->nlist, m = d->m, dsub = dim / m;
+  const uint32_t jt = (m % 4 == 0) ? 4 : 1;
+  if ((size_t)jt * 256 * dsub * 4 > 150u * 1024)
+    return fail(MI355_ERR_NOT_SUPPORTED, "dim / m = %u: the codebook slices do not fit LDS", dsub);
+  if ((size_t)dim * 16 > 150u * 1024) return fail(MI355_ERR_NOT_SUPPORTED, "dim %u too large", dim);
+  ST_TRY(need_device(d->device));
+  if (n_rows == 0) {
+    for (uint32_t p = 0; p <= nlist; ++p) out_part_offsets[p] = 0;
+    return MI355_OK;
+  }
+  EncodeScratch w;
+  HIP_TRY(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+  hipStream_t st = w.st;
+  const bool host = d->mem == MI355_MEM_HOST;
+  // chunk of rows: the [chunk, nlist] coarse matrix stays within 1 GiB
+  uint64_t chunk = std::min<uint64_t>(65536, ((size_t)1 << 30) / ((size_t)nlist * 4));
+  chunk = std::max<uint64_t>(256, chunk & ~(uint64_t)255);
+  chunk = std::min<uint64_t>(chunk, (n_rows + 255) & ~(uint64_t)255);
+
+  ST_TRY(w.cen.ensure(sizeof(float) * (size_t)nlist * dim));
+  ST_TRY(w.cb.ensure(sizeof(float) * (size_t)m * 256 * dsub));
+  ST_TRY(w.cn.ensure(sizeof(float) * nlist));
+  ST_TRY(w.qp.ensure(sizeof(float) * chunk * dim));
+  ST_TRY(w.qq.ensure(sizeof(float) * chunk));
+  ST_TRY(w.coarse.ensure(sizeof(float) * chunk * nlist));
+  ST_TRY(w.assign.ensure(sizeof(uint32_t) * n_rows));
+  ST_TRY(w.hist.ensure(sizeof(uint32_t) * nlist));
+  ST_TRY(w.codes_src.ensure((size_t)n_rows * m));
+  if (host) {
+    ST_TRY(w.x.ensure(sizeof(float) * chunk * dim));
+    ST_TRY(w.codes_dst.ensure((size_t)n_rows * m));
+    ST_TRY(w.order.ensure(sizeof(uint64_t) * n_rows));
+  }
+  HIP_TRY(copy_in(w.cen.p, d->centroids, sizeof(float) * (size_t)nlist * dim, d->mem, st));
+  HIP_TRY(copy_in(w.cb.p, d->codebook, sizeof(float) * (size_t)m * 256 * dsub, d->mem, st));
+  hipLaunchKernelGGL(k_centroid_norms, dim3((nlist + 63) / 64), dim3(64), 0, st, w.cen.as<float>(), nlist, dim,
+                     w.cn.as<float>());
+  HIP_TRY(hipMemsetAsync(w.hist.p, 0, sizeof(uint32_t) * nlist, st));
+
+  // ---- pass A: partition + codes of every row, in source order
+  const size_t enc_lds = (size_t)jt * 256 * dsub * 4;
+  if (jt == 4)
+    HIP_TRY(hipFuncSetAttribute((const void*)k_encode_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_lds));
+  else
+    HIP_TRY(hipFuncSetAttribute((const void*)k_encode_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)enc_lds));
+  for (uint64_t r0 = 0; r0 < n_rows; r0 += chunk) {
+    const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, n_rows - r0);
+    const float* d_x = vectors + (size_t)r0 * dim;
+    if (host) {
+      HIP_TRY(hipMemcpyAsync(w.x.p, d_x, sizeof(float) * (size_t)n * dim, hipMemcpyHostToDevice, st));
+      d_x = w.x.as<float>();
+    }
+    hipLaunchKernelGGL(k_prep_queries, dim3((n + 3) / 4), dim3(256), 4 * (((size_t)dim + 3) & ~(size_t)3) * 4, st, d_x,
+                       n, dim, d->metric, w.qp.as<float>(), w.qq.as<float>());
+    hipLaunchKernelGGL(k_coarse_mfma, dim3((nlist + CM_T - 1) / CM_T, (n + CM_T - 1) / CM_T), dim3(256), 0, st,
+                       w.qp.as<float>(), w.qq.as<float>(), n, w.cen.as<float>(), w.cn.as<float>(), nlist, dim,
+                       d->metric, w.coarse.as<float>());
+    hipLaunchKernelGGL(k_argmin_rows, dim3(n), dim3(256), 0, st, w.coarse.as<float>(), n, nlist,
+                       w.assign.as<uint32_t>() + r0, w.hist.as<uint32_t>());
+    EncodeArgs ea{w.qp.as<float>(), r0, n, w.assign.as<uint32_t>(), w.cen.as<float>(), w.cb.as<float>(),
+                  dim, m, dsub, d->metric, w.codes_src.as<uint8_t>()};
+    if (jt == 4)
+      hipLaunchKernelGGL(k_encode_rows<4>, dim3((n + 255) / 256, m / 4), dim3(256), enc_lds, st, ea);
+    else
+      hipLaunchKernelGGL(k_encode_rows<1>, dim3((n + 255) / 256, m), dim3(256), enc_lds, st, ea);
+    HIP_TRY(hipGetLastError());
+    if (host) HIP_TRY(hipStreamSynchronize(st));  // w.x is reused by the next chunk
+  }
+
+  // ---- partition offsets (nlist values: host scan)
+  std::vector<uint32_t> hist(nlist);
+  HIP_TRY(hipMemcpyAsync(hist.data(), w.hist.p, sizeof(uint32_t) * nlist, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<unsigned long long> base(nlist);
+  uint64_t run = 0;
+  for (uint32_t p = 0; p < nlist; ++p) {
+    out_part_offsets[p] = run;
+    base[p] = run;
+    run += hist[p];
+  }
+  out_part_offsets[nlist] = run;
+  if (run != n_rows) return fail(MI355_ERR_RUNTIME, "partition histogram counts %llu of %llu rows",
+                                 (unsigned long long)run, (unsigned long long)n_rows);
+
+  // ---- pass B: stable position of every row (chunks of <= 65536 rows = 256 blocks)
+  const uint64_t bchunk = 65536;
+  const uint32_t max_blocks = (uint32_t)((std::min(bchunk, n_rows) + 255) / 256);
+  ST_TRY(w.cntB.ensure(sizeof(uint32_t) * (size_t)max_blocks * nlist));
+  ST_TRY(w.lrank.ensure(sizeof(uint32_t) * (size_t)max_blocks * 256));
+  ST_TRY(w.run[0].ensure(sizeof(unsigned long long) * nlist));
+  ST_TRY(w.run[1].ensure(sizeof(unsigned long long) * nlist));
+  HIP_TRY(hipMemcpyAsync(w.run[0].p, base.data(), sizeof(unsigned long long) * nlist, hipMemcpyHostToDevice, st));
+  uint64_t* d_order = host ? w.order.as<uint64_t>() : out_order;
+  int cur = 0;
+  for (uint64_t r0 = 0; r0 < n_rows; r0 += bchunk, cur ^= 1) {
+    const uint32_t nb = (uint32_t)((std::min(bchunk, n_rows - r0) + 255) / 256);
+    HIP_TRY(hipMemsetAsync(w.cntB.p, 0, sizeof(uint32_t) * (size_t)nb * nlist, st));
+    hipLaunchKernelGGL(k_local_rank, dim3(nb), dim3(256), 0, st, w.assign.as<uint32_t>(), r0, n_rows, nlist,
+                       w.cntB.as<uint32_t>(), w.lrank.as<uint32_t>());
+    hipLaunchKernelGGL(k_block_scan, dim3((nlist + 255) / 256), dim3(256), 0, st, w.cntB.as<uint32_t>(), nb, nlist,
+                       w.run[cur].as<unsigned long long>(), w.run[cur ^ 1].as<unsigned long long>());
+    hipLaunchKernelGGL(k_positions, dim3(nb), dim3(256), 0, st, w.assign.as<uint32_t>(), r0, n_rows, nlist,
+                       w.cntB.as<uint32_t>(), w.lrank.as<uint32_t>(), w.run[cur].as<unsigned long long>(), d_order);
+  }
+  HIP_TRY(hipGetLastError());
+
+  // ---- pass C: code rows into index order
+  uint8_t* d_codes = host ? w.codes_dst.as<uint8_t>() : out_codes;
+  {
+    const uint64_t items = n_rows * (m / jt);
+    const uint64_t blocks = (items + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return fail(MI355_ERR_NOT_SUPPORTED, "too many rows for one permute launch");
+    if (jt == 4)
+      hipLaunchKernelGGL(k_permute_codes<4>, dim3((uint32_t)blocks), dim3(256), 0, st, w.codes_src.as<uint8_t>(),
+                         d_order, n_rows, m, d_codes);
+    else
+      hipLaunchKernelGGL(k_permute_codes<1>, dim3((uint32_t)blocks), dim3(256), 0, st, w.codes_src.as<uint8_t>(),
+                         d_order, n_rows, m, d_codes);
+    HIP_TRY(hipGetLastError());
+  }
+  if (host) {
+    HIP_TRY(hipMemcpyAsync(out_codes, d_codes, (size_t)n_rows * m, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_order, d_order, sizeof(uint64_t) * n_rows, hipMemcpyDeviceToHost, st));
+  }
+  if (out_assign)
+    HIP_TRY(hipMemcpyAsync(out_assign, w.assign.p, sizeof(uint32_t) * n_rows,
+                           host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return MI355_OK;
 }
 

@@ -268,3 +268,45 @@ def shard_plan(part_offsets, shard_count):
     out = np.empty(po.size - 1, dtype=np.uint32)
     check(lib().mi355_shard_plan(_ptr(po), C.c_uint32(po.size - 1), C.c_uint32(shard_count), _ptr(out)))
     return out
+
+
+def ivfpq_encode(vectors, centroids, codebook, metric="l2", device=0, return_assign=False):
+    """Index population (include/mi355_ann.h mi355_ivfpq_encode): assign every row
+    of `vectors` [n, dim] f32 to its IVF partition, PQ-encode its residual with the
+    trained `codebook` [m, 256, dim/m] and lay the rows out partition by partition —
+    the O(N) transform stage behind `Table.create_index(Index::IvfPq(..))`
+    (rust/lancedb/src/table/create_index.rs:114-151, :283-303).
+
+    Host arrays in -> host arrays out; device arrays (torch CUDA tensors or
+    DeviceArray, all three inputs) -> device outputs.  Returns
+    (part_offsets [nlist+1] u64 numpy, codes [n, m] u8, order [n] i64/u64
+    [, assign [n]]): exactly what IvfPqIndex takes (row_ids = ids[order],
+    raw_vectors = vectors[order])."""
+    dev_in = _is_device(vectors)
+    if dev_in != _is_device(centroids) or dev_in != _is_device(codebook):
+        raise ValueError("vectors, centroids and codebook must live in the same memory")
+    if not dev_in:
+        vectors = _host(vectors, np.float32)
+        centroids = _host(centroids, np.float32)
+        codebook = _host(codebook, np.float32)
+    n, dim = int(vectors.shape[0]), int(vectors.shape[1])
+    nlist, m = int(centroids.shape[0]), int(codebook.shape[0])
+    if tuple(centroids.shape) != (nlist, dim) or tuple(codebook.shape)[:2] != (m, 256) or m == 0 or dim % m \
+            or int(codebook.shape[2]) != dim // m:
+        raise ValueError("centroids must be [nlist, dim] and codebook [m, 256, dim/m]")
+    mcode = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else int(metric)
+    po = np.zeros(nlist + 1, dtype=np.uint64)
+    if dev_in:
+        dev_index = getattr(vectors.device, "index", vectors.device) or 0
+        codes, order, assign = _device_empty_like(vectors, [((n, m), "uint8"), ((n,), "int64"), ((n,), "int32")])
+    else:
+        dev_index = device
+        codes = np.empty((n, m), dtype=np.uint8)
+        order = np.empty(n, dtype=np.uint64)
+        assign = np.empty(n, dtype=np.uint32)
+    desc = _abi.EncodeDesc(struct_size=C.sizeof(_abi.EncodeDesc), dim=dim, nlist=nlist, m=m, nbits=8, metric=mcode,
+                           mem=_abi.MEM_DEVICE if dev_in else _abi.MEM_HOST, device=dev_index,
+                           centroids=_ptr(centroids), codebook=_ptr(codebook))
+    check(lib().mi355_ivfpq_encode(C.byref(desc), _ptr(vectors), C.c_uint64(n), _ptr(po), _ptr(codes), _ptr(order),
+                                   _ptr(assign) if return_assign else None))
+    return (po, codes, order, assign) if return_assign else (po, codes, order)

@@ -655,3 +655,84 @@ int32_t orc_shard_plan(const uint64_t *part_offsets, uint32_t nlist,
   free(c);
   return MI355_OK;
 }
+
+/* ------------------------------------------------------------ index population
+ * Restates the transform stage of the index build (assign + residual PQ encode +
+ * stable partition order); definitions in include/mi355_ann.h (mi355_ivfpq_encode). */
+int32_t orc_ivfpq_encode(const mi355_encode_desc *d, const float *vectors, uint64_t n_rows,
+                         uint64_t *out_part_offsets, uint8_t *out_codes, uint64_t *out_order,
+                         uint32_t *out_assign) {
+  if (!d || d->struct_size != sizeof(mi355_encode_desc) || !vectors || !out_part_offsets || !out_codes ||
+      !out_order || d->nbits != 8 || d->dim == 0 || d->m == 0 || d->dim % d->m || d->metric > MI355_METRIC_DOT)
+    return MI355_ERR_INVALID_INPUT;
+  const uint32_t dim = d->dim, nlist = d->nlist, m = d->m, dsub = dim / m;
+  float *cn = (float *)malloc(sizeof(float) * nlist);
+  for (uint32_t p = 0; p < nlist; ++p)
+    cn[p] = orc_chain_dot(d->centroids + (size_t)p * dim, d->centroids + (size_t)p * dim, dim);
+  uint32_t *assign = (uint32_t *)malloc(sizeof(uint32_t) * (n_rows ? n_rows : 1));
+  uint8_t *codes_src = (uint8_t *)malloc((size_t)m * (n_rows ? n_rows : 1));
+#pragma omp parallel
+  {
+    float *x = (float *)malloc(sizeof(float) * dim);
+#pragma omp for schedule(static)
+    for (uint64_t i = 0; i < n_rows; ++i) {
+      const float *src = vectors + (size_t)i * dim;
+      float qq = orc_chain_dot(src, src, dim);
+      if (d->metric == MI355_METRIC_COSINE) {
+        float nrm = sqrtf(qq);
+        for (uint32_t t = 0; t < dim; ++t) x[t] = src[t] / nrm;
+        qq = orc_chain_dot(x, x, dim);
+      } else {
+        memcpy(x, src, sizeof(float) * dim);
+      }
+      uint32_t best = 0;
+      float bd = 0.0f;
+      int have = 0;
+      for (uint32_t p = 0; p < nlist; ++p) {
+        float dot = orc_chain_dot(x, d->centroids + (size_t)p * dim, dim);
+        float dd = d->metric == MI355_METRIC_DOT ? 1.0f - dot : fmaf(-2.0f, dot, qq + cn[p]);
+        /* NaN never wins; the first finite-or-inf minimum does */
+        if (dd == dd && (!have || dd < bd)) {
+          bd = dd;
+          best = p;
+          have = 1;
+        }
+      }
+      assign[i] = best;
+      if (d->metric != MI355_METRIC_DOT)
+        for (uint32_t t = 0; t < dim; ++t) x[t] = x[t] - d->centroids[(size_t)best * dim + t];
+      for (uint32_t j = 0; j < m; ++j) {
+        uint32_t bc = 0;
+        float bv = 0.0f;
+        int hv = 0;
+        for (uint32_t c = 0; c < 256; ++c) {
+          const float *cb = d->codebook + ((size_t)j * 256 + c) * dsub;
+          float v = d->metric == MI355_METRIC_DOT ? 1.0f - orc_chain_dot(x + j * dsub, cb, dsub)
+                                                  : orc_chain_l2(x + j * dsub, cb, dsub);
+          if (v == v && (!hv || v < bv)) {
+            bv = v;
+            bc = c;
+            hv = 1;
+          }
+        }
+        codes_src[(size_t)i * m + j] = (uint8_t)bc;
+      }
+    }
+    free(x);
+  }
+  uint64_t *cnt = (uint64_t *)calloc(nlist + 1, sizeof(uint64_t));
+  for (uint64_t i = 0; i < n_rows; ++i) cnt[assign[i] + 1]++;
+  for (uint32_t p = 0; p < nlist; ++p) cnt[p + 1] += cnt[p];
+  memcpy(out_part_offsets, cnt, sizeof(uint64_t) * (nlist + 1));
+  for (uint64_t i = 0; i < n_rows; ++i) { /* stable: source order inside a partition */
+    uint64_t pos = cnt[assign[i]]++;
+    out_order[pos] = i;
+    memcpy(out_codes + (size_t)pos * m, codes_src + (size_t)i * m, m);
+  }
+  if (out_assign) memcpy(out_assign, assign, sizeof(uint32_t) * n_rows);
+  free(cnt);
+  free(codes_src);
+  free(assign);
+  free(cn);
+  return MI355_OK;
+}

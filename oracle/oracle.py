@@ -202,3 +202,24 @@ def shard_plan(part_offsets, shard_count):
     st = lib().orc_shard_plan(_ptr(po), C.c_uint32(nlist), C.c_uint32(shard_count), _ptr(out))
     assert st == 0
     return out
+
+
+def ivfpq_encode(vectors, centroids, codebook, metric="l2"):
+    """-> (part_offsets [nlist+1], codes [n, m] index order, order [n], assign [n])."""
+    v = _f32(vectors)
+    cen, cb = _f32(centroids), _f32(codebook)
+    n, dim = v.shape
+    nlist, m = cen.shape[0], cb.shape[0]
+    d = _abi.EncodeDesc()
+    d.struct_size = C.sizeof(_abi.EncodeDesc)
+    d.dim, d.nlist, d.m, d.nbits = dim, nlist, m, 8
+    d.metric = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else metric
+    d.mem, d.device = _abi.MEM_HOST, 0
+    d.centroids, d.codebook = _ptr(cen), _ptr(cb)
+    po = np.zeros(nlist + 1, dtype=np.uint64)
+    codes = np.empty((n, m), dtype=np.uint8)
+    order = np.empty(n, dtype=np.uint64)
+    assign = np.empty(n, dtype=np.uint32)
+    st = lib().orc_ivfpq_encode(C.byref(d), _ptr(v), C.c_uint64(n), _ptr(po), _ptr(codes), _ptr(order), _ptr(assign))
+    assert st == 0
+    return po, codes, order, assign

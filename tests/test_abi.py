@@ -106,3 +106,26 @@ def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_encode_validates_before_touching_a_device(L):
+    cent = np.zeros((4, 8), np.float32)
+    cb = np.zeros((2, 256, 4), np.float32)
+    po = np.zeros(5, np.uint64)
+
+    def call(**over):
+        f = dict(struct_size=C.sizeof(_abi.EncodeDesc), dim=8, nlist=4, m=2, nbits=8, metric=0, mem=0, device=0,
+                 centroids=cent.ctypes.data, codebook=cb.ctypes.data)
+        f.update(over)
+        d = _abi.EncodeDesc(**f)
+        return L.mi355_ivfpq_encode(C.byref(d), None, C.c_uint64(0), C.c_void_p(po.ctypes.data), None, None, None)
+
+    assert call(struct_size=8) == _abi.ERR_INVALID_INPUT and "ABI mismatch" in _lib.last_error()
+    assert call(m=3) == _abi.ERR_INVALID_INPUT
+    assert call(nbits=4) == _abi.ERR_NOT_SUPPORTED
+    assert call(metric=7) == _abi.ERR_INVALID_INPUT
+    assert call(centroids=None) == _abi.ERR_INVALID_INPUT
+    with pytest.raises(ValueError):
+        lancedb_amd.ivfpq_encode(np.zeros((3, 8), np.float32), cent, np.zeros((3, 256, 4), np.float32))
+    with pytest.raises(ValueError):
+        lancedb_amd.ivfpq_encode(np.zeros((3, 8), np.float32), np.zeros((4, 6), np.float32), cb)

@@ -288,3 +288,23 @@ def test_prefilter_postfilter_row_counts_like_the_reference(oracle):
     # block list = complement of the allow list
     ids_b, dist_b, _, _ = oracle.flat_search(v, q, k=10, block_rowids=np.arange(1, 512, 2, dtype=np.uint64))
     assert (ids_b == ids).all() and (dist_b == dist).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_encode_restatement_against_numpy_trainer(oracle, metric):
+    """orc_ivfpq_encode (the checker of mi355_ivfpq_encode) against the independent
+    numpy assignment / encoding of oracle/train.py (float64-free, different
+    summation order: agreement up to rounding-level near-ties), plus the
+    structural definitions: offsets = histogram prefix sums, order = stable sort."""
+    rng = np.random.default_rng(8)
+    cent = rng.normal(size=(24, 32)).astype(np.float32) * 2
+    x = (cent[rng.integers(0, 24, size=6000)] + rng.normal(size=(6000, 32))).astype(np.float32)
+    t = train.train_ivfpq(x, nlist=16, m=8, metric=metric, iters=4)
+    po, codes, order, assign = oracle.ivfpq_encode(x, t["centroids"], t["codebook"], metric)
+    assert (po[1:] - po[:-1] == np.bincount(assign, minlength=16)).all() and po[0] == 0
+    assert (order == np.argsort(assign, kind="stable")).all()
+    agree = assign[order] == t["assign"]  # the trainer's arrays are in index order
+    assert agree.mean() > 0.999
+    if agree.all():
+        assert (po == t["part_offsets"]).all()
+        assert (codes == t["codes"]).mean() > 0.999

@@ -326,6 +326,44 @@ int32_t mi355_ivfpq_encode(const mi355_encode_desc *desc, const float *vectors /
                            uint64_t *out_order /*[n_rows]: source row at each index position*/,
                            uint32_t *out_assign /*[n_rows] partition of each SOURCE row, or NULL*/);
 
+/*
+ * Index training (second half): the k-means behind
+ * IvfBuildParams (num_partitions, max_iterations, sample_rate) and PQBuildParams
+ * (one 256-entry codebook per sub-vector, trained on residuals) —
+ * rust/lancedb/src/index/vector.rs:61-119, create_index.rs:68-102, :283-303; the
+ * reference already sends this stage out of process for accelerators
+ * (python/python/lancedb/table.py:2883-2937).  lance's own trainer [EXT] draws a random
+ * initialisation, so centroid-for-centroid parity with it is undefined; this entry point
+ * is a DETERMINISTIC Lloyd iteration — the caller supplies the initial centroids — whose
+ * result is bit-exact against oracle/ann_oracle.c orc_kmeans_train:
+ *   cosine: rows are normalised first (as mi355_ivfpq_encode)
+ *   repeat `iters` times:
+ *     assign(x) = argmin_c coarse(x, c), ties to the lower c   (the search's coarse formula)
+ *     c <- (sum of its rows, added one by one in source-row order, f32) / count  (IEEE divide);
+ *          a centroid without rows keeps its value
+ * `ld` is the distance in floats between consecutive rows (0 = dim): a PQ sub-quantiser is
+ * trained on columns [j*dsub, (j+1)*dsub) of the residual matrix without copying it out.
+ */
+typedef struct mi355_kmeans_desc {
+  uint32_t struct_size;
+  uint32_t dim, k, metric, iters;
+  uint32_t mem;   /* MI355_MEM_*: vectors, centroids and the outputs */
+  int32_t device;
+  uint32_t reserved0;
+  uint64_t ld;    /* row stride of `vectors` in floats; 0 = dim */
+} mi355_kmeans_desc;
+
+int32_t mi355_kmeans_train(const mi355_kmeans_desc *desc, const float *vectors, uint64_t n_rows,
+                           float *centroids /*[k, dim] in: initial, out: trained*/,
+                           uint64_t *out_counts /*[k] rows per centroid at the last assignment, or NULL*/);
+
+/* Residuals of the rows to their partition centroid, the training set of the PQ
+   codebooks: out[i] = x_i - c[assign(x_i)] (cosine: x normalised first; dot: out = x).
+   out_assign may be NULL. */
+int32_t mi355_ivf_residuals(const mi355_kmeans_desc *desc /*k = nlist; iters, ld as above*/,
+                            const float *vectors, uint64_t n_rows, const float *centroids,
+                            float *out_residuals /*[n_rows, dim] dense*/, uint32_t *out_assign);
+
 /* Deterministic partition -> shard assignment used by mi355_index_open
    (greedy: partitions by descending length, each to the least loaded shard;
    ties to the lower shard id).  out_owner is [nlist]. */

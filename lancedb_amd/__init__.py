@@ -8,7 +8,9 @@ from . import _abi  # noqa: F401
 from ._lib import (EngineError, InvalidInput, NotSupported, QueryTimeout, build, device_count,  # noqa: F401
                    lib)
 from ._hip import DeviceArray, synchronize  # noqa: F401
-from .index import FlatIndex, IvfPqIndex, SearchResult, ivfpq_encode, merge_topk, shard_plan  # noqa: F401
+from .index import (FlatIndex, IvfPqIndex, SearchResult, ivf_residuals, ivfpq_encode, kmeans_train,  # noqa: F401
+                    merge_topk, shard_plan)
+from .build import IvfPqBuilder, suggested_num_partitions, suggested_num_sub_vectors  # noqa: F401
 from .query import DEFAULT_TOP_K, VectorQuery, VectorQueryRequest, VectorTable  # noqa: F401
 
 __version__ = "0.1.0"

@@ -114,6 +114,20 @@ class EncodeDesc(C.Structure):
     ]
 
 
+class KmeansDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("dim", C.c_uint32),
+        ("k", C.c_uint32),
+        ("metric", C.c_uint32),
+        ("iters", C.c_uint32),
+        ("mem", C.c_uint32),
+        ("device", C.c_int32),
+        ("reserved0", C.c_uint32),
+        ("ld", C.c_uint64),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -156,7 +170,7 @@ EXPORTED_SYMBOLS = (
     "mi355_flat_sync",
     "mi355_flat_search",
     "mi355_flat_info",
-    "mi355_ivfpq_encode",
+    "mi355_ivfpq_encode", "mi355_kmeans_train", "mi355_ivf_residuals",
     "mi355_merge_topk",
     "mi355_shard_plan",
 )

@@ -11,7 +11,7 @@ import numpy as np
 from ._lib import EngineError, lib
 
 _rt = None
-_H2D, _D2H = 1, 2
+_H2D, _D2H, _D2D = 1, 2, 3
 
 
 def runtime():
@@ -67,6 +67,13 @@ class DeviceArray:
             _check(rt.hipMemcpy(out.ctypes.data_as(C.c_void_p), self._p, C.c_size_t(self.nbytes), C.c_int(_D2H)),
                    "hipMemcpy D2H")
         return out
+
+    def copy_from(self, src):
+        """Device-to-device copy of another device array of the same byte size."""
+        if self.nbytes:
+            _check(runtime().hipMemcpy(self._p, C.c_void_p(src.data_ptr()), C.c_size_t(self.nbytes), C.c_int(_D2D)),
+                   "hipMemcpy D2D")
+        return self
 
     def data_ptr(self):
         return self._p.value or 0

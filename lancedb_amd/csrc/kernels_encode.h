@@ -204,3 +204,41 @@ __global__ void k_permute_codes(const uint8_t* __restrict__ src, const uint64_t*
   else
     dst[at * per + w] = src[row * per + w];
 }
+
+// ---- index training (mi355_kmeans_train / mi355_ivf_residuals) -------------------------
+// Lloyd update: one thread per (centroid, dimension) adds the centroid's rows ONE BY ONE in
+// source-row order (the stable order of pass B) — a sum whose order is part of the
+// definition, so the trained centroids are bit-exact against the oracle; loads run four
+// rows ahead of the adds.
+__global__ __launch_bounds__(256) void k_centroid_update(const float* __restrict__ xp,
+                                                         const uint64_t* __restrict__ order,
+                                                         const unsigned long long* __restrict__ po, uint32_t dim,
+                                                         float* __restrict__ cen) {
+  const uint32_t p = blockIdx.x;
+  const uint32_t d = blockIdx.y * 256 + threadIdx.x;
+  const unsigned long long lo = po[p], hi = po[p + 1];
+  if (d >= dim || hi == lo) return;  // a centroid without rows keeps its value
+  float acc = 0.f;
+  unsigned long long i = lo;
+  for (; i + 4 <= hi; i += 4) {
+    const float v0 = xp[(size_t)order[i] * dim + d], v1 = xp[(size_t)order[i + 1] * dim + d];
+    const float v2 = xp[(size_t)order[i + 2] * dim + d], v3 = xp[(size_t)order[i + 3] * dim + d];
+    acc = acc + v0;
+    acc = acc + v1;
+    acc = acc + v2;
+    acc = acc + v3;
+  }
+  for (; i < hi; ++i) acc = acc + xp[(size_t)order[i] * dim + d];
+  cen[(size_t)p * dim + d] = ieee_divf(acc, (float)(hi - lo));
+}
+
+__global__ void k_residuals(const float* __restrict__ xp, const uint32_t* __restrict__ assign,
+                            const float* __restrict__ cen, uint64_t n, uint32_t dim, uint32_t metric,
+                            float* __restrict__ out) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n * dim) return;
+  const uint64_t row = g / dim;
+  const uint32_t d = (uint32_t)(g - row * dim);
+  const float v = xp[g];
+  out[g] = metric == MI355_METRIC_DOT ? v : v - cen[(size_t)assign[row] * dim + d];
+}

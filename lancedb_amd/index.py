@@ -310,3 +310,73 @@ def ivfpq_encode(vectors, centroids, codebook, metric="l2", device=0, return_ass
     check(lib().mi355_ivfpq_encode(C.byref(desc), _ptr(vectors), C.c_uint64(n), _ptr(po), _ptr(codes), _ptr(order),
                                    _ptr(assign) if return_assign else None))
     return (po, codes, order, assign) if return_assign else (po, codes, order)
+
+
+def _kmeans_desc(dim, k, metric, iters, ld, dev_in, dev_index):
+    mcode = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else int(metric)
+    return _abi.KmeansDesc(struct_size=C.sizeof(_abi.KmeansDesc), dim=dim, k=k, metric=mcode, iters=iters,
+                           mem=_abi.MEM_DEVICE if dev_in else _abi.MEM_HOST, device=dev_index, reserved0=0, ld=ld)
+
+
+def kmeans_train(vectors, init_centroids, metric="l2", iters=50, cols=None, device=0):
+    """Deterministic Lloyd iterations on the GPU (include/mi355_ann.h
+    mi355_kmeans_train): the trainer behind IvfBuildParams / PQBuildParams
+    (rust/lancedb/src/index/vector.rs:61-119).  `init_centroids` [k, dim] seeds
+    it; `cols=(lo, hi)` trains on that column range of `vectors` in place (a PQ
+    sub-quantiser on the residual matrix).  -> (centroids [k, dim], counts [k])."""
+    dev_in = _is_device(vectors)
+    if dev_in != _is_device(init_centroids):
+        raise ValueError("vectors and init_centroids must live in the same memory")
+    if not dev_in:
+        vectors = _host(vectors, np.float32)
+        cen = np.array(init_centroids, dtype=np.float32, order="C", copy=True)
+    else:
+        cen, = _device_empty_like(vectors, [(tuple(init_centroids.shape), "float32")])
+        _copy_device(cen, init_centroids)
+    n, width = int(vectors.shape[0]), int(vectors.shape[1])
+    lo, hi = (0, width) if cols is None else cols
+    k, dim = int(cen.shape[0]), int(cen.shape[1])
+    if not (0 <= lo < hi <= width) or dim != hi - lo or k == 0:
+        raise ValueError("init_centroids must be [k, hi - lo] for the trained column range")
+    dev_index = (getattr(vectors.device, "index", vectors.device) or 0) if dev_in else device
+    desc = _kmeans_desc(dim, k, metric, iters, width, dev_in, dev_index)
+    base = C.c_void_p((vectors.data_ptr() if dev_in else vectors.ctypes.data) + 4 * lo)
+    counts = np.zeros(k, dtype=np.uint64)
+    if dev_in:
+        dcounts, = _device_empty_like(vectors, [((k,), "int64")])
+        check(lib().mi355_kmeans_train(C.byref(desc), base, C.c_uint64(n), _ptr(cen), _ptr(dcounts)))
+        return cen, dcounts
+    check(lib().mi355_kmeans_train(C.byref(desc), base, C.c_uint64(n), _ptr(cen), _ptr(counts)))
+    return cen, counts
+
+
+def ivf_residuals(vectors, centroids, metric="l2", device=0):
+    """x - centroid[partition(x)] for every row (cosine: x normalised first; dot: x):
+    the training set of the PQ codebooks.  -> (residuals [n, dim], assign [n])."""
+    dev_in = _is_device(vectors)
+    if dev_in != _is_device(centroids):
+        raise ValueError("vectors and centroids must live in the same memory")
+    if not dev_in:
+        vectors, centroids = _host(vectors, np.float32), _host(centroids, np.float32)
+    n, dim = int(vectors.shape[0]), int(vectors.shape[1])
+    k = int(centroids.shape[0])
+    if tuple(centroids.shape) != (k, dim) or k == 0:
+        raise ValueError("centroids must be [nlist, dim]")
+    if dev_in:
+        dev_index = getattr(vectors.device, "index", vectors.device) or 0
+        out, assign = _device_empty_like(vectors, [((n, dim), "float32"), ((n,), "int32")])
+    else:
+        dev_index = device
+        out, assign = np.empty((n, dim), dtype=np.float32), np.empty(n, dtype=np.uint32)
+    desc = _kmeans_desc(dim, k, metric, 0, 0, dev_in, dev_index)
+    check(lib().mi355_ivf_residuals(C.byref(desc), _ptr(vectors), C.c_uint64(n), _ptr(centroids), _ptr(out),
+                                    _ptr(assign)))
+    return out, assign
+
+
+def _copy_device(dst, src):
+    from ._hip import DeviceArray
+    if isinstance(dst, DeviceArray):
+        dst.copy_from(src)
+    else:
+        dst.copy_(src)

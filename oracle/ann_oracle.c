@@ -736,3 +736,107 @@ int32_t orc_ivfpq_encode(const mi355_encode_desc *d, const float *vectors, uint6
   free(cn);
   return MI355_OK;
 }
+
+/* ---- index training (checker of mi355_kmeans_train / mi355_ivf_residuals) ----------
+ * Deterministic Lloyd iteration as defined in include/mi355_ann.h; the reference's
+ * build parameters: rust/lancedb/src/index/vector.rs:61-119 (num_partitions,
+ * max_iterations, sample_rate, num_sub_vectors), create_index.rs:283-303.  lance's
+ * trainer itself is an external dependency with a random initialisation [EXT]; what is
+ * restated here is the definition both sides of the parity test follow. */
+static void orc_prep_row(const float *src, uint32_t dim, uint32_t metric, float *x, float *qq) {
+  float s = orc_chain_dot(src, src, dim);
+  if (metric == MI355_METRIC_COSINE) {
+    float nrm = sqrtf(s);
+    for (uint32_t t = 0; t < dim; ++t) x[t] = src[t] / nrm;
+    s = orc_chain_dot(x, x, dim);
+  } else {
+    memcpy(x, src, sizeof(float) * dim);
+  }
+  *qq = s;
+}
+
+static uint32_t orc_nearest(const float *x, float qq, const float *cen, const float *cn, uint32_t k,
+                            uint32_t dim, uint32_t metric) {
+  uint32_t best = 0;
+  float bd = 0.0f;
+  int have = 0;
+  for (uint32_t p = 0; p < k; ++p) {
+    float dot = orc_chain_dot(x, cen + (size_t)p * dim, dim);
+    float dd = metric == MI355_METRIC_DOT ? 1.0f - dot : fmaf(-2.0f, dot, qq + cn[p]);
+    if (dd == dd && (!have || dd < bd)) {
+      bd = dd;
+      best = p;
+      have = 1;
+    }
+  }
+  return best;
+}
+
+int32_t orc_kmeans_train(const mi355_kmeans_desc *d, const float *vectors, uint64_t n_rows, float *centroids,
+                         uint64_t *out_counts) {
+  if (!d || d->struct_size != sizeof(mi355_kmeans_desc) || !centroids || d->dim == 0 || d->k == 0 ||
+      d->metric > MI355_METRIC_DOT || (n_rows && !vectors))
+    return MI355_ERR_INVALID_INPUT;
+  const uint32_t dim = d->dim, k = d->k;
+  const uint64_t ld = d->ld ? d->ld : dim;
+  if (ld < dim) return MI355_ERR_INVALID_INPUT;
+  float *x = (float *)malloc(sizeof(float) * dim * (n_rows ? n_rows : 1));
+  float *qq = (float *)malloc(sizeof(float) * (n_rows ? n_rows : 1));
+  uint32_t *assign = (uint32_t *)malloc(sizeof(uint32_t) * (n_rows ? n_rows : 1));
+  float *cn = (float *)malloc(sizeof(float) * k);
+  float *sum = (float *)malloc(sizeof(float) * (size_t)k * dim);
+  uint64_t *cnt = (uint64_t *)calloc(k, sizeof(uint64_t));
+#pragma omp parallel for schedule(static)
+  for (uint64_t i = 0; i < n_rows; ++i) orc_prep_row(vectors + i * ld, dim, d->metric, x + i * dim, qq + i);
+  for (uint32_t it = 0; it < d->iters; ++it) {
+    for (uint32_t p = 0; p < k; ++p)
+      cn[p] = orc_chain_dot(centroids + (size_t)p * dim, centroids + (size_t)p * dim, dim);
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < n_rows; ++i)
+      assign[i] = orc_nearest(x + i * dim, qq[i], centroids, cn, k, dim, d->metric);
+    memset(sum, 0, sizeof(float) * (size_t)k * dim);
+    memset(cnt, 0, sizeof(uint64_t) * k);
+    for (uint64_t i = 0; i < n_rows; ++i) { /* source-row order inside every centroid */
+      float *s = sum + (size_t)assign[i] * dim;
+      const float *r = x + i * dim;
+      for (uint32_t t = 0; t < dim; ++t) s[t] = s[t] + r[t];
+      cnt[assign[i]]++;
+    }
+    for (uint32_t p = 0; p < k; ++p)
+      if (cnt[p]) {
+        const float c = (float)cnt[p];
+        for (uint32_t t = 0; t < dim; ++t) centroids[(size_t)p * dim + t] = sum[(size_t)p * dim + t] / c;
+      }
+  }
+  if (out_counts) memcpy(out_counts, cnt, sizeof(uint64_t) * k);
+  free(cnt);
+  free(sum);
+  free(cn);
+  free(assign);
+  free(qq);
+  free(x);
+  return MI355_OK;
+}
+
+int32_t orc_ivf_residuals(const mi355_kmeans_desc *d, const float *vectors, uint64_t n_rows, const float *centroids,
+                          float *out_residuals, uint32_t *out_assign) {
+  if (!d || d->struct_size != sizeof(mi355_kmeans_desc) || !centroids || d->dim == 0 || d->k == 0 ||
+      d->metric > MI355_METRIC_DOT || (n_rows && (!vectors || !out_residuals)))
+    return MI355_ERR_INVALID_INPUT;
+  const uint32_t dim = d->dim, k = d->k;
+  const uint64_t ld = d->ld ? d->ld : dim;
+  float *cn = (float *)malloc(sizeof(float) * k);
+  for (uint32_t p = 0; p < k; ++p)
+    cn[p] = orc_chain_dot(centroids + (size_t)p * dim, centroids + (size_t)p * dim, dim);
+#pragma omp parallel for schedule(static)
+  for (uint64_t i = 0; i < n_rows; ++i) {
+    float *x = out_residuals + i * dim, qq;
+    orc_prep_row(vectors + i * ld, dim, d->metric, x, &qq);
+    uint32_t a = orc_nearest(x, qq, centroids, cn, k, dim, d->metric);
+    if (out_assign) out_assign[i] = a;
+    if (d->metric != MI355_METRIC_DOT)
+      for (uint32_t t = 0; t < dim; ++t) x[t] = x[t] - centroids[(size_t)a * dim + t];
+  }
+  free(cn);
+  return MI355_OK;
+}

@@ -223,3 +223,38 @@ def ivfpq_encode(vectors, centroids, codebook, metric="l2"):
     st = lib().orc_ivfpq_encode(C.byref(d), _ptr(v), C.c_uint64(n), _ptr(po), _ptr(codes), _ptr(order), _ptr(assign))
     assert st == 0
     return po, codes, order, assign
+
+
+def _kmeans_desc(dim, k, metric, iters, ld):
+    d = _abi.KmeansDesc()
+    d.struct_size = C.sizeof(_abi.KmeansDesc)
+    d.dim, d.k, d.iters = dim, k, iters
+    d.metric = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else metric
+    d.mem, d.device, d.ld = _abi.MEM_HOST, 0, ld
+    return d
+
+
+def kmeans_train(vectors, init_centroids, metric="l2", iters=10, cols=None):
+    """Deterministic Lloyd (include/mi355_ann.h mi355_kmeans_train) -> (centroids, counts).
+    `cols=(lo, hi)` trains on that column range of `vectors` (strided rows)."""
+    v = _f32(vectors)
+    lo, hi = (0, v.shape[1]) if cols is None else cols
+    cen = np.array(init_centroids, dtype=np.float32, order="C", copy=True)
+    k, dim = cen.shape
+    assert dim == hi - lo
+    counts = np.zeros(k, dtype=np.uint64)
+    d = _kmeans_desc(dim, k, metric, iters, v.shape[1])
+    base = C.c_void_p(v.ctypes.data + 4 * lo)
+    st = lib().orc_kmeans_train(C.byref(d), base, C.c_uint64(v.shape[0]), _ptr(cen), _ptr(counts))
+    assert st == 0
+    return cen, counts
+
+
+def ivf_residuals(vectors, centroids, metric="l2"):
+    v, cen = _f32(vectors), _f32(centroids)
+    out = np.empty_like(v)
+    assign = np.empty(v.shape[0], dtype=np.uint32)
+    d = _kmeans_desc(v.shape[1], cen.shape[0], metric, 0, 0)
+    st = lib().orc_ivf_residuals(C.byref(d), _ptr(v), C.c_uint64(v.shape[0]), _ptr(cen), _ptr(out), _ptr(assign))
+    assert st == 0
+    return out, assign

@@ -42,6 +42,17 @@ def main():
         out["sample_bit_exact"] = bool((got[0] == epo).all() and (got[1] == ecodes).all() and (got[2] == eorder).all())
     except Exception as e:  # noqa: BLE001
         out["oracle_error"] = repr(e)
+    # training: Lloyd iterations of the IVF k-means on a sample (sample_rate 64 -> 262144 rows)
+    ns, iters = min(n, 262144), 5
+    init = DeviceArray.from_numpy(x[rng.choice(ns, size=nlist, replace=False)])
+    ds = DeviceArray.from_numpy(x[:ns])
+    lancedb_amd.kmeans_train(ds, init, iters=1)
+    lancedb_amd.synchronize()
+    t0 = time.perf_counter()
+    lancedb_amd.kmeans_train(ds, init, iters=iters)
+    lancedb_amd.synchronize()
+    t_km = time.perf_counter() - t0
+    out["kmeans"] = dict(rows=ns, k=nlist, iters=iters, seconds=t_km, row_iters_per_s=ns * iters / t_km)
     print(json.dumps(out))
 
 

@@ -129,3 +129,37 @@ def test_encode_validates_before_touching_a_device(L):
         lancedb_amd.ivfpq_encode(np.zeros((3, 8), np.float32), cent, np.zeros((3, 256, 4), np.float32))
     with pytest.raises(ValueError):
         lancedb_amd.ivfpq_encode(np.zeros((3, 8), np.float32), np.zeros((4, 6), np.float32), cb)
+
+
+def test_kmeans_validates_before_touching_a_device(L):
+    cen = np.zeros((4, 8), np.float32)
+
+    def call(fn, **over):
+        f = dict(struct_size=C.sizeof(_abi.KmeansDesc), dim=8, k=4, metric=0, iters=1, mem=0, device=0, reserved0=0, ld=0)
+        f.update(over)
+        d = _abi.KmeansDesc(**f)
+        if fn == "train":
+            return L.mi355_kmeans_train(C.byref(d), None, C.c_uint64(0), C.c_void_p(cen.ctypes.data), None)
+        return L.mi355_ivf_residuals(C.byref(d), None, C.c_uint64(0), C.c_void_p(cen.ctypes.data), None, None)
+
+    for fn in ("train", "resid"):
+        assert call(fn, struct_size=4) == _abi.ERR_INVALID_INPUT and "ABI mismatch" in _lib.last_error()
+        assert call(fn, k=0) == _abi.ERR_INVALID_INPUT
+        assert call(fn, metric=9) == _abi.ERR_INVALID_INPUT
+        assert call(fn, ld=4) == _abi.ERR_INVALID_INPUT
+    with pytest.raises(ValueError):
+        lancedb_amd.kmeans_train(np.zeros((10, 8), np.float32), np.zeros((4, 6), np.float32))
+    with pytest.raises(ValueError):
+        lancedb_amd.kmeans_train(np.zeros((10, 8), np.float32), np.zeros((4, 4), np.float32), cols=(6, 10))
+
+
+def test_builder_parameter_defaults_follow_the_reference():
+    """index/vector.rs:306-319 (sub-vectors) and :64-66 (partitions = sqrt(rows))."""
+    assert [lancedb_amd.suggested_num_sub_vectors(d) for d in (768, 1536, 24, 7, 16, 8)] == [48, 96, 3, 1, 1, 1]
+    assert lancedb_amd.suggested_num_partitions(1_000_000) == 1000
+    with pytest.raises(NotImplementedError):
+        lancedb_amd.IvfPqBuilder(num_bits=4)
+    b = lancedb_amd.IvfPqBuilder()
+    assert (b.sample_rate, b.max_iterations, b.distance_type) == (256, 50, "l2")
+    with pytest.raises(ValueError):
+        b.train(np.zeros((10, 16), np.float32))

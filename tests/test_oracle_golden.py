@@ -308,3 +308,28 @@ def test_encode_restatement_against_numpy_trainer(oracle, metric):
     if agree.all():
         assert (po == t["part_offsets"]).all()
         assert (codes == t["codes"]).mean() > 0.999
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+def test_kmeans_restatement_against_numpy_lloyd(oracle, metric):
+    """orc_kmeans_train against a plain numpy Lloyd iteration (float64 sums): same
+    assignments on well-separated data, centroids equal to rounding."""
+    rng = np.random.default_rng(5)
+    cent = rng.normal(size=(10, 12)) * 6
+    x = (cent[rng.integers(0, 10, size=3000)] + rng.normal(size=(3000, 12))).astype(np.float32)
+    init = x[rng.choice(3000, size=10, replace=False)].copy()
+    got, counts = oracle.kmeans_train(x, init, metric, 4)
+    xs = x.astype(np.float64)
+    if metric == "cosine":
+        xs = xs / np.linalg.norm(xs, axis=1, keepdims=True)
+    c = init.astype(np.float64)
+    for _ in range(4):
+        a = ((xs[:, None] - c[None]) ** 2).sum(-1).argmin(1)
+        last = np.bincount(a, minlength=10)
+        for p in range(10):
+            if last[p]:
+                c[p] = xs[a == p].mean(0)
+    assert (counts == last).all()
+    np.testing.assert_allclose(got, c, rtol=2e-4, atol=2e-5)
+    r, a2 = oracle.ivf_residuals(x, got, metric)
+    np.testing.assert_allclose(r, xs - got.astype(np.float64)[a2], rtol=1e-4, atol=1e-5)

@@ -296,29 +296,13 @@ def main():
         dist.destroy_process_group()
 
 
-def _gpu_kmeans(torch, x, k, iters, gen):
-    """Plain Lloyd k-means on the GPU (training helper of the recall leg only)."""
-    n = x.shape[0]
-    c = x[torch.randperm(n, generator=gen, device=x.device)[:k]].clone()
-    for _ in range(iters):
-        a = torch.cdist(x, c).argmin(1)
-        cnt = torch.bincount(a, minlength=k).to(x.dtype)
-        sums = torch.zeros_like(c).index_add_(0, a, x)
-        live = cnt > 0
-        c[live] = sums[live] / cnt[live, None]
-        dead = (~live).nonzero().flatten()
-        if dead.numel():
-            c[dead] = x[torch.randint(0, n, (dead.numel(),), generator=gen, device=x.device)]
-    return c
-
-
 def recall_at_10(a, np, dim, m):
     """recall@10 of the engine's IVF-PQ search against exact flat search (the
     engine's own flat path, bit-identical to the oracle's exact sweep) on a REAL
     index: Gaussian-mixture vectors; IVF centroids and residual PQ codebooks
-    trained with plain Lloyd k-means (torch on the GPU, training only: index
+    trained and all rows encoded by the engine's own build entry points (index
     parameters follow the reference's builder, 8-bit PQ with m sub-vectors,
-    rust/lancedb/src/index/vector.rs:266-319).  The 100 M throughput index has
+    rust/lancedb/src/index/vector.rs:61-119, :266-319).  The 100 M throughput index has
     random codes, so recall is only meaningful here."""
     import torch
     import lancedb_amd
@@ -330,29 +314,42 @@ def recall_at_10(a, np, dim, m):
     comps = torch.randn((2048, dim), generator=g, device=dev) * 1.5
     x = comps[torch.randint(0, 2048, (n,), generator=g, device=dev)] + torch.randn((n, dim), generator=g, device=dev)
     q = comps[torch.randint(0, 2048, (nq,), generator=g, device=dev)] + torch.randn((nq, dim), generator=g, device=dev)
-    cen = _gpu_kmeans(torch, x, nlist, 6, g)
-    assign = torch.cdist(x, cen).argmin(1)
-    resid = x - cen[assign]
+    # the engine's own build path (mi355_kmeans_train / mi355_ivf_residuals / mi355_ivfpq_encode),
+    # device-resident; sample sizes as the reference's sample_rate = 256 (index/vector.rs:76-91)
+    iters = 6
+    torch.cuda.synchronize()
+    pick = torch.randperm(n, generator=g, device=dev)
+    ivf_rows = x[pick[:min(n, 256 * nlist)].sort().values].contiguous()
+    init = ivf_rows[torch.randperm(ivf_rows.shape[0], generator=g, device=dev)[:nlist].sort().values].contiguous()
+    torch.cuda.synchronize()
+    t_train = time.perf_counter()
+    cen, _ = lancedb_amd.kmeans_train(ivf_rows, init, iters=iters)
+    pq_rows = x[pick[:min(n, 256 * 256)].sort().values].contiguous()
+    torch.cuda.synchronize()
+    resid, _ = lancedb_amd.ivf_residuals(pq_rows, cen)
+    seeds = resid[torch.randperm(resid.shape[0], generator=g, device=dev)[:256].sort().values]
     codebook = torch.empty((m, 256, dsub), device=dev)
-    codes = torch.empty((n, m), dtype=torch.uint8, device=dev)
     for j in range(m):
-        sub = resid[:, j * dsub:(j + 1) * dsub].contiguous()
-        cb = _gpu_kmeans(torch, sub, 256, 6, g)
+        cb0 = seeds[:, j * dsub:(j + 1) * dsub].contiguous()
+        torch.cuda.synchronize()
+        cb, _ = lancedb_amd.kmeans_train(resid, cb0, iters=iters, cols=(j * dsub, (j + 1) * dsub))
         codebook[j] = cb
-        codes[:, j] = torch.cdist(sub, cb).argmin(1).to(torch.uint8)
-    order = torch.argsort(assign, stable=True)
-    counts = torch.bincount(assign, minlength=nlist).cpu().numpy()
-    part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
-    part_offsets[1:] = np.cumsum(counts)
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t_train
+    t_enc = time.perf_counter()
+    part_offsets, codes, order = lancedb_amd.ivfpq_encode(x, cen, codebook)
+    t_enc = time.perf_counter() - t_enc
     xs = x[order].contiguous()
-    ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes[order].contiguous(),
-                                order.contiguous(), raw_vectors=xs)
+    torch.cuda.synchronize()
+    ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes, order, raw_vectors=xs)
     fl = lancedb_amd.FlatIndex(x.contiguous())
     torch.cuda.synchronize()
     hq = q.cpu().numpy()
     truth = fl.search(hq, k=10).rowids
     out = {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "queries": nq, "truth": "exact flat search (engine flat path)",
-           "data": "2048-component Gaussian mixture; IVF + residual PQ trained by 6 Lloyd iterations"}
+           "data": "2048-component Gaussian mixture; IVF + residual PQ trained by 6 Lloyd iterations "
+                   "(mi355_kmeans_train), rows encoded by mi355_ivfpq_encode",
+           "train_seconds": round(t_train, 2), "encode_rows_per_s": round(n / t_enc)}
     for nprobe, rf in ((64, 0), (64, 10), (16, 0)):
         got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf).rowids
         rec = float(np.mean([len(set(truth[i].tolist()) & set(got[i].tolist())) / 10.0 for i in range(nq)]))

@@ -432,3 +432,51 @@ def test_vector_table_mirror_end_to_end(oracle):
     flat = t.vector_search(q[1]).bypass_vector_index().limit(4).execute()
     fi, fd, _, _ = oracle.flat_search(raw, q[1:], k=4)
     assert flat["_rowid"].tolist() == fi[0].tolist() and (flat["_distance"] == fd[0]).all()
+
+
+def test_c4_config_shape_nlist_65536_nprobe_128_sharded_coarse(oracle):
+    """BASELINE.json configs[3] at a reduced row count: nlist = 65536, m = 96 x 8 bit,
+    dim 768, nprobe = 128, partitions AND the coarse stage sharded 8 ways (two-phase
+    search), merged with mi355_merge_topk == the unsharded oracle result."""
+    from lancedb_amd.distributed import coarse_slice
+    DA = lancedb_amd.DeviceArray
+    nlist, dim, m, shards, nprobe = 65536, 768, 96, 8, 128
+    s = train.synthetic_index(400_000, dim, nlist, m, seed=65, skew=1.0, empty_parts=1000)
+    rng = np.random.default_rng(4)
+    q = (s["centroids"][rng.integers(0, nlist, size=12)] + rng.normal(0, 0.3, size=(12, dim))).astype(np.float32)
+    g, o = _both(oracle, s)
+    exp = o.search(q, k=10, nprobe_min=nprobe, nprobe_max=nprobe)
+    _assert_same(g.search(q, k=10, nprobe_min=nprobe, nprobe_max=nprobe), exp)
+    hs = [lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                                 shard_count=shards, shard_rank=r) for r in range(shards)]
+    lists = [h.coarse_topn(q, nprobe, *coarse_slice(nlist, shards, r)) for r, h in enumerate(hs)]
+    pr, _, _ = lancedb_amd.merge_topk(DA.from_numpy(np.stack([l[0].astype(np.int64) for l in lists])),
+                                      DA.from_numpy(np.stack([l[1] for l in lists])),
+                                      DA.from_numpy(np.stack([l[2].astype(np.int32) for l in lists])), nprobe)
+    probes = pr.numpy().astype(np.uint64)
+    parts = [h.search_probes(q, probes, k=10) for h in hs]
+    mi, md, mc = lancedb_amd.merge_topk(DA.from_numpy(np.stack([p.rowids.astype(np.int64) for p in parts])),
+                                        DA.from_numpy(np.stack([p.distances for p in parts])),
+                                        DA.from_numpy(np.stack([p.counts.astype(np.int32) for p in parts])), 10)
+    assert (mi.numpy().astype(np.uint64) == exp[0]).all() and (md.numpy() == exp[1]).all()
+    assert (mc.numpy().astype(np.uint32) == exp[2]).all()
+
+
+@pytest.mark.parametrize("raw_dtype", ["f32", "f16"])
+def test_c5_config_shape_1536d_cosine_refine10(oracle, raw_dtype):
+    """BASELINE.json configs[4] at a reduced row count: dim 1536, cosine, nprobe = 64,
+    refine_factor = 10 with the raw-vector re-rank on the GPU (f32 and f16 raw columns)."""
+    n, dim, nlist, m = 60_000, 1536, 256, 96
+    s = train.synthetic_index(n, dim, nlist, m, seed=15, skew=0.7)
+    rng = np.random.default_rng(8)
+    raw = rng.normal(size=(n, dim)).astype(np.float32)
+    dt = _abi.DTYPE_F32
+    if raw_dtype == "f16":
+        raw, dt = raw.astype(np.float16).view(np.uint16), _abi.DTYPE_F16
+    g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                               raw_vectors=raw, metric="cosine", raw_dtype=dt)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                           raw_vectors=raw, metric="cosine", raw_dtype=dt)
+    q = rng.normal(size=(24, dim)).astype(np.float32)
+    for kw in (dict(k=10, nprobe_min=64, nprobe_max=64, refine_factor=10), dict(k=10, nprobe_min=64, nprobe_max=64)):
+        _assert_same(g.search(q, **kw), o.search(q, **kw))

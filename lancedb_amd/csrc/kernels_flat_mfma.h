@@ -28,8 +28,6 @@
 #define FG_GROUP 32 // rows per group minimum
 #define FG_MAX_SEG 1024
 #define FG_CAND_CAP 1024  // candidate groups per query before the exact re-scan kicks in
-#define STAGES_LDS(S) ((S) == 3 ? 3 : 2)  // LDS stage buffers of a schedule (4 = staggered, two buffers)
-#define FG_PF_LDS 2048    // scratch landing zone of the L2 prefetch pieces (256 B per wave)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 fg_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float fg_f32x4;
@@ -136,18 +134,12 @@ struct FlatGemmArgs {
   uint32_t n_qtiles;     // nq_pad / 128
   uint32_t n_rtiles;     // ceil(n_rows / 128)
   float omc;             // 1 - c_err (weight of |v|^2 in the L2 bound)
-  uint32_t pf_dist;      // L2 prefetch distance in k-tiles (0 = off; two-stage schedules)
   float* gm;             // [n_rtiles * 4][nq_pad] group minima of lo
 };
 
 __device__ __forceinline__ void fg_glds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-__device__ __forceinline__ void fg_glds4(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
 // 256 threads = 4 waves as 2 (rows) x 2 (queries); each wave owns a 64 x 64 block of
@@ -214,24 +206,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
     for (int i = 0; i < SB; ++i) fg_glds16(kB + oB[i], sB + (i * NT + wid * 64) * 16);
   };
 
-  // L2 prefetch of the row tile's k-tile `kt` (clamped): one 4-byte LDS-DMA per 128-B line
-  // into a scratch corner of LDS - no destination VGPR, counted by vmcnt like any piece.  The
-  // rows of a tile are 128-B chunks of different DRAM pages; with one k-tile of look-ahead the
-  // HBM latency of that scattered read sat on every step's critical path.
-  constexpr int PF_LANES = BM / (NT / 64);  // rows per wave
-  static_assert(PF_LANES <= 64, "one prefetch piece per wave");
-  unsigned char* pf_lds = smem + STAGES_LDS(STAGES) * (A_BYTES + B_BYTES) + wid * 256;
-  uint32_t pf_off;
-  {
-    uint64_t vr = row0 + (uint32_t)wid * PF_LANES + (lane < PF_LANES ? lane : 0);
-    if (vr >= a.n_rows) vr = a.n_rows - 1;
-    pf_off = (uint32_t)((vr - row0) * pitch);
-  }
-  auto prefetch = [&](uint32_t kt) {
-    if (kt >= KT) kt = KT - 1;
-    if (lane < PF_LANES) fg_glds4(baseA + (size_t)kt * (FG_BK * 2) + pf_off, pf_lds);
-  };
-
   fg_f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -282,128 +256,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
     }
     __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
   };
-  if constexpr (STAGES == 4) {
-    // Two LDS buffers, the two wave groups staggered by one barrier.  Group 0 (wr = 0) and
-    // group 1 (wr = 1) place one wave each on every SIMD; in lockstep both would issue DMA,
-    // wait, read fragments and only then feed the matrix pipe together.  Here they alternate:
-    //   slot 2kt+1 (between barriers 2kt+1 and 2kt+2): group 0 computes tile kt and issues its
-    //              DMA pieces of tile kt+1 between its MFMAs; group 1 issues its pieces of kt+1
-    //   slot 2kt+2: group 1 computes tile kt; group 0 only waits for its DMA
-    // Tile kt lives in buffer kt & 1.  WAR: tile kt+1 overwrites the buffer of tile kt-1, last
-    // read in slot 2kt (group 1), and no piece is issued before barrier 2kt+1.  RAW: tile kt+1
-    // is first read in slot 2kt+3; every wave retires its own pieces (vmcnt(0)) before it
-    // arrives at barrier 2kt+3.  Both groups execute 1 + 2 KT barriers.  One copy of the
-    // compute code serves both groups (the pieces sit behind a scalar branch), so the register
-    // allocation is that of the lockstep kernel.
-    static_assert(WM == 2, "two wave groups");
-    constexpr int PIECES = SA + SB;
-    static_assert(PIECES * 4 <= MI * NI, "one DMA piece per 4 MFMAs of the second k-half");
+  if constexpr (STAGES == 2) {
+    // two stages, two barriers per k-step
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     for (uint32_t kt = 0; kt < KT; ++kt) {
       const uint32_t buf = kt & 1u;
-      const bool more = kt + 1 < KT;
-      if (wr == 1) {
-        if (more) stage(kt + 1, buf ^ 1u);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      const bool pieces = more && wr == 0;
-      const unsigned char* sA = smem + buf * (A_BYTES + B_BYTES);
-      const unsigned char* sB = sA + A_BYTES;
-      unsigned char* dA = smem + (buf ^ 1u) * (A_BYTES + B_BYTES);
-      unsigned char* dB = dA + A_BYTES;
-      const unsigned char* kA = baseA + (size_t)(kt + 1) * (FG_BK * 2);
-      const unsigned char* kB = baseB + (size_t)(kt + 1) * (FG_BK * 2);
-      fg_bf16x8 fa[2][MI], fb[2][NI];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint32_t ch = ((kk * 4 + fk) ^ sw) << 4;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) fb[kk][i] = *(const fg_bf16x8*)(sB + offB0 + i * 2048 + ch);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[kk][i] = *(const fg_bf16x8*)(sA + offA0 + i * 2048 + ch);
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][mi], fb[0][ni], acc[mi][ni], 0, 0, 0);
-      {
-        constexpr int PAIRS = (MI + NI) / 2, PRE = MI - PAIRS;
-        __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
-        if constexpr (PRE > 0) __builtin_amdgcn_sched_group_barrier(0x008, NI * PRE, 0);
-#pragma unroll
-        for (int i = 0; i < PAIRS; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-      }
-      // second k-half: 4 MFMAs, then (group 0) one DMA piece of the next tile
-#pragma unroll
-      for (int t = 0; t < MI * NI / 4; ++t) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int mi = (t * 4 + u) / NI, ni = (t * 4 + u) % NI;
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][mi], fb[1][ni], acc[mi][ni], 0, 0, 0);
-        }
-        if (t < PIECES && pieces) {
-          if (t < SA)
-            fg_glds16(kA + oA[t < SA ? t : 0], dA + (t * NT + wid * 64) * 16);
-          else
-            fg_glds16(kB + oB[t >= SA ? t - SA : 0], dB + ((t - SA) * NT + wid * 64) * 16);
-        }
-      }
-      if (wr == 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+      if (kt + 1 < KT) {
+        stage(kt + 1, buf ^ 1u);
+        // this stage's DMAs have landed, the next stage's SA + SB fly on
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-    }
-  } else if constexpr (STAGES == 2) {
-    // two stages, two barriers per k-step; with pf_dist the wave also keeps one prefetch piece
-    // per step in flight (issued after the stage's pieces, so counted vmcnt still retires the
-    // stage in order)
-    const uint32_t pf = a.pf_dist;
-    stage(0, 0);
-    if (pf) {
-      prefetch(1);
-      for (uint32_t kt = 0; kt < KT; ++kt) {
-        const uint32_t buf = kt & 1u;
-        if (kt + 1 < KT) {
-          stage(kt + 1, buf ^ 1u);
-          prefetch(kt + 1 + pf);
-          // outstanding after this stage's pieces landed: prefetch, next stage's pieces, prefetch
-          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB + 2) : "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        compute(buf);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      for (uint32_t kt = 0; kt < KT; ++kt) {
-        const uint32_t buf = kt & 1u;
-        if (kt + 1 < KT) {
-          stage(kt + 1, buf ^ 1u);
-          // this stage's DMAs have landed, the next stage's SA + SB fly on
-          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        compute(buf);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
-      }
+      __builtin_amdgcn_s_barrier();
+      compute(buf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
     }
   } else {
     // three stages, ONE barrier per k-step: stage kt+2 is issued after the barrier of step kt,

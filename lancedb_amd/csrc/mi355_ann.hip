@@ -1638,8 +1638,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
   hipStream_t st = f->stream;
   // tile shape: 256 x 256 (8 waves) for real batches, 128 x 128 (4 waves, 2 workgroups per CU) for small ones
   const uint32_t tile = nq > 128 ? env_u32("MI355_FLAT_TILE", 256) : 128;  // dev knob: 128, 256, 3 (= 256 x 128, 3 stages)
-  const bool stag = tile == 4;  // dev: 256 x 256, the two wave groups staggered by one barrier
-  const bool big = tile == 256 || stag, tri = tile == 3;
+  const bool big = tile == 256, tri = tile == 3;
   const uint32_t BM = (big || tri) ? 256 : 128, BN = big ? 256 : 128;
   const uint32_t n_rtiles = (uint32_t)((f->n_rows + BM - 1) / BM);
   const uint32_t n_groups = n_rtiles * (BM / FG_GROUP);
@@ -1697,19 +1696,13 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ga.n_qtiles = n_pad / BN;
     ga.n_rtiles = n_rtiles;
     ga.omc = 1.f - f->c_err;
-    ga.pf_dist = env_u32("MI355_FLAT_PF", 0);  // dev: L2 prefetch distance of the row tile (k-tiles)
     ga.gm = f->g_gm.as<float>();
     const uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;
-    const size_t gemm_lds = (size_t)(tri ? 3 : 2) * (BM + BN) * FG_BK * 2 + FG_PF_LDS;
+    const size_t gemm_lds = (size_t)(tri ? 3 : 2) * (BM + BN) * FG_BK * 2;
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \
     if (tri) {                                                                                      \
       auto kern = k_flat_gemm<MET, 4, 2, 4, 4, 3>;                                                  \
-      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                  (int)gemm_lds));                                                  \
-      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
-    } else if (stag) {                                                                              \
-      auto kern = k_flat_gemm<MET, 2, 4, 8, 4, 4>;                                                  \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_flat_prep_queries(FlatQueryPrepArgs a) 
 struct FlatGemmArgs {
   const uint16_t* v;     // [n_rows, dimp] bf16 (shadow or the column itself)
   const uint16_t* qb;    // [nq_pad, dimp] bf16
-  const float* vv;       // [n_rows]
+  const float* vv;       // [n_rows rounded up to 256], tail 0
   const float* qa;       // [nq_pad]
   const float* qg;       // [nq_pad]
   uint64_t n_rows;
@@ -165,36 +165,56 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar branches on the wave's role
   const int wr = wid / WN, wc = wid % WN;
   // XCD-aware order: the query tiles of one row tile run back to back on ONE XCD
-  // (block b lands on XCD b % 8), so the row tile is fetched from HBM once.
-  const uint32_t b = blockIdx.x;
-  const uint32_t xcd = b & 7u, slot = b >> 3;
-  const uint32_t qt = slot % a.n_qtiles;
-  const uint32_t rt = (slot / a.n_qtiles) * 8u + xcd;
-  if (rt >= a.n_rtiles) return;
-  const uint64_t row0 = (uint64_t)rt * BM;
-  const uint32_t q0 = qt * BN;
+  // (block b lands on XCD b % 8), so the row tile is fetched from HBM once.  A workgroup
+  // walks the virtual block ids vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple
+  // of 8, so it stays on its XCD's tiles): with one virtual block per workgroup this is the
+  // plain grid, with a grid of one workgroup per CU slot it is a persistent kernel that
+  // issues the next tile's first stage before the last k-step of the current one.
   const uint32_t KT = a.dimp / FG_BK;
   const size_t pitch = (size_t)a.dimp * 2;  // bytes per row of v / qb
+  const uint32_t total_vb = ((a.n_rtiles + 7u) / 8u) * 8u * a.n_qtiles;
+  uint32_t rt = 0, qt = 0;
+  auto next_valid = [&](uint32_t v) {  // first virtual block >= v (stride gridDim.x) that maps to a row tile
+    while (v < total_vb) {
+      const uint32_t slot = v >> 3;
+      qt = slot % a.n_qtiles;
+      rt = (slot / a.n_qtiles) * 8u + (v & 7u);
+      if (rt < a.n_rtiles) break;
+      v += gridDim.x;
+    }
+    return v;
+  };
+  uint32_t vb = next_valid(blockIdx.x);
+  if (vb >= total_vb) return;
 
   // loader: slot s = i * NT + tid of a stage holds (row s / 8, chunk s % 8); the chunk index is
   // XOR-swizzled with (row & 7) on the SOURCE side (LDS-DMA writes lane-linear) so that the 16
   // rows of one ds_read_b128 fragment read cover all 64 banks
   // per-thread source offsets from the tile's (wave-uniform) base: 32 bits each
-  const unsigned char* baseA = (const unsigned char*)a.v + row0 * pitch;
-  const unsigned char* baseB = (const unsigned char*)a.qb + (size_t)q0 * pitch;
+  uint64_t row0 = 0;
+  uint32_t q0 = 0;
+  const unsigned char* baseA = nullptr;
+  const unsigned char* baseB = nullptr;
   uint32_t oA[SA], oB[SB];
+  auto set_tile = [&]() {  // from rt / qt
+    row0 = (uint64_t)rt * BM;
+    q0 = qt * BN;
+    baseA = (const unsigned char*)a.v + row0 * pitch;
+    baseB = (const unsigned char*)a.qb + (size_t)q0 * pitch;
 #pragma unroll
-  for (int i = 0; i < SA; ++i) {
-    const uint32_t s = i * NT + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
-    uint64_t vr = row0 + r;
-    if (vr >= a.n_rows) vr = a.n_rows - 1;  // clamped; masked in the epilogue
-    oA[i] = (uint32_t)((vr - row0) * pitch) + (c ^ (r & 7u)) * 16u;
-  }
+    for (int i = 0; i < SA; ++i) {
+      const uint32_t s = i * NT + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
+      uint64_t vr = row0 + r;
+      if (vr >= a.n_rows) vr = a.n_rows - 1;  // clamped; masked in the epilogue
+      oA[i] = (uint32_t)((vr - row0) * pitch) + (c ^ (r & 7u)) * 16u;
+    }
 #pragma unroll
-  for (int i = 0; i < SB; ++i) {
-    const uint32_t s = i * NT + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
-    oB[i] = (uint32_t)(r * pitch) + (c ^ (r & 7u)) * 16u;
-  }
+    for (int i = 0; i < SB; ++i) {
+      const uint32_t s = i * NT + tid, r = s / FG_CHUNKS, c = s % FG_CHUNKS;
+      oB[i] = (uint32_t)(r * pitch) + (c ^ (r & 7u)) * 16u;
+    }
+  };
+  set_tile();
   auto stage = [&](uint32_t kt, uint32_t buf) {
     unsigned char* sA = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* sB = sA + A_BYTES;
@@ -207,10 +227,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
   };
 
   fg_f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = fg_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses (bytes inside a stage): row*128 + ((chunk ^ (row&7)) << 4)
   const uint32_t fr = lane & 15, fk = lane >> 4;
@@ -256,89 +272,131 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
     }
     __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
   };
-  if constexpr (STAGES == 2) {
-    // two stages, two barriers per k-step
-    stage(0, 0);
-    for (uint32_t kt = 0; kt < KT; ++kt) {
-      const uint32_t buf = kt & 1u;
-      if (kt + 1 < KT) {
+  uint32_t p0 = 0;  // LDS buffer of the current tile's k-tile 0 (two-stage schedule)
+  if constexpr (STAGES == 2) stage(0, 0);
+  while (true) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = fg_f32x4{0.f, 0.f, 0.f, 0.f};
+    // the tile the epilogue below belongs to (set_tile() moves on to the next one before it runs)
+    const uint64_t e_row0 = row0;
+    const uint32_t e_q0 = q0, e_rt = rt;
+    const uint32_t nvb = next_valid(vb + gridDim.x);  // sets rt / qt of the next tile
+    const bool has_next = nvb < total_vb;
+    if constexpr (STAGES == 2) {
+      // two stages, two barriers per k-step
+      for (uint32_t kt = 0; kt + 1 < KT; ++kt) {
+        const uint32_t buf = (p0 + kt) & 1u;
         stage(kt + 1, buf ^ 1u);
         // this stage's DMAs have landed, the next stage's SA + SB fly on
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        compute(buf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
       }
-      __builtin_amdgcn_s_barrier();
-      compute(buf);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
-    }
-  } else {
-    // three stages, ONE barrier per k-step: stage kt+2 is issued after the barrier of step kt,
-    // i.e. when every wave has finished reading the buffer it overwrites (that of step kt-1)
-    stage(0, 0);
-    if (KT > 1) stage(1, 1);
-    uint32_t buf = 0;
-    for (uint32_t kt = 0; kt < KT; ++kt) {
-      if (kt + 1 < KT)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");  // stage kt landed, stage kt+1 may fly
-      else
+      {
+        const uint32_t buf = (p0 + KT - 1) & 1u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 2 < KT) stage(kt + 2, buf == 0 ? 2 : buf - 1);
-      compute(buf);
-      buf = buf == 2 ? 0 : buf + 1;
-    }
-  }
-
-  // ---- epilogue: lo = approx - eps, minimum per 32-row group ------------------
-  // D layout (16x16): col = lane & 15 -> query, row = (lane >> 4) * 4 + reg -> row of V
-  float qa[NI], qg[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const uint32_t n = q0 + wc * NI * 16 + ni * 16 + fr;
-    qa[ni] = a.qa[n];
-    qg[ni] = a.qg[n];
-  }
-#pragma unroll
-  for (int g = 0; g < MI / 2; ++g) {  // the wave's groups of 32 rows (two MFMA row tiles each)
-    float gmin[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) gmin[ni] = __builtin_huge_valf();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int mi = g * 2 + h;
-      const uint64_t r0 = row0 + wr * MI * 16 + mi * 16 + fk * 4;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const uint64_t r = r0 + reg;
-        if (r >= a.n_rows) continue;
-        const float vv = a.vv[r];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const float s = acc[mi][ni][reg];
-          float lo;
-          if (METRIC == MI355_METRIC_L2)
-            lo = qa[ni] + a.omc * vv + qg[ni] * s;             // (1-c)(qq + vv) - 2 s
-          else if (METRIC == MI355_METRIC_COSINE)
-            lo = qa[ni] + qg[ni] * s * (1.0f / sqrtf(vv));     // (1-2c) - s / (|q||v|)
-          else
-            lo = qa[ni] - s - qg[ni] * sqrtf(vv);              // 1 - s - 1.01 c |q||v|
-          // non-finite scores (overflow, NaN inputs) must never be filtered out here:
-          // the exact re-rank decides what they are
-          if (!(fabsf(lo) < __builtin_huge_valf())) lo = -__builtin_huge_valf();
-          gmin[ni] = fminf(gmin[ni], lo);
+        __builtin_amdgcn_s_barrier();
+        if (has_next) {
+          // the other buffer was last read in step KT-2, behind that step's closing barrier:
+          // the next tile's first stage flies under this step's MFMAs and the epilogue
+          set_tile();
+          stage(0, buf ^ 1u);
         }
+        compute(buf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
+      p0 = (p0 + KT) & 1u;
+    } else {
+      // three stages, ONE barrier per k-step: stage kt+2 is issued after the barrier of step kt,
+      // i.e. when every wave has finished reading the buffer it overwrites (that of step kt-1)
+      stage(0, 0);
+      if (KT > 1) stage(1, 1);
+      uint32_t buf = 0;
+      for (uint32_t kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");  // stage kt landed, stage kt+1 may fly
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < KT) stage(kt + 2, buf == 0 ? 2 : buf - 1);
+        compute(buf);
+        buf = buf == 2 ? 0 : buf + 1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // the next tile's stage(0) overwrites buffer 0
+      if (has_next) set_tile();
     }
-    const uint32_t grp = rt * (BM / 32) + wr * (MI / 2) + g;
+
+    // ---- epilogue: lo = approx - eps, minimum per 32-row group ------------------
+    // D layout (16x16): col = lane & 15 -> query, row = (lane >> 4) * 4 + reg -> row of V
+    float qa[NI], qg[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      float v = gmin[ni];
-      v = fminf(v, __shfl_xor(v, 16));
-      v = fminf(v, __shfl_xor(v, 32));
-      if (fk == 0) a.gm[(size_t)grp * a.nq_pad + q0 + wc * NI * 16 + ni * 16 + fr] = v;
+      const uint32_t n = e_q0 + wc * NI * 16 + ni * 16 + fr;
+      qa[ni] = a.qa[n];
+      qg[ni] = a.qg[n];
+    }
+    // the rows' terms: one 16-B load per MFMA row tile, all issued before the first use (vv is
+    // padded to whole tiles; one load per row behind its bounds check cost an L2 round trip each)
+    float4 vv4[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      vv4[mi] = *(const float4*)(a.vv + e_row0 + wr * MI * 16 + mi * 16 + fk * 4);
+#pragma unroll
+    for (int g = 0; g < MI / 2; ++g) {  // the wave's groups of 32 rows (two MFMA row tiles each)
+      // gmin: minimum over the group's finite-or-infinite scores; chk turns NaN as soon as one
+      // score is NaN or +-inf (x * 0 is NaN exactly for those): such a group must never be
+      // filtered out - the exact re-rank decides what its rows are
+      float gmin[NI], chk[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        gmin[ni] = __builtin_huge_valf();
+        chk[ni] = 0.f;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int mi = g * 2 + h;
+        const uint64_t r0 = e_row0 + wr * MI * 16 + mi * 16 + fk * 4;
+        const float vvr[4] = {vv4[mi].x, vv4[mi].y, vv4[mi].z, vv4[mi].w};
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const bool live = r0 + reg < a.n_rows;  // rows past the column: no score
+          const float vv = vvr[reg];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const float s = acc[mi][ni][reg];
+            float lo;
+            if (METRIC == MI355_METRIC_L2)
+              lo = qa[ni] + a.omc * vv + qg[ni] * s;             // (1-c)(qq + vv) - 2 s
+            else if (METRIC == MI355_METRIC_COSINE)
+              lo = qa[ni] + qg[ni] * s * (1.0f / sqrtf(vv));     // (1-2c) - s / (|q||v|)
+            else
+              lo = qa[ni] - s - qg[ni] * sqrtf(vv);              // 1 - s - 1.01 c |q||v|
+            lo = live ? lo : __builtin_huge_valf();
+            gmin[ni] = fminf(gmin[ni], lo);
+            chk[ni] = __fmaf_rn(live ? lo : 0.f, 0.f, chk[ni]);
+          }
+        }
+      }
+      const uint32_t grp = e_rt * (BM / 32) + wr * (MI / 2) + g;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        float v = chk[ni] == chk[ni] ? gmin[ni] : -__builtin_huge_valf();
+        v = fminf(v, __shfl_xor(v, 16));
+        v = fminf(v, __shfl_xor(v, 32));
+        if (fk == 0) a.gm[(size_t)grp * a.nq_pad + e_q0 + wc * NI * 16 + ni * 16 + fr] = v;
+      }
+    }
+    if (!has_next) break;
+    vb = nvb;
+    if constexpr (STAGES != 2) {
+      // nothing in flight: the loop head stages the next tile from scratch
     }
   }
 }

@@ -1597,8 +1597,12 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
         s = f->shadow.ensure((size_t)d->n_rows * f->dimp * 2);
         if (s) return bail(s);
       }
-      s = f->vv.ensure(sizeof(float) * d->n_rows);
+      // padded to whole 256-row tiles (tail = 0): the GEMM epilogue loads its tile's terms unconditionally
+      const size_t vv_rows = (d->n_rows + 255) / 256 * 256;
+      s = f->vv.ensure(sizeof(float) * vv_rows);
       if (s) return bail(s);
+      if (hipMemsetAsync(f->vv.as<float>() + d->n_rows, 0, sizeof(float) * (vv_rows - d->n_rows), f->stream) != hipSuccess)
+        return bail(fail(MI355_ERR_RUNTIME, "memset failed"));
       s = f->vmax.ensure(64);
       if (s) return bail(s);
       if (hipMemsetAsync(f->vmax.p, 0, 64, f->stream) != hipSuccess) return bail(fail(MI355_ERR_RUNTIME, "memset failed"));
@@ -1697,7 +1701,20 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ga.n_rtiles = n_rtiles;
     ga.omc = 1.f - f->c_err;
     ga.gm = f->g_gm.as<float>();
-    const uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;
+    uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;  // one per (row tile, query tile)
+    // persistent grid: one workgroup per CU slot walks its XCD's tiles and overlaps the next tile's
+    // first stage with the current tile's last k-step and epilogue.  MI355_FLAT_PERSIST: 0 = one
+    // workgroup per tile, 1 = default, N >= 8 = a grid of N workgroups (dev / tests: forces the
+    // cross-tile path on small columns)
+    if (const uint32_t persist = env_u32("MI355_FLAT_PERSIST", 1)) {
+      uint32_t slots = persist / 8 * 8;
+      if (persist < 8) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, f->device));
+        slots = (uint32_t)std::max(cus, 8) / 8 * 8 * ((big || tri) ? 1u : 2u);
+      }
+      gemm_blocks = std::min(gemm_blocks, slots);
+    }
     const size_t gemm_lds = (size_t)(tri ? 3 : 2) * (BM + BN) * FG_BK * 2;
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \

@@ -480,3 +480,26 @@ def test_c5_config_shape_1536d_cosine_refine10(oracle, raw_dtype):
     q = rng.normal(size=(24, dim)).astype(np.float32)
     for kw in (dict(k=10, nprobe_min=64, nprobe_max=64, refine_factor=10), dict(k=10, nprobe_min=64, nprobe_max=64)):
         _assert_same(g.search(q, **kw), o.search(q, **kw))
+
+
+@pytest.mark.parametrize("tile", ["128", "256", "3"])
+def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, monkeypatch, tile):
+    """A grid of 8 workgroups (one per XCD) walks every tile of the column: the cross-tile
+    path of the flat GEMM (next tile's first stage issued under the last k-step, ragged last
+    row tile, virtual blocks that map to no row tile) against the exact sweep."""
+    monkeypatch.setenv("MI355_FLAT_PERSIST", "8")
+    monkeypatch.setenv("MI355_FLAT_TILE", tile)
+    rng = np.random.default_rng(99)
+    n, dim = 9000 + 37, 136  # 36 row tiles of 256 (last one ragged), dim padded to 192 -> 3 k-tiles
+    v = rng.normal(size=(n, dim)).astype(np.float32)
+    q = rng.normal(size=(300, dim)).astype(np.float32)  # 2 query tiles of 256 / 3 of 128
+    f = lancedb_amd.FlatIndex(v)
+    for metric in ("l2", "cosine", "dot"):
+        mt = _abi.METRIC_NAMES[metric]
+        _assert_same(f.search(q, k=10, metric=mt), oracle.flat_search(v, q, k=10, metric=mt))
+        assert f.info()[0] == 1
+    # a single k-tile per row tile (dim <= 64): the first stage of the next tile is the only stage
+    v1, q1 = np.ascontiguousarray(v[:, :40]), np.ascontiguousarray(q[:, :40])
+    f1 = lancedb_amd.FlatIndex(v1)
+    _assert_same(f1.search(q1, k=5), oracle.flat_search(v1, q1, k=5))
+    assert f1.info()[0] == 1

@@ -1,6 +1,6 @@
 """Throughput of mi355_ivfpq_encode (index population) at the C3 index shape
 (dim 768, nlist 4096, m 96) on device-resident rows, with the CPU oracle
-(OpenMP, all host cores) timed on a sample.  python -u scripts/bench_encode.py [rows]"""
+(OpenMP, all host cores) timed on a sample.  python -u tests/tools/bench_encode.py [rows]"""
 import json
 import sys
 import time

@@ -1,0 +1,97 @@
+"""Host logic of lancedb_amd/build.py (the mirror of the reference's IvfPqIndexBuilder,
+rust/lancedb/src/index/vector.rs:61-119, :306-319) on a CPU-only box: the three device
+entry points are stood in for by the CPU oracle (test infrastructure; the GPU runs of the
+same builder are in tests/test_gpu_train.py), so what is under test is the sampling, the
+seeding, the shapes handed to the C ABI and the quality of the resulting index."""
+import numpy as np
+import pytest
+
+import lancedb_amd
+from lancedb_amd import _abi
+from lancedb_amd import build as build_mod
+
+
+@pytest.fixture()
+def oracle_backend(oracle, monkeypatch):
+    calls = []
+
+    def kmeans_train(vectors, init, metric="l2", iters=50, cols=None, device=0):
+        calls.append(("kmeans", vectors.shape, init.shape, metric, iters, cols))
+        return oracle.kmeans_train(vectors, init, metric, iters, cols=cols)
+
+    def ivf_residuals(vectors, centroids, metric="l2", device=0):
+        calls.append(("residuals", vectors.shape, centroids.shape, metric))
+        return oracle.ivf_residuals(vectors, centroids, metric)
+
+    def ivfpq_encode(vectors, centroids, codebook, metric="l2", device=0, return_assign=False):
+        calls.append(("encode", vectors.shape, metric))
+        po, codes, order, assign = oracle.ivfpq_encode(vectors, centroids, codebook, metric)
+        return (po, codes, order, assign) if return_assign else (po, codes, order)
+
+    monkeypatch.setattr(build_mod, "kmeans_train", kmeans_train)
+    monkeypatch.setattr(build_mod, "ivf_residuals", ivf_residuals)
+    monkeypatch.setattr(build_mod, "ivfpq_encode", ivfpq_encode)
+    return calls
+
+
+def _data(n=6000, dim=32, nc=24, seed=3):
+    rng = np.random.default_rng(seed)
+    cent = rng.normal(size=(nc, dim)).astype(np.float32) * 3
+    return (cent[rng.integers(0, nc, size=n)] + rng.normal(size=(n, dim))).astype(np.float32)
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_train_calls_and_shapes(oracle_backend, metric):
+    x = _data()
+    b = lancedb_amd.IvfPqBuilder(distance_type=metric, num_partitions=16, num_sub_vectors=8, sample_rate=8,
+                                 max_iterations=3, seed=5)
+    cent, cb = b.train(x)
+    assert cent.shape == (16, 32) and cb.shape == (8, 256, 4) and cent.dtype == cb.dtype == np.float32
+    kinds = [c[0] for c in oracle_backend]
+    assert kinds == ["kmeans", "residuals"] + ["kmeans"] * 8
+    # IVF: sample_rate * num_partitions rows; PQ: sample_rate * 256 rows, one sub-vector range per call
+    assert oracle_backend[0][1] == (8 * 16, 32) and oracle_backend[0][2] == (16, 32) and oracle_backend[0][4] == 3
+    assert oracle_backend[1][1] == (8 * 256, 32)
+    assert [c[5] for c in oracle_backend[2:]] == [(4 * j, 4 * j + 4) for j in range(8)]
+    assert all(c[2] == (256, 4) for c in oracle_backend[2:])
+    # the sub-quantisers of l2 / cosine indexes are plain l2 k-means on residuals
+    assert {c[3] for c in oracle_backend[2:]} == {"dot" if metric == "dot" else "l2"}
+    if metric == "cosine":  # seeded with unit rows
+        assert np.isfinite(cent).all()
+    # same seed -> same index; another seed -> another sample
+    cent2, cb2 = lancedb_amd.IvfPqBuilder(distance_type=metric, num_partitions=16, num_sub_vectors=8, sample_rate=8,
+                                          max_iterations=3, seed=5).train(x)
+    assert (cent2 == cent).all() and (cb2 == cb).all()
+    cent3, _ = lancedb_amd.IvfPqBuilder(distance_type=metric, num_partitions=16, num_sub_vectors=8, sample_rate=8,
+                                        max_iterations=3, seed=6).train(x)
+    assert not (cent3 == cent).all()
+
+
+def test_defaults_and_errors(oracle_backend):
+    x = _data(n=3000, dim=16)
+    b = lancedb_amd.IvfPqBuilder(max_iterations=2, sample_rate=4)
+    cent, cb = b.train(x)
+    assert cent.shape == (int(np.sqrt(3000)), 16)       # num_partitions = sqrt(rows)
+    assert cb.shape == (1, 256, 16)                     # 16 % 16 == 0 -> dim / 16 sub-vectors
+    with pytest.raises(ValueError, match="does not divide"):
+        lancedb_amd.IvfPqBuilder(num_partitions=4, num_sub_vectors=5).train(x)
+    with pytest.raises(ValueError, match="not enough rows"):
+        lancedb_amd.IvfPqBuilder(num_partitions=4).train(x[:100])
+
+
+def test_built_index_is_searchable_and_accurate(oracle, oracle_backend):
+    """The arrays the builder produces open as an index whose refined top-10 matches exact search."""
+    x = _data(n=8000, dim=32, nc=32, seed=11)
+    b = lancedb_amd.IvfPqBuilder(num_partitions=32, num_sub_vectors=8, sample_rate=16, max_iterations=6)
+    cent, cb = b.train(x)
+    po, codes, order = build_mod.ivfpq_encode(x, cent, cb, metric="l2")
+    order = order.astype(np.int64)
+    assert sorted(order.tolist()) == list(range(8000)) and int(po[-1]) == 8000
+    ox = oracle.OracleIndex(cent, cb, po, codes, order.astype(np.uint64), raw_vectors=x[order])
+    q = x[:40] + np.float32(0.01)
+    ids, _, cnt, st = ox.search(q, k=10, nprobe_min=8, nprobe_max=8, refine_factor=10)
+    truth = oracle.flat_search(x, q, k=10, metric=_abi.METRIC_L2)[0]
+    assert st == 0 and (cnt == 10).all()
+    recall = np.mean([len(set(ids[i].tolist()) & set(truth[i].tolist())) / 10 for i in range(40)])
+    assert recall > 0.9, recall
+    assert (ids[:, 0] == np.arange(40)).all()  # every query's own row comes back first

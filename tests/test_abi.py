@@ -163,3 +163,27 @@ def test_builder_parameter_defaults_follow_the_reference():
     assert (b.sample_rate, b.max_iterations, b.distance_type) == (256, 50, "l2")
     with pytest.raises(ValueError):
         b.train(np.zeros((10, 16), np.float32))
+
+
+def test_flat_gemm_tile_walk_visits_every_tile_once():
+    """Model of k_flat_gemm's virtual-block walk (csrc/kernels_flat_mfma.h: vb = blockIdx.x +
+    i * gridDim.x; xcd = vb & 7, slot = vb >> 3, qt = slot % n_qtiles, rt = (slot / n_qtiles) * 8
+    + xcd; virtual blocks with rt >= n_rtiles are skipped): for any grid that is a multiple of 8
+    every (row tile, query tile) is visited exactly once, by a workgroup whose blockIdx % 8 is the
+    tile's XCD label, and the query tiles of one row tile are adjacent slots on that XCD."""
+    for n_rtiles, n_qtiles in ((1, 1), (7, 3), (8, 4), (36, 2), (61, 5), (200, 8)):
+        total_vb = (n_rtiles + 7) // 8 * 8 * n_qtiles
+        for grid in (8, 16, 64, 256, total_vb):
+            grid = min(grid, total_vb)
+            seen = {}
+            for b in range(grid):
+                vb = b
+                while vb < total_vb:
+                    slot = vb >> 3
+                    qt, rt = slot % n_qtiles, (slot // n_qtiles) * 8 + (vb & 7)
+                    if rt < n_rtiles:
+                        assert (rt, qt) not in seen
+                        seen[(rt, qt)] = b
+                        assert b % 8 == rt % 8
+                    vb += grid
+            assert len(seen) == n_rtiles * n_qtiles

@@ -121,7 +121,8 @@ def main_flat(a):
                    "batch_queries": B, "k": k},
         "roofline": {"bound": "mfma", "kernel": "whole step (k_flat_gemm dominates; + segmin/tau/compact/rerank)",
                      "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-                     "traffic": None, "algorithmic_flops_per_step": flops},
+                     "traffic": traffic_from_profiles(f"flat_{n}x{dim}_bf16_batch{B}_k{k}_{a.flat_metric}", B),
+                     "algorithmic_flops_per_step": flops},
     }
     if a.cpu_seconds > 0:
         from oracle import oracle as orc
@@ -366,7 +367,9 @@ def traffic_from_profiles(workload, batch):
     MI355X_MICROARCH.md); null when no matching measurement is committed."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+    paths = glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")) + \
+        glob.glob(os.path.join(ROOT, "profiles", "*fetch_size*.json"))
+    for path in sorted(paths):
         try:
             t = json.load(open(path))
         except (OSError, ValueError):

@@ -23,6 +23,7 @@
 #include "../../include/mi355_ann.h"
 #include "kernels_flat.h"
 #include "kernels_flat_mfma.h"
+#include "kernels_flat_mfma8.h"
 #include "kernels_ivfpq.h"
 #include "kernels_skew.h"
 #include "kernels_encode.h"
@@ -1641,8 +1642,9 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
                              const RangeFilter& range, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt) {
   hipStream_t st = f->stream;
   // tile shape: 256 x 256 (8 waves) for real batches, 128 x 128 (4 waves, 2 workgroups per CU) for small ones
-  const uint32_t tile = nq > 128 ? env_u32("MI355_FLAT_TILE", 256) : 128;  // dev knob: 128, 256, 3 (= 256 x 128, 3 stages)
-  const bool big = tile == 256, tri = tile == 3;
+  const uint32_t tile = nq > 128 ? env_u32("MI355_FLAT_TILE", 256) : 128;  // dev knob: 128, 256, 3 (= 256 x 128, 3 stages), 8 (experimental 8-phase)
+  const bool oct = tile == 8;  // dev: EXPERIMENTAL 8-phase schedule (kernels_flat_mfma8.h), not validated on hardware
+  const bool big = tile == 256 || oct, tri = tile == 3;
   const uint32_t BM = (big || tri) ? 256 : 128, BN = big ? 256 : 128;
   const uint32_t n_rtiles = (uint32_t)((f->n_rows + BM - 1) / BM);
   const uint32_t n_groups = n_rtiles * (BM / FG_GROUP);
@@ -1706,7 +1708,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     // first stage with the current tile's last k-step and epilogue.  MI355_FLAT_PERSIST: 0 = one
     // workgroup per tile, 1 = default, N >= 8 = a grid of N workgroups (dev / tests: forces the
     // cross-tile path on small columns)
-    if (const uint32_t persist = env_u32("MI355_FLAT_PERSIST", 1)) {
+    if (const uint32_t persist = oct ? 0u : env_u32("MI355_FLAT_PERSIST", 1)) {
       uint32_t slots = persist / 8 * 8;
       if (persist < 8) {
         int cus = 0;
@@ -1720,6 +1722,11 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
   {                                                                                                 \
     if (tri) {                                                                                      \
       auto kern = k_flat_gemm<MET, 4, 2, 4, 4, 3>;                                                  \
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)gemm_lds));                                                  \
+      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
+    } else if (oct) {                                                                               \
+      auto kern = k_flat_gemm8<MET>;                                                                \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \

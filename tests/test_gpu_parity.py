@@ -503,3 +503,22 @@ def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, monkeypatch, ti
     f1 = lancedb_amd.FlatIndex(v1)
     _assert_same(f1.search(q1, k=5), oracle.flat_search(v1, q1, k=5))
     assert f1.info()[0] == 1
+
+
+@pytest.mark.skipif(__import__("os").environ.get("MI355_TEST_EXPERIMENTAL") != "1",
+                    reason="experimental 8-phase flat GEMM (csrc/kernels_flat_mfma8.h): opt in with MI355_TEST_EXPERIMENTAL=1")
+def test_flat_mfma_eight_phase_schedule_experimental(oracle, monkeypatch):
+    """Screen of the not-yet-validated 8-phase schedule (MI355_FLAT_TILE=8) against the exact
+    sweep: ragged last row tile, 1 / 2 / 3 / 12 k-tiles, three metrics.  Follow with
+    scripts/ab_flat.sh (group-minimum checksum must equal the other tiles')."""
+    monkeypatch.setenv("MI355_FLAT_TILE", "8")
+    rng = np.random.default_rng(123)
+    for n, dim in ((9000 + 37, 40), (9000 + 37, 100), (5000, 136), (6000, 768)):
+        v = rng.normal(size=(n, dim)).astype(np.float32)
+        q = rng.normal(size=(300, dim)).astype(np.float32)
+        f = lancedb_amd.FlatIndex(v)
+        for metric in ("l2", "cosine", "dot"):
+            mt = _abi.METRIC_NAMES[metric]
+            for _ in range(3):  # repeated: a race would come and go
+                _assert_same(f.search(q, k=10, metric=mt), oracle.flat_search(v, q, k=10, metric=mt))
+            assert f.info()[0] == 1

@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--flat-rows", type=int, default=10_000_000)
     ap.add_argument("--flat-batch", type=int, default=1024)
     ap.add_argument("--flat-metric", default="l2", choices=["l2", "cosine", "dot"])
+    ap.add_argument("--flat-gemm", type=int, default=0, help="mi355_flat_configure gemm_variant (0 = the library's choice)")
+    ap.add_argument("--flat-grid", type=int, default=0, help="mi355_flat_configure grid_workgroups")
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--slice-rows", type=int, default=0)
     return ap.parse_args()
@@ -93,6 +95,7 @@ def main_flat(a):
     fl = lancedb_amd.FlatIndex(col.view(torch.int16), dtype=_abi.DTYPE_BF16, device=0)
     stream = torch.cuda.current_stream().cuda_stream
     fl.set_stream(stream)
+    fl.configure(gemm_variant=a.flat_gemm, grid_workgroups=a.flat_grid)
     mt = _abi.METRIC_NAMES[a.flat_metric]
     params = _abi.make_params(k=k, nprobe_min=1, nprobe_max=1, metric=mt)
     out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
@@ -214,11 +217,19 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ix.set_stream(stream)  # engine kernels, RCCL and torch share one ordered stream
     ix.configure(scan_variant=a.scan_variant, slice_rows=a.slice_rows, profile=0)
-    from lancedb_amd.distributed import ShardedSearcher
-    searcher = ShardedSearcher(ix, stream=stream)  # all-gather of [B,k] candidates + k-way merge when world > 1
+    comm = searcher = None
+    if world > 1:
+        # the exchange is RCCL behind the C ABI (mi355_comm_* / mi355_search_sharded: one packed
+        # all-gather of the per-shard candidate records on the search stream + a k-way merge on every
+        # rank); torch.distributed only carries the 128-byte communicator id to the other ranks
+        from lancedb_amd.distributed import Comm, ShardedSearcher, unique_id
+        uid = [unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = Comm(uid[0], rank, world, device=local_rank)
+        searcher = ShardedSearcher(ix, comm)
 
     def step(i):
-        r = searcher.search(qpool[i % P], params, out=out)
+        r = searcher.search(qpool[i % P], params, out=out) if searcher else ix.search(qpool[i % P], params, out=out)
         return r.rowids, r.distances, r.counts
 
     def fence():

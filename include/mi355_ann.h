@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MI355_ANN_ABI_VERSION 2u
+#define MI355_ANN_ABI_VERSION 3u
 
 /* ---- status codes (rust/lancedb/src/error.rs:55-145) -------------------- */
 enum {
@@ -71,13 +71,38 @@ enum {
   MI355_DTYPE_F16 = 2
 };
 
+/* ApproxMode (rust/lancedb/src/lib.rs:298-313; VectorQueryRequest.approx_mode,
+   query.rs:1092, forwarded at table/query.rs:241-242).  "This currently only affects
+   RQ-quantized vector indexes ... Other index types ignore this setting": carried,
+   validated and ignored by the IVF-PQ / flat paths. */
+enum {
+  MI355_APPROX_UNSET = 0, /* approx_mode = None */
+  MI355_APPROX_FAST = 1,
+  MI355_APPROX_NORMAL = 2, /* the reference's default */
+  MI355_APPROX_ACCURATE = 3
+};
+
+/* mi355_index_desc.flags */
+enum {
+  /* keep the generic [sub-quantiser][rows] code layout (k_scan_pair) even when the
+     pre-skewed production layout is available for this m */
+  MI355_INDEX_GENERIC_SCAN = 1u,
+  /* raw_vectors stay in the CALLER's host memory (which must outlive the handle): the
+     library page-locks the range and the refine kernel gathers the k*refine_factor
+     candidate rows over PCIe (zero copy).  For columns that do not fit HBM (C5:
+     100 M x 1536).  Requires mem == MI355_MEM_HOST. */
+  MI355_INDEX_RAW_HOST_MAPPED = 2u
+};
+
 /* layout of the PQ code block handed to mi355_index_open */
 enum {
-  /* [n_rows, m] u8, rows ordered by partition (partition p = rows
-     part_offsets[p] .. part_offsets[p+1]) */
+  /* [n_rows, mb] u8, rows ordered by partition (partition p = rows
+     part_offsets[p] .. part_offsets[p+1]); mb = m * nbits / 8 code bytes per row.
+     4-bit codes: byte t of a row holds sub-quantiser 2t in its LOW nibble and 2t+1 in
+     its HIGH nibble ([EXT] assumption, the common packing) */
   MI355_CODES_ROW_MAJOR = 0,
-  /* per partition a [m, len_p] u8 block (sub-quantiser major), partitions
-     concatenated at byte offset m * part_offsets[p]: the transposed storage
+  /* per partition a [mb, len_p] u8 block (sub-quantiser major), partitions
+     concatenated at byte offset mb * part_offsets[p]: the transposed storage
      lance-index keeps per partition ([EXT]) */
   MI355_CODES_PART_TRANSPOSED = 1
 };
@@ -96,7 +121,7 @@ typedef struct mi355_index_desc {
   uint32_t dim;         /* vector dimension */
   uint32_t nlist;       /* IVF partitions (num_partitions) */
   uint32_t m;           /* PQ sub-vectors (num_sub_vectors); dim % m == 0 */
-  uint32_t nbits;       /* PQ bits; 8 supported (4 -> NOT_SUPPORTED) */
+  uint32_t nbits;       /* PQ bits: 8, or 4 with even m (table/create_index.rs:96-101) */
   uint32_t metric;      /* MI355_METRIC_* the index was trained with */
   uint64_t n_rows;      /* rows covered by the index */
   uint32_t mem;         /* MI355_MEM_*: where the pointers below live */
@@ -118,6 +143,8 @@ typedef struct mi355_index_desc {
      sharding. */
   uint32_t shard_count;
   uint32_t shard_rank;
+  uint32_t flags;               /* MI355_INDEX_* */
+  uint32_t reserved;
 } mi355_index_desc;
 
 /*
@@ -139,7 +166,11 @@ typedef struct mi355_search_params {
   uint32_t io_mem;        /* MI355_MEM_*: where queries / outputs live.  DEVICE
                              = enqueue on the handle's stream and return
                              without waiting (see mi355_*_set_stream) */
-  uint32_t timeout_ms;    /* 0 = none (QueryExecutionOptions.timeout, query.rs:641) */
+  uint32_t timeout_ms;    /* 0 = none (QueryExecutionOptions.timeout, query.rs:641).  A device-side
+                             deadline: the scan kernels stop taking work items once it has passed and
+                             every later kernel of the call exits at once; host-I/O calls then return
+                             MI355_ERR_TIMEOUT, device-I/O calls report it through mi355_last_stats
+                             (timed_out) / mi355_index_sync.  Results of a timed-out call are undefined. */
   /* Prefilter (QueryRequest.filter with prefilter = true, the reference's default:
      rust/lancedb/src/query.rs:489-507, :899; table/query.rs:251-262): the rows a
      filter kept or dropped, as the caller's evaluation of the predicate, in the
@@ -147,7 +178,7 @@ typedef struct mi355_search_params {
      `filter_rowids` is sorted ascending, lives where io_mem says, and is applied
      BEFORE the top-k: the result is the k nearest among the permitted rows. */
   uint32_t filter_mode;   /* MI355_FILTER_* */
-  uint32_t reserved0;
+  uint32_t approx_mode;   /* MI355_APPROX_* (ignored by IVF-PQ / flat, see the enum) */
   const uint64_t *filter_rowids; /* [n_filter] sorted ascending, unique */
   uint64_t n_filter;
 } mi355_search_params;
@@ -187,6 +218,11 @@ typedef struct mi355_stats {
   float us_total;
   uint32_t scan_variant;       /* which ADC kernel ran (MI355_SCAN_*) */
   uint32_t scan_launches;      /* timed launch sequences folded into us_* */
+  uint32_t timed_out;          /* 1 = the device-side deadline of timeout_ms stopped the last call */
+  uint32_t bad_probes;         /* mi355_search_probes: probe ids that are not partitions of this
+                                  index (they are skipped; host-I/O calls also fail with InvalidInput) */
+  uint32_t coalesced_calls;    /* concurrent host-I/O mi355_search calls served by the last device batch */
+  uint32_t graph_replays;      /* searches of this handle served by a cached hipGraph so far */
   uint32_t reserved;
 } mi355_stats;
 
@@ -196,7 +232,18 @@ enum {
                             [sub-quantiser][code] table, any m */
   MI355_SCAN_SKEW = 2    /* production: pre-skewed code streams + [code][column]
                             table (bank-conflict-free gathers), partition-major
-                            work queues per XCD; m in {32,48,64,80,96} */
+                            work queues per XCD; 8-bit codes, m in {32,48,64,80,96} */
+};
+
+/* mi355_index_configure `profile` bits above the low byte */
+enum {
+  MI355_PROFILE_MASK = 0xFFu,
+  /* capture the launch sequence of small host-I/O batches (<= 64 queries) in a hipGraph,
+     cached per (batch size, k, refine, nprobe, range / filter shape) */
+  MI355_CFG_GRAPH = 0x100u,
+  /* serve concurrent host-I/O mi355_search calls whose parameters agree from ONE device
+     batch (leader / follower hand-off inside the handle, no extra thread) */
+  MI355_CFG_COALESCE = 0x200u
 };
 
 /* ---- library ------------------------------------------------------------ */
@@ -217,10 +264,13 @@ int32_t mi355_index_sync(mi355_index *index);
 /* tuning knobs: MI355_SCAN_* variant (AUTO = the one the index layout was
    packed for at open; a mismatching explicit choice is INVALID_INPUT), slice
    length (rows per scan work item of the generic kernel, 0 = default) and
-   profiling: 0 = counters only, 1 = also per-stage device
+   profiling (low byte of `profile`): 0 = counters only, 1 = also per-stage device
    times of the LAST search, 2 = counters and times ACCUMULATE over searches
    until the next configure().  Times come from hipEvents recorded on the search
-   stream with no host synchronisation; they are read back by mi355_last_stats. */
+   stream with no host synchronisation; they are read back by mi355_last_stats.
+   Higher bits: MI355_CFG_GRAPH / MI355_CFG_COALESCE (latency / concurrency modes,
+   host-I/O calls only; both are ON after mi355_index_open, a configure() call sets
+   them as given). */
 int32_t mi355_index_configure(mi355_index *index, uint32_t scan_variant,
                               uint32_t slice_rows, uint32_t profile);
 /* rows kept on this handle and how many partitions are non-empty here */
@@ -278,6 +328,26 @@ int32_t mi355_flat_search(mi355_flat *flat, const float *queries,
                           uint64_t *out_rowids, float *out_dist,
                           uint32_t *out_counts);
 
+/* Tuning of the flat GEMM filter.  gemm_variant: MI355_FLAT_GEMM_* (AUTO = the library's
+   choice per batch size).  grid_workgroups: 0 = one persistent workgroup per CU slot,
+   1 = one workgroup per tile, N >= 8 = a persistent grid of N / 8 * 8 workgroups.
+   flags: MI355_FLAT_CHECKSUM = after every GEMM launch synchronise and keep an
+   order-independent checksum of the group-minimum matrix (mi355_flat_checksum; used to
+   compare schedules bit for bit). */
+enum {
+  MI355_FLAT_GEMM_AUTO = 0,
+  MI355_FLAT_GEMM_128 = 1,       /* 128 x 128 tile, 4 waves, two barriers per k-step */
+  MI355_FLAT_GEMM_256 = 2,       /* 256 x 256 tile, 8 waves, two barriers per k-step */
+  MI355_FLAT_GEMM_256x128_3 = 3, /* 256 x 128, three LDS stages, one barrier per k-step */
+  MI355_FLAT_GEMM_8PHASE = 4,    /* 256 x 256, persistent 8-phase schedule (counted vmcnt,
+                                    staggered wave groups), fast epilogue */
+  MI355_FLAT_GEMM_8PHASE_REF = 5 /* the same schedule with variant 2's epilogue arithmetic */
+};
+enum { MI355_FLAT_CHECKSUM = 1u };
+int32_t mi355_flat_configure(mi355_flat *flat, uint32_t gemm_variant,
+                             uint32_t grid_workgroups, uint32_t flags);
+int32_t mi355_flat_checksum(mi355_flat *flat, uint64_t *out_checksum);
+
 /* which kernels served the last mi355_flat_search: 1 = bf16 MFMA GEMM filter +
    exact re-rank, 2 = exact scalar sweep (small columns, lower-bounded ranges);
    out_has_filter = 1 when the handle carries the filter data (bf16 shadow / row
@@ -317,12 +387,13 @@ typedef struct mi355_encode_desc {
   uint32_t mem;       /* MI355_MEM_*: where vectors and the outputs live */
   int32_t device;
   const float *centroids; /* [nlist, dim], same memory as `mem` */
-  const float *codebook;  /* [m, 256, dim/m] */
+  const float *codebook;  /* [m, 2^nbits, dim/m] */
 } mi355_encode_desc;
 
 int32_t mi355_ivfpq_encode(const mi355_encode_desc *desc, const float *vectors /*[n_rows, dim] f32*/,
                            uint64_t n_rows, uint64_t *out_part_offsets /*[nlist+1], ALWAYS host*/,
-                           uint8_t *out_codes /*[n_rows, m], index order*/,
+                           uint8_t *out_codes /*[n_rows, m * nbits / 8], index order
+                                                (4-bit: sub-quantiser 2t in the low nibble of byte t)*/,
                            uint64_t *out_order /*[n_rows]: source row at each index position*/,
                            uint32_t *out_assign /*[n_rows] partition of each SOURCE row, or NULL*/);
 
@@ -363,6 +434,72 @@ int32_t mi355_kmeans_train(const mi355_kmeans_desc *desc, const float *vectors, 
 int32_t mi355_ivf_residuals(const mi355_kmeans_desc *desc /*k = nlist; iters, ld as above*/,
                             const float *vectors, uint64_t n_rows, const float *centroids,
                             float *out_residuals /*[n_rows, dim] dense*/, uint32_t *out_assign);
+
+/*
+ * ---- multi-GPU exchange behind the ABI -------------------------
+ * The reference has no collective; this exchange is the engine's own:
+ * one process per GPU, the IVF partition list sharded across ranks
+ * (mi355_index_desc.shard_count / shard_rank = world / rank), RCCL over xGMI for the
+ * candidate all-gather.  No PyTorch: a Rust host creates the communicator from a
+ * 128-byte id it distributes over its own channel (file, socket, MPI ...).
+ */
+typedef struct mi355_comm mi355_comm;
+#define MI355_COMM_ID_BYTES 128
+/* rank 0: a fresh id (ncclGetUniqueId) */
+int32_t mi355_comm_unique_id(void *out_id /*[MI355_COMM_ID_BYTES]*/);
+/* every rank, collectively (ncclCommInitRank on `device`); world = 1 needs no peers */
+int32_t mi355_comm_create(const void *id, uint32_t rank, uint32_t world, int32_t device,
+                          mi355_comm **out);
+int32_t mi355_comm_destroy(mi355_comm *comm);
+
+enum {
+  /* score only this rank's slice of the centroids and select the probe list after an
+     all-gather of per-rank (partition, distance) pairs (C4: nlist = 65536) */
+  MI355_SHARD_COARSE = 1u
+};
+
+/* per-rank load of the last mi355_search_sharded call, identical on every rank */
+#define MI355_MAX_RANKS 64
+typedef struct mi355_comm_stats {
+  uint32_t struct_size;
+  uint32_t world;
+  uint32_t rank;
+  uint32_t n_gathers;                   /* RCCL all-gathers issued by the last call */
+  uint64_t bytes_gathered;              /* received bytes, this rank */
+  uint64_t rows_scanned[MI355_MAX_RANKS]; /* ADC rows per rank (sum over its work items) */
+  float imbalance;                      /* max / mean of rows_scanned */
+  uint32_t reserved;
+} mi355_comm_stats;
+int32_t mi355_comm_last_stats(mi355_comm *comm, mi355_comm_stats *out);
+
+/*
+ * The sharded search: called collectively by every rank with the SAME queries and
+ * params on its own shard handle; the result is identical on every rank and
+ * identical to the unsharded mi355_search — including refine_factor (the global
+ * k * refine_factor ANN candidates are selected FIRST, each rank then refines the
+ * candidates whose raw vectors it owns and a second all-gather + merge keeps k:
+ * rank-sharded raw vectors, C5) and maximum_nprobes (the expansion decision is taken
+ * on the merged counts, so all ranks take it together).
+ * One packed all-gather per exchange ([B, kk] x 16-B candidate records + [B] counts)
+ * on the handle's stream, then k_merge on every rank.  Device-I/O calls return
+ * without waiting; queries / outputs live where params->io_mem says.
+ */
+int32_t mi355_search_sharded(mi355_index *index, mi355_comm *comm, const float *queries,
+                             uint32_t n_queries, const mi355_search_params *params,
+                             uint32_t flags, uint64_t *out_rowids, float *out_dist,
+                             uint32_t *out_counts);
+
+/* Flat search with the rows sharded across ranks (SURVEY.md §8e "replicas-only
+   fallback: shard rows, same final all-gather"): every rank searches its own slice of
+   the column (row_ids carry the global ids), then the same gather + merge. */
+int32_t mi355_flat_search_sharded(mi355_flat *flat, mi355_comm *comm, const float *queries,
+                                  uint32_t n_queries, const mi355_search_params *params,
+                                  uint64_t *out_rowids, float *out_dist,
+                                  uint32_t *out_counts);
+
+/* centroid slice [lo, hi) rank scores in the sharded coarse stage (contiguous, balanced) */
+int32_t mi355_coarse_slice(uint32_t nlist, uint32_t world, uint32_t rank, uint32_t *out_lo,
+                           uint32_t *out_hi);
 
 /* Deterministic partition -> shard assignment used by mi355_index_open
    (greedy: partitions by descending length, each to the least loaded shard;

@@ -6,7 +6,7 @@ exactly; `struct_size` guards against drift at run time.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_INVALID_INPUT = 1
@@ -37,6 +37,31 @@ FILTER_NONE = 0
 FILTER_ALLOW = 1
 FILTER_BLOCK = 2
 
+APPROX_UNSET = 0
+APPROX_FAST = 1
+APPROX_NORMAL = 2
+APPROX_ACCURATE = 3
+APPROX_NAMES = {"fast": APPROX_FAST, "normal": APPROX_NORMAL, "accurate": APPROX_ACCURATE}
+
+INDEX_GENERIC_SCAN = 1
+INDEX_RAW_HOST_MAPPED = 2
+
+PROFILE_MASK = 0xFF
+CFG_GRAPH = 0x100
+CFG_COALESCE = 0x200
+
+FLAT_GEMM_AUTO = 0
+FLAT_GEMM_128 = 1
+FLAT_GEMM_256 = 2
+FLAT_GEMM_256x128_3 = 3
+FLAT_GEMM_8PHASE = 4
+FLAT_GEMM_8PHASE_REF = 5
+FLAT_CHECKSUM = 1
+
+SHARD_COARSE = 1
+COMM_ID_BYTES = 128
+MAX_RANKS = 64
+
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 
@@ -61,6 +86,8 @@ class IndexDesc(C.Structure):
         ("device", C.c_int32),
         ("shard_count", C.c_uint32),
         ("shard_rank", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -79,7 +106,7 @@ class SearchParams(C.Structure):
         ("io_mem", C.c_uint32),
         ("timeout_ms", C.c_uint32),
         ("filter_mode", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("approx_mode", C.c_uint32),
         ("filter_rowids", C.c_void_p),
         ("n_filter", C.c_uint64),
     ]
@@ -145,6 +172,23 @@ class Stats(C.Structure):
         ("us_total", C.c_float),
         ("scan_variant", C.c_uint32),
         ("scan_launches", C.c_uint32),
+        ("timed_out", C.c_uint32),
+        ("bad_probes", C.c_uint32),
+        ("coalesced_calls", C.c_uint32),
+        ("graph_replays", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class CommStats(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("world", C.c_uint32),
+        ("rank", C.c_uint32),
+        ("n_gathers", C.c_uint32),
+        ("bytes_gathered", C.c_uint64),
+        ("rows_scanned", C.c_uint64 * MAX_RANKS),
+        ("imbalance", C.c_float),
         ("reserved", C.c_uint32),
     ]
 
@@ -170,6 +214,15 @@ EXPORTED_SYMBOLS = (
     "mi355_flat_sync",
     "mi355_flat_search",
     "mi355_flat_info",
+    "mi355_flat_configure",
+    "mi355_flat_checksum",
+    "mi355_comm_unique_id",
+    "mi355_comm_create",
+    "mi355_comm_destroy",
+    "mi355_comm_last_stats",
+    "mi355_search_sharded",
+    "mi355_flat_search_sharded",
+    "mi355_coarse_slice",
     "mi355_ivfpq_encode", "mi355_kmeans_train", "mi355_ivf_residuals",
     "mi355_merge_topk",
     "mi355_shard_plan",
@@ -180,7 +233,7 @@ METRIC_NAMES = {"l2": METRIC_L2, "cosine": METRIC_COSINE, "dot": METRIC_DOT}
 
 def make_params(k=10, nprobe_min=20, nprobe_max=20, refine_factor=0,
                 metric=METRIC_DEFAULT, lower_bound=None, upper_bound=None,
-                io_mem=MEM_HOST, timeout_ms=0, allow_rowids=None, block_rowids=None):
+                io_mem=MEM_HOST, timeout_ms=0, allow_rowids=None, block_rowids=None, approx_mode=None):
     """Fill a SearchParams with VectorQueryRequest defaults
     (rust/lancedb/src/query.rs:1097-1114: nprobes 20/20, k 10, no refine)."""
     p = SearchParams()
@@ -196,6 +249,14 @@ def make_params(k=10, nprobe_min=20, nprobe_max=20, refine_factor=0,
     p.upper_bound = 0.0 if upper_bound is None else float(upper_bound)
     p.io_mem = io_mem
     p.timeout_ms = timeout_ms
+    if approx_mode is None:
+        p.approx_mode = APPROX_UNSET
+    elif isinstance(approx_mode, str):  # lib.rs:343-357
+        if approx_mode.lower() not in APPROX_NAMES:
+            raise ValueError(f"approx_mode must be one of 'fast', 'normal', or 'accurate', got '{approx_mode}'")
+        p.approx_mode = APPROX_NAMES[approx_mode.lower()]
+    else:
+        p.approx_mode = int(approx_mode)
     # prefilter: a sorted, unique u64 array (numpy for host I/O, a device array for device I/O);
     # the array is kept alive on the params object
     flt = allow_rowids if allow_rowids is not None else block_rowids

@@ -15,14 +15,17 @@ ROOT = os.path.dirname(_PKG)
 # MI355_ANN_LIB: dev override used to A/B kernel variants built side by side
 LIB_PATH = os.environ.get("MI355_ANN_LIB") or os.path.join(_PKG, "libmi355_ann.so")
 _CSRC = os.path.join(_PKG, "csrc")
-# the translation unit first, then everything it includes (any change rebuilds)
-_SOURCES = [os.path.join(_CSRC, "mi355_ann.hip")] + sorted(
-    os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".inc")))
+_OBJ = os.path.join(_PKG, "build")
+# one object per translation unit (compiled in parallel); every header / generated include is
+# a dependency of every unit
+_UNITS = sorted(f for f in os.listdir(_CSRC) if f.endswith(".hip"))
+_HEADERS = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".inc")))
 _HEADER = os.path.join(ROOT, "include", "mi355_ann.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function"]
+               "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
+# the multi-GPU exchange (mi355_comm_*, mi355_search_sharded) is RCCL behind the C ABI
+LINK_FLAGS = ["-shared", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 
 _lib = None
 
@@ -48,27 +51,58 @@ class QueryTimeout(EngineError, TimeoutError):
     pass
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in _SOURCES + [_HEADER])
-
-
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 the C-ABI library in-tree."""
-    if not force and not _stale():
-        return LIB_PATH
+def _hipcc():
     hipcc = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + [_SOURCES[0], "-o", LIB_PATH]
+    return hipcc if os.path.exists(hipcc) else "hipcc"
+
+
+def _newer(path, deps):
+    if not os.path.exists(path):
+        return True
+    t = os.path.getmtime(path)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def _stale():
+    srcs = [os.path.join(_CSRC, u) for u in _UNITS]
+    return _newer(LIB_PATH, srcs + _HEADERS + [_HEADER])
+
+
+def build(force=False, verbose=False, extra_flags=(), lib_path=None, obj_dir=None):
+    """hipcc --offload-arch=gfx950 the C-ABI library in-tree: one object per unit of
+    csrc/*.hip (in parallel), then one link.  `extra_flags` / `lib_path` / `obj_dir`
+    build a side-by-side dev variant (scripts/build_variants.sh)."""
+    lib_path = lib_path or LIB_PATH
+    obj_dir = obj_dir or _OBJ
+    if not force and not extra_flags and lib_path == LIB_PATH and not _stale():
+        return lib_path
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    for u in _UNITS:
+        src = os.path.join(_CSRC, u)
+        obj = os.path.join(obj_dir, u[:-4] + ".o")
+        if force or extra_flags or _newer(obj, [src] + _HEADERS + [_HEADER]):
+            cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+            jobs.append((u, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for u, p in jobs:
+        out, _ = p.communicate()
+        if verbose or p.returncode != 0:
+            print(out)
+        if p.returncode != 0:
+            failed.append((u, out))
+    if failed:
+        raise RuntimeError("hipcc failed building libmi355_ann.so:\n" +
+                           "\n".join(f"--- {u}\n{out[-4000:]}" for u, out in failed))
+    objs = [os.path.join(obj_dir, u[:-4] + ".o") for u in _UNITS]
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC"] + objs + LINK_FLAGS + ["-o", lib_path]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed building libmi355_ann.so:\n" + r.stdout[-4000:])
-    return LIB_PATH
+        raise RuntimeError("link of libmi355_ann.so failed:\n" + r.stdout[-4000:])
+    return lib_path
 
 
 def _bind_hip_runtime():
@@ -91,12 +125,14 @@ def _bind_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    # the same holds for RCCL (SONAME librccl.so.1 in both copies): one collective library per process
+    for name in ("libamdhip64.so", "librccl.so"):
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def lib():

@@ -1,0 +1,85 @@
+// ann_core.hip — library-level entry points of include/mi355_ann.h: ABI version,
+// device discovery, the per-thread error slot and the deterministic shard plan.
+// HIP runtime only: no torch, no Triton, no CUDA-compat headers.
+#include "ann_internal.h"
+
+// ------------------------------------------------------------------ errors --
+static thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+// ------------------------------------------------------------ shard plan ----
+void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::vector<uint32_t>& owner) {
+  owner.assign(nlist, 0);
+  if (shards <= 1) return;
+  std::vector<uint32_t> order(nlist);
+  for (uint32_t p = 0; p < nlist; ++p) order[p] = p;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    uint64_t la = po[a + 1] - po[a], lb = po[b + 1] - po[b];
+    if (la != lb) return la > lb;
+    return a < b;
+  });
+  std::vector<uint64_t> load(shards, 0);
+  for (uint32_t i = 0; i < nlist; ++i) {
+    uint32_t p = order[i], best = 0;
+    for (uint32_t s = 1; s < shards; ++s)
+      if (load[s] < load[best]) best = s;
+    owner[p] = best;
+    load[best] += po[p + 1] - po[p];
+  }
+}
+
+// ---------------------------------------------------------------- library ---
+extern "C" uint32_t mi355_abi_version(void) { return MI355_ANN_ABI_VERSION; }
+
+extern "C" int32_t mi355_device_count(int32_t* out_count) {
+  if (!out_count) return fail(MI355_ERR_INVALID_INPUT, "out_count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *out_count = n;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_last_error(char* buf, size_t buf_len) {
+  if (!buf || buf_len == 0) return MI355_ERR_INVALID_INPUT;
+  snprintf(buf, buf_len, "%s", g_last_error.c_str());
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_shard_plan(const uint64_t* part_offsets, uint32_t nlist,
+                                    uint32_t shard_count, uint32_t* out_owner) {
+  if (!part_offsets || !out_owner || shard_count == 0 || nlist == 0)
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_shard_plan: bad arguments");
+  std::vector<uint32_t> owner;
+  shard_plan_host(part_offsets, nlist, shard_count, owner);
+  memcpy(out_owner, owner.data(), sizeof(uint32_t) * nlist);
+  return MI355_OK;
+}
+
+int32_t need_device(int32_t device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(MI355_ERR_RUNTIME,
+                "no HIP device visible (hipGetDeviceCount: %s); the MI355X engine has no CPU "
+                "fallback",
+                e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  }
+  if (device < 0 || device >= n)
+    return fail(MI355_ERR_INVALID_INPUT, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  return MI355_OK;
+}

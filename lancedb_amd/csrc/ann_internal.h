@@ -1,0 +1,272 @@
+// ann_internal.h — host-side internals shared by the translation units of
+// libmi355_ann.so (include/mi355_ann.h is the only public surface).
+//
+//   ann_core.hip    library calls, error slot, shard plan
+//   ann_index.hip   IVF-PQ handle: open / configure / search / probes / merge
+//   ann_flat.hip    flat handle: open / search (MFMA filter + exact re-rank)
+//   ann_build.hip   index training and population
+//   ann_comm.hip    RCCL exchange behind the ABI: mi355_comm_*, mi355_search_sharded
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_ann.h"
+#include "device_common.h"
+
+// ------------------------------------------------------------------ errors --
+// message of the last failing call on this thread (mi355_last_error)
+int32_t fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return fail(MI355_ERR_RUNTIME, "HIP error %d (%s) at %s:%d: %s", (int)_e,         \
+                  hipGetErrorString(_e), __FILE__, __LINE__, #expr);                    \
+  } while (0)
+
+#define ST_TRY(expr)               \
+  do {                             \
+    int32_t _s = (expr);           \
+    if (_s != MI355_OK) return _s; \
+  } while (0)
+
+// grow-only device buffer.  Handle members are released by the handle's close; a
+// function-local one is a ScratchBuf (released on every exit path).
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  uint32_t* gen = nullptr;  // bumped on every re-allocation (invalidates cached hipGraphs)
+  int32_t ensure(size_t bytes) {
+    if (bytes <= cap) return MI355_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      (void)hipGetLastError();
+      return fail(MI355_ERR_RUNTIME, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    if (gen) ++*gen;
+    return MI355_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
+struct ScratchBuf : DevBuf {
+  ScratchBuf() = default;
+  ScratchBuf(const ScratchBuf&) = delete;
+  ScratchBuf& operator=(const ScratchBuf&) = delete;
+  ~ScratchBuf() { release(); }
+};
+
+static inline size_t dtype_size(uint32_t dt) { return dt == MI355_DTYPE_F32 ? 4 : 2; }
+
+// copy `bytes` from a caller buffer (host or device) to device memory
+static inline hipError_t copy_in(void* dst, const void* src, size_t bytes, uint32_t mem, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  return hipMemcpyAsync(dst, src, bytes, mem == MI355_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+}
+
+int32_t need_device(int32_t device);
+void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::vector<uint32_t>& owner);
+
+// Build-time dev knobs (-DMI355_DEV_KNOBS, scripts/build_variants.sh only): environment
+// overrides for kernel tuning experiments.  The product build reads no environment.
+#ifdef MI355_DEV_KNOBS
+static inline uint32_t dev_knob(const char* name, uint32_t dflt) {
+  const char* s = getenv(name);
+  if (!s || !*s) return dflt;
+  return (uint32_t)strtoul(s, nullptr, 10);
+}
+#else
+static inline uint32_t dev_knob(const char*, uint32_t dflt) { return dflt; }
+#endif
+
+// top-k selection width: slots per lane of the in-register selector (64 lanes each);
+// k > 256 runs the same selector in several passes (device_common.h, WaveTopK floor)
+static inline int kpl_for(uint32_t kk) { return kk <= 64 ? 1 : kk <= 128 ? 2 : 4; }
+
+template <typename Args, typename KernFn>
+static inline void launch_by_kpl(int kpl, KernFn k1, KernFn k2, KernFn k4, dim3 grid, dim3 block, size_t lds,
+                                 hipStream_t st, const Args& a) {
+  if (kpl == 1)
+    hipLaunchKernelGGL(k1, grid, block, lds, st, a);
+  else if (kpl == 2)
+    hipLaunchKernelGGL(k2, grid, block, lds, st, a);
+  else
+    hipLaunchKernelGGL(k4, grid, block, lds, st, a);
+}
+
+// ---------------------------------------------------------------- handles ---
+// Per-launch-sequence timestamps, recorded on the search stream without any
+// host synchronisation; elapsed times are read back in mi355_last_stats.
+struct EventSet {
+  hipEvent_t ev[6];
+};
+
+
+struct GraphKey {
+  uint32_t nq, k, kk, nprobe, flags;  // flags: refine | range shape | filter mode
+  bool operator<(const GraphKey& o) const {
+    return std::tie(nq, k, kk, nprobe, flags) < std::tie(o.nq, o.k, o.kk, o.nprobe, o.flags);
+  }
+};
+struct GraphEntry {
+  hipGraphExec_t exec = nullptr;
+  bool seen = false;    // the shape ran eagerly once (the workspace is sized): the next call captures
+  bool failed = false;  // capture / instantiate did not work for this shape: eager from now on
+  uint32_t gen = 0;     // workspace generation the graph was captured against
+  // what is baked into the captured kernels (a replay needs them to be identical)
+  float lower = 0.f, upper = 0.f;
+  uint32_t timeout_ms = 0;
+  const void* d_q = nullptr;
+  const void* d_ids = nullptr;
+  uint64_t work_items = 0;
+};
+
+// one waiting host-I/O search of the coalescing queue
+struct PendingSearch {
+  const float* queries;
+  uint32_t nq;
+  const mi355_search_params* params;
+  uint64_t* out_rowids;
+  float* out_dist;
+  uint32_t* out_counts;
+  int32_t status = MI355_OK;
+  std::string error;
+  bool done = false;
+};
+
+struct mi355_index {
+  int32_t device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;  // serialises device work of the handle
+  // shape
+  uint32_t dim = 0, nlist = 0, m = 0, dsub = 0, metric = 0, nbits = 8, mb = 0;  // mb: code bytes per row
+  uint64_t n_local = 0;
+  uint32_t parts_owned = 0, max_len = 0;
+  uint32_t shard_count = 1, shard_rank = 0;
+  // device data
+  DevBuf centroids, cnorm, codebook, codes, code_off, plen, pstride, lrow0, grow0, row_ids, raw;
+  bool has_row_ids = false, has_raw = false;
+  uint32_t raw_dtype = 0;
+  void* raw_mapped_host = nullptr;  // MI355_INDEX_RAW_HOST_MAPPED: registered caller memory
+  const void* raw_mapped_dev = nullptr;
+  std::vector<uint64_t> raw_row_of_local;  // unused unless mapped (see ann_index.hip)
+  std::vector<uint32_t> h_plen;
+  // code layout: MI355_SCAN_PAIR = [mb][pstride] blocks, MI355_SCAN_SKEW = pre-skewed streams
+  uint32_t layout = MI355_SCAN_PAIR;
+  uint32_t n_cus = 256;
+  uint32_t wall_khz = 100000;  // rate of the constant device clock behind timeout_ms (wall_clock64)
+  DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
+  // workspace
+  DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2, w_dist2, w_cnt2, w_ctl,
+      w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann;
+  uint32_t ws_gen = 0;  // bumped by every workspace re-allocation
+  // config
+  uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
+  bool use_graph = true, coalesce = true;
+  mi355_stats stats{};
+  std::vector<EventSet> ev_free, ev_pending;
+  std::map<GraphKey, GraphEntry> graphs;
+  // coalescing queue (guarded by qmu): callers that find the handle busy park here and the
+  // thread that owns the device batches every compatible request it finds when it is done
+  std::mutex qmu;
+  std::condition_variable qcv;
+  std::vector<PendingSearch*> queue;
+  bool busy = false;
+};
+
+struct mi355_flat {
+  int32_t device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  uint32_t dim = 0, dtype = 0;
+  uint64_t n_rows = 0;
+  DevBuf vectors, row_ids;
+  bool has_row_ids = false;
+  DevBuf w_q, w_cand, w_ids, w_dist, w_cnt;
+  // MFMA filter + exact re-rank (kernels_flat_mfma.h)
+  bool mfma = false;      // built at open when the column is large enough
+  bool shadowed = false;  // GEMM reads a bf16 shadow (column is f32/f16 or dim % 64 != 0)
+  uint32_t dimp = 0;
+  float c_err = 0.f, vv_max = 0.f;
+  DevBuf shadow, vv, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand, w_filter, w_sum;
+  uint32_t last_path = 0;  // 1 = MFMA filter, 2 = exact sweep (reported by mi355_flat_info)
+  uint32_t gemm_variant = MI355_FLAT_GEMM_AUTO, grid_workgroups = 0, cfg_flags = 0;
+  uint64_t checksum = 0;
+};
+
+// ------------------------------------------------- cross-TU entry points ----
+// one pass of the IVF-PQ pipeline over `nq` device-resident queries (ann_index.hip)
+struct SearchPlan {
+  uint32_t k, kk, nprobe;
+  bool refine;
+  RangeFilter range;
+  RowFilter filter;
+  const uint64_t* ext_probes = nullptr;  // device [nq, nprobe]: skip the coarse stage (mi355_search_probes)
+  // sharded search: stop after the ANN merge and leave the kk best (distance, position, rowid)
+  // records per query in out_cand [nq, kk] (refine runs after the cross-rank merge)
+  Cand* out_cand = nullptr;
+};
+int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl, uint64_t* d_ids,
+                  float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann);
+int32_t validate_params(const mi355_search_params* p);
+int32_t make_row_filter(const mi355_search_params* p, DevBuf& stage, hipStream_t st, RowFilter* out);
+int32_t arm_deadline(mi355_index* ix, uint32_t timeout_ms, hipStream_t st);
+
+// scan launchers (ann_scan_pair.hip / ann_scan_skew.hip)
+struct ScanArgs;
+struct SkewArgs;
+int32_t launch_scan_pair(const ScanArgs& sa, dim3 grid, hipStream_t st, uint32_t vpt, uint32_t nt);
+size_t scan_pair_lds(uint32_t m, uint32_t nbits, uint32_t dim, uint32_t lr, uint32_t nt);
+int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint32_t dim, uint32_t kk, hipStream_t st);
+
+struct IndexView;
+int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,
+                      const uint32_t* in_cnt, const uint32_t* owner, uint32_t my_rank, uint32_t kk,
+                      const RangeFilter& range, Cand* out, hipStream_t st);
+IndexView make_view(const mi355_index* ix);
+
+// pieces of the search path shared with the sharded search (ann_comm.hip)
+struct SearchShape {
+  uint32_t k, kk, np_min, np_max;
+};
+int32_t check_search(mi355_index* ix, const float* queries, uint32_t n_queries, const mi355_search_params* p,
+                     const uint64_t* ext_probes, uint32_t ext_nprobe, uint64_t* out_rowids, float* out_dist,
+                     uint32_t* out_counts, SearchShape* sh, bool sharded_call);
+void account(mi355_index* ix, uint32_t nq, uint32_t nprobe);
+int32_t drain_events(mi355_index* ix, bool discard);
+void reset_stats(mi355_index* ix);
+int32_t coarse_topn_device(mi355_index* ix, const float* d_q, uint32_t nq, uint32_t nprobe, uint32_t cent_lo,
+                           uint32_t cent_hi, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt);
+int32_t run_flat_search_device(mi355_flat* f, const float* d_q, uint32_t nq, const mi355_search_params* p,
+                               uint64_t* d_ids, float* d_dist, uint32_t* d_cnt);

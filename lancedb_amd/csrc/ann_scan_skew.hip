@@ -1,0 +1,45 @@
+// ann_scan_skew.hip — launcher of the production ADC scan kernel (k_scan_skew: pre-skewed code
+// streams, conflict-free [code][column] table, persistent workgroups on per-XCD queues).
+// Its own translation unit so that the kernel families compile in parallel.
+#include "ann_internal.h"
+#include "kernels_ivfpq.h"
+#include "kernels_skew.h"
+
+template <int M>
+static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_t dim, uint32_t kk,
+                                  hipStream_t st) {
+  auto lds_of = [&](int nw, int lr) {
+    return (size_t)SK_TABLE_BYTES + (((size_t)dim * 4 + 15) & ~(size_t)15) +
+           (size_t)nw * lr * 64 * 8 + (size_t)(nw + 10) * 4 + 128;
+  };
+#define LAUNCH_SK(LR, NT, MULTI)                                                                \
+  {                                                                                             \
+    auto kern = k_scan_skew<M, LR, NT, MULTI>;                                                       \
+    const size_t lds = lds_of(NT / 64, LR);                                                     \
+    if (lds > 160u * 1024)                                                                      \
+      return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds));                                                     \
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(NT), lds, st, sa);                            \
+  }
+  if (kk <= 64) LAUNCH_SK(2, 1024, false)
+  else if (kk <= 128) LAUNCH_SK(3, 1024, false)
+  else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false)
+  else LAUNCH_SK(5, 512, true)  // passes of SCAN_PASS_ROWS rows per work item
+#undef LAUNCH_SK
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint32_t dim,
+                                uint32_t kk, hipStream_t st) {
+  switch (m) {
+    case 32: return launch_scan_skew_m<32>(sa, n_blocks, dim, kk, st);
+    case 48: return launch_scan_skew_m<48>(sa, n_blocks, dim, kk, st);
+    case 64: return launch_scan_skew_m<64>(sa, n_blocks, dim, kk, st);
+    case 80: return launch_scan_skew_m<80>(sa, n_blocks, dim, kk, st);
+    case 96: return launch_scan_skew_m<96>(sa, n_blocks, dim, kk, st);
+  }
+  return fail(MI355_ERR_NOT_SUPPORTED, "no skewed scan kernel for m = %u", m);
+}
+

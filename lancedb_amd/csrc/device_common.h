@@ -19,6 +19,36 @@ struct Cand {  // 16 B candidate record kept between scan -> merge -> refine
 
 #define CAND_EMPTY_POS 0xFFFFFFFFu
 
+// Device-side control word of an index handle (one 64-B line, zeroed per call).
+// `deadline` is QueryExecutionOptions.timeout (rust/lancedb/src/query.rs:626-658) as a
+// device clock value: the persistent scan polls it between work items, every other kernel
+// at entry; the first kernel that sees it pass latches `timed_out` and the rest of the
+// call's launch sequence exits at once.
+struct DevCtl {
+  unsigned long long rows_scanned;  // stats: vectors scanned (sum over (query, partition) pairs)
+  unsigned long long deadline;      // wall_clock64() value after which kernels stop; 0 = none
+  uint32_t timed_out;
+  uint32_t bad_probes;              // probe ids outside 0..nlist-1 (mi355_search_probes)
+  uint32_t pad[10];
+};
+
+__device__ __forceinline__ bool ctl_expired(DevCtl* ctl) {
+  if (!ctl) return false;
+  if (__hip_atomic_load(&ctl->timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+  const unsigned long long dl = ctl->deadline;
+  if (dl && (unsigned long long)wall_clock64() > dl) {
+    __hip_atomic_store(&ctl->timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  return false;
+}
+
+// first kernel of a call with a timeout: deadline = now + ticks of the constant-rate device clock
+static __global__ void k_arm_deadline(DevCtl* ctl, unsigned long long ticks) {
+  ctl->deadline = ticks ? (unsigned long long)wall_clock64() + ticks : 0ull;
+  ctl->timed_out = 0;
+}
+
 // Correctly rounded sqrt / divide.  NOT __fsqrt_rn / __fdiv_rn: without
 // OCML_BASIC_ROUNDED_OPERATIONS hipcc maps __fsqrt_rn to the approximate native
 // sqrt (__clang_hip_math.h).  sqrtf() and '/' are IEEE under
@@ -99,6 +129,11 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
 // always the exact kk smallest by (distance, rowid).  Expected admissions for n
 // random keys are ~kk*ln(n/kk): the hot loop only pays one compare per row.
 // ---------------------------------------------------------------------------
+//
+// k > 64 * KPL: the selector runs in PASSES (wave_select_sorted below).  Pass p admits
+// only keys strictly above the `floor` = the last key pass p-1 emitted, so it yields ranks
+// p*C .. p*C + C-1 of the same total order; the reference bounds neither `limit`
+// (rust/lancedb/src/query.rs:818-907) nor `refine_factor` (query.rs:1302-1332).
 template <int KPL>
 struct WaveTopK {
   float d[KPL];
@@ -107,9 +142,28 @@ struct WaveTopK {
   uint32_t thr_lo, thr_hi;
   int thr_lane, thr_slot;
   uint32_t kk;
+  // admission floor (wave-uniform): keys <= floor are ignored
+  uint32_t fl_on;
+  float fl_d;
+  uint32_t fl_lo, fl_hi;
+  // last key handed out by drain_sorted (wave-uniform)
+  float last_d;
+  uint32_t last_lo, last_hi;
+
+  __device__ __forceinline__ void set_floor(bool on, float fd, uint32_t flo, uint32_t fhi) {
+    fl_on = on ? 1u : 0u;
+    fl_d = fd;
+    fl_lo = flo;
+    fl_hi = fhi;
+  }
 
   __device__ __forceinline__ void init(uint32_t kk_, int lane) {
     kk = kk_;
+    fl_on = 0;
+    fl_d = 0.f;
+    fl_lo = fl_hi = 0;
+    last_d = 0.f;
+    last_lo = last_hi = 0;
 #pragma unroll
     for (int s = 0; s < KPL; ++s) {
       d[s] = __builtin_huge_valf();
@@ -172,6 +226,7 @@ struct WaveTopK {
   __device__ __forceinline__ void insert_uniform(float cd, uint32_t cpos, uint32_t clo,
                                                  uint32_t chi, int lane) {
     if (!key_less(cd, chi, clo, thr_d, thr_hi, thr_lo)) return;
+    if (fl_on && !key_less(fl_d, fl_hi, fl_lo, cd, chi, clo)) return;  // not above the floor
     if (lane == thr_lane) {
 #pragma unroll
       for (int s = 0; s < KPL; ++s)
@@ -189,7 +244,7 @@ struct WaveTopK {
   // still beat the threshold are drained one by one.
   __device__ __forceinline__ void offer(bool valid, float cd, uint32_t cpos, uint64_t cid,
                                         int lane) {
-    uint64_t mask = __ballot(valid && cd <= thr_d);
+    uint64_t mask = __ballot(valid && cd <= thr_d && (!fl_on || cd >= fl_d));
     uint32_t clo = (uint32_t)cid, chi = (uint32_t)(cid >> 32);
     while (mask) {
       int l = __ffsll((unsigned long long)mask) - 1;
@@ -262,6 +317,9 @@ struct WaveTopK {
         }
       }
       if (!bv) break;  // wave-uniform: nothing left
+      last_d = bd;  // after the butterfly every lane holds the winner's key
+      last_lo = blo;
+      last_hi = bhi;
       if (lane == bl) {
 #pragma unroll
         for (int s = 0; s < KPL; ++s)
@@ -275,6 +333,38 @@ struct WaveTopK {
     return n;
   }
 };
+
+// The k smallest keys of a candidate stream in ascending (distance, rowid) order, for ANY k:
+// passes of up to 64 * KPL keys.  `gen(top)` must offer the WHOLE stream to `top` each time it
+// is called (it runs once per pass); `emit(rank, d, pos, id)` runs on the owning lane.
+// Returns the number of keys emitted (< k when the stream is shorter).  After the call
+// `kth_d` holds the distance of the last emitted key (+inf when none).
+template <int KPL, typename Gen, typename Emit>
+__device__ __forceinline__ uint32_t wave_select_sorted(uint32_t k, int lane, Gen gen, Emit emit, float* kth_d = nullptr) {
+  WaveTopK<KPL> top;
+  uint32_t base = 0;
+  bool fl_on = false;
+  float fd = __builtin_huge_valf();
+  uint32_t flo = 0, fhi = 0;
+  while (base < k) {
+    const uint32_t c = min(k - base, (uint32_t)(KPL * MI355_WAVE));
+    top.init(c, lane);
+    top.set_floor(fl_on, fd, flo, fhi);
+    gen(top);
+    const uint32_t b0 = base;
+    const uint32_t n = top.drain_sorted(lane, [&](uint32_t r, float d, uint32_t pos, uint64_t id) { emit(b0 + r, d, pos, id); });
+    base += n;
+    if (n) {
+      fl_on = true;
+      fd = top.last_d;
+      flo = top.last_lo;
+      fhi = top.last_hi;
+    }
+    if (n < c) break;  // the stream is exhausted
+  }
+  if (kth_d) *kth_d = fl_on ? fd : __builtin_huge_valf();
+  return base;
+}
 
 // ---------------------------------------------------------------------------
 // K4 (scan-side): shuffle-free selection for the ADC hot loop.

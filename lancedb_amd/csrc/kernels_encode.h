@@ -23,7 +23,7 @@
 
 // ---- pass A: arg-min over the coarse distances of one row --------------------------
 // NaN never wins; among equal minima the lowest partition id wins (oracle: first minimum)
-__global__ __launch_bounds__(256) void k_argmin_rows(const float* __restrict__ coarse, uint32_t n, uint32_t nlist,
+static __global__ __launch_bounds__(256) void k_argmin_rows(const float* __restrict__ coarse, uint32_t n, uint32_t nlist,
                                                      uint32_t* __restrict__ assign, uint32_t* __restrict__ hist) {
   __shared__ uint32_t s_key[4], s_idx[4];
   const uint32_t row = blockIdx.x;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_argmin_rows(const float* __restrict__ c
 // ---- pass B: stable positions ---------------------------------------------------------
 // block b of a chunk covers rows [r0 + 256 b, +256): rank of each row among the earlier
 // rows of the same partition in the block; the first row of a partition records the count
-__global__ __launch_bounds__(256) void k_local_rank(const uint32_t* __restrict__ assign, uint64_t r0, uint64_t n_rows,
+static __global__ __launch_bounds__(256) void k_local_rank(const uint32_t* __restrict__ assign, uint64_t r0, uint64_t n_rows,
                                                     uint32_t nlist, uint32_t* __restrict__ cntB,
                                                     uint32_t* __restrict__ lrank) {
   __shared__ uint32_t s_a[256];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_local_rank(const uint32_t* __restrict__
 
 // one thread per partition: exclusive scan of its counts over the chunk's blocks; the
 // partition's running offset advances into run_out (k_positions still needs run_in)
-__global__ void k_block_scan(uint32_t* __restrict__ cntB, uint32_t n_blocks, uint32_t nlist,
+static __global__ void k_block_scan(uint32_t* __restrict__ cntB, uint32_t n_blocks, uint32_t nlist,
                              const unsigned long long* __restrict__ run_in,
                              unsigned long long* __restrict__ run_out) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,7 +102,7 @@ __global__ void k_block_scan(uint32_t* __restrict__ cntB, uint32_t n_blocks, uin
   run_out[p] = run_in[p] + rel;
 }
 
-__global__ __launch_bounds__(256) void k_positions(const uint32_t* __restrict__ assign, uint64_t r0, uint64_t n_rows,
+static __global__ __launch_bounds__(256) void k_positions(const uint32_t* __restrict__ assign, uint64_t r0, uint64_t n_rows,
                                                    uint32_t nlist, const uint32_t* __restrict__ cntB,
                                                    const uint32_t* __restrict__ lrank,
                                                    const unsigned long long* __restrict__ chunk_base,
@@ -120,19 +120,23 @@ struct EncodeArgs {
   uint64_t r0, n;          // first source row and row count of this chunk
   const uint32_t* assign;  // [n_total]
   const float* centroids;  // [nlist, dim]
-  const float* codebook;   // [m, 256, dsub]
+  const float* codebook;   // [m, 2^NBITS, dsub]
   uint32_t dim, m, dsub, metric;
-  uint8_t* codes;          // [n_total, m] SOURCE order
+  uint32_t mb;             // code bytes per row: m * NBITS / 8
+  uint8_t* codes;          // [n_total, mb] SOURCE order
 };
 
-// grid (row blocks of 256, m / JT): thread = (row, JT consecutive sub-quantisers)
-template <int JT>
+// grid (row blocks of 256, m / JT): thread = (row, JT consecutive sub-quantisers).
+// NBITS = 4 (JT = 2): two codes per byte, sub-quantiser 2t in the low nibble of byte t.
+template <int JT, int NBITS>
 __global__ __launch_bounds__(256) void k_encode_rows(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* cb = (float*)smem;  // [JT][256][dsub]
+  constexpr uint32_t KS = 1u << NBITS;
+  static_assert(NBITS == 8 || (NBITS == 4 && JT == 2), "4-bit codes are encoded a byte (two sub-quantisers) at a time");
+  float* cb = (float*)smem;  // [JT][KS][dsub]
   const int tid = threadIdx.x;
   const uint32_t j0 = blockIdx.y * JT, dsub = a.dsub;
-  for (uint32_t e = tid; e < (uint32_t)JT * 256u * dsub; e += 256) cb[e] = a.codebook[(size_t)j0 * 256 * dsub + e];
+  for (uint32_t e = tid; e < (uint32_t)JT * KS * dsub; e += 256) cb[e] = a.codebook[(size_t)j0 * KS * dsub + e];
   __syncthreads();
   const uint64_t i = (uint64_t)blockIdx.x * 256 + tid;
   if (i >= a.n) return;
@@ -153,8 +157,8 @@ __global__ __launch_bounds__(256) void k_encode_rows(EncodeArgs a) {
     uint32_t bc = 0;
     float bv = 0.f;
     bool have = false;
-    const float* cj = cb + (size_t)jj * 256 * dsub;
-    for (uint32_t c = 0; c < 256; ++c) {
+    const float* cj = cb + (size_t)jj * KS * dsub;
+    for (uint32_t c = 0; c < KS; ++c) {
       float acc = 0.f;
       auto step = [&](float rv, float e) {  // e: same LDS address in every lane (broadcast)
         if (dotm)
@@ -179,9 +183,13 @@ __global__ __launch_bounds__(256) void k_encode_rows(EncodeArgs a) {
         have = true;
       }
     }
-    packed |= bc << (8 * jj);
+    packed |= bc << (NBITS * jj);
   }
-  uint8_t* dst = a.codes + (size_t)row * a.m + j0;
+  if (NBITS == 4) {
+    a.codes[(size_t)row * a.mb + j0 / 2] = (uint8_t)packed;
+    return;
+  }
+  uint8_t* dst = a.codes + (size_t)row * a.mb + j0;
   if (JT == 4)
     *(uint32_t*)dst = packed;  // m % 4 == 0: the row's codes are 4-byte aligned
   else
@@ -210,7 +218,7 @@ __global__ void k_permute_codes(const uint8_t* __restrict__ src, const uint64_t*
 // source-row order (the stable order of pass B) — a sum whose order is part of the
 // definition, so the trained centroids are bit-exact against the oracle; loads run four
 // rows ahead of the adds.
-__global__ __launch_bounds__(256) void k_centroid_update(const float* __restrict__ xp,
+static __global__ __launch_bounds__(256) void k_centroid_update(const float* __restrict__ xp,
                                                          const uint64_t* __restrict__ order,
                                                          const unsigned long long* __restrict__ po, uint32_t dim,
                                                          float* __restrict__ cen) {
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void k_centroid_update(const float* __restrict
   cen[(size_t)p * dim + d] = ieee_divf(acc, (float)(hi - lo));
 }
 
-__global__ void k_residuals(const float* __restrict__ xp, const uint32_t* __restrict__ assign,
+static __global__ void k_residuals(const float* __restrict__ xp, const uint32_t* __restrict__ assign,
                             const float* __restrict__ cen, uint64_t n, uint32_t dim, uint32_t metric,
                             float* __restrict__ out) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -52,7 +52,7 @@ struct FlatRowPrepArgs {
   uint32_t* max_key;  // [1] f32 sort key of max vv (atomicMax)
 };
 
-__global__ __launch_bounds__(256) void k_flat_prep_rows(FlatRowPrepArgs a) {
+static __global__ __launch_bounds__(256) void k_flat_prep_rows(FlatRowPrepArgs a) {
   const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= a.n_rows) return;
@@ -85,7 +85,7 @@ struct FlatQueryPrepArgs {
   float* qslack;       // [nq_pad] 2 * eps_max(q): added to the k-th segment minimum
 };
 
-__global__ __launch_bounds__(256) void k_flat_prep_queries(FlatQueryPrepArgs a) {
+static __global__ __launch_bounds__(256) void k_flat_prep_queries(FlatQueryPrepArgs a) {
   const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= a.nq_pad) return;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
 
 // dev (MI355_FLAT_SYNC=1): order-independent checksum of the group-minimum matrix, to compare
 // GEMM schedules bit for bit on identical inputs
-__global__ void k_flat_checksum(const float* __restrict__ gm, size_t n, unsigned long long* __restrict__ out) {
+static __global__ void k_flat_checksum(const float* __restrict__ gm, size_t n, unsigned long long* __restrict__ out) {
   unsigned long long acc = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     acc += (unsigned long long)__float_as_uint(gm[i]) * (i % 1000003ull + 1ull);
@@ -413,7 +413,7 @@ __global__ void k_flat_checksum(const float* __restrict__ gm, size_t n, unsigned
 
 // ---------------------------------------------------- threshold + candidates ---
 // segment minima: gm [n_groups][nq_pad] -> seg [n_seg][nq_pad]
-__global__ __launch_bounds__(256) void k_flat_segmin(const float* __restrict__ gm, uint32_t n_groups,
+static __global__ __launch_bounds__(256) void k_flat_segmin(const float* __restrict__ gm, uint32_t n_groups,
                                                      uint32_t nq_pad, uint32_t groups_per_seg,
                                                      float* __restrict__ seg) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
@@ -425,32 +425,33 @@ __global__ __launch_bounds__(256) void k_flat_segmin(const float* __restrict__ g
   seg[(size_t)s * nq_pad + q] = m;
 }
 
-// tau_q = (k-th smallest segment minimum) + slack_q; one wave per query
+// tau_q = (k-th smallest segment minimum) + slack_q; one wave per query (any k: passes of
+// 64 * KPL segments; more than n_seg rows asked for -> +inf, every group is a candidate)
 template <int KPL>
 __global__ __launch_bounds__(64) void k_flat_tau(const float* __restrict__ seg, uint32_t n_seg, uint32_t nq_pad,
                                                  uint32_t k, const float* __restrict__ qslack,
                                                  float* __restrict__ tau, uint32_t* __restrict__ cand_cnt) {
   const int lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
-  WaveTopK<KPL> top;
-  top.init(k, lane);
-  for (uint32_t s0 = 0; s0 < n_seg; s0 += MI355_WAVE) {
-    const uint32_t s = s0 + lane;
-    float v = 0.f;
-    if (s < n_seg) v = seg[(size_t)s * nq_pad + q];
-    // -inf marks "score not representable": always a candidate, never evidence for the bound
-    top.offer(s < n_seg && v > -__builtin_huge_valf(), v, s, (uint64_t)s, lane);
-  }
-  // thr_d is the worst kept key = the k-th smallest once k segments were offered
-  float t = top.thr_d;
-  if (n_seg < k) t = __builtin_huge_valf();
+  auto gen = [&](WaveTopK<KPL>& top) {
+    for (uint32_t s0 = 0; s0 < n_seg; s0 += MI355_WAVE) {
+      const uint32_t s = s0 + lane;
+      float v = 0.f;
+      if (s < n_seg) v = seg[(size_t)s * nq_pad + q];
+      // -inf marks "score not representable": always a candidate, never evidence for the bound
+      top.offer(s < n_seg && v > -__builtin_huge_valf(), v, s, (uint64_t)s, lane);
+    }
+  };
+  float t = __builtin_huge_valf();
+  const uint32_t got = wave_select_sorted<KPL>(k, lane, gen, [](uint32_t, float, uint32_t, uint64_t) {}, &t);
+  if (got < k) t = __builtin_huge_valf();  // fewer than k usable segments: no bound
   if (lane == 0) {
     tau[q] = t + qslack[q];
     cand_cnt[q] = 0;
   }
 }
 
-__global__ __launch_bounds__(256) void k_flat_compact(const float* __restrict__ gm, uint32_t n_groups,
+static __global__ __launch_bounds__(256) void k_flat_compact(const float* __restrict__ gm, uint32_t n_groups,
                                                       uint32_t nq_pad, uint32_t nq, const float* __restrict__ tau,
                                                       uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ cand) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
@@ -501,48 +502,72 @@ __global__ __launch_bounds__(256) void k_flat_rerank(FlatRerankArgs a) {
   const uint32_t cnt = a.cand_cnt[b];
   const bool all = cnt > FG_CAND_CAP;
   const uint64_t total = all ? f.n_rows : (uint64_t)cnt * FG_GROUP;
-  WaveTopK<KPL> top;
-  top.init(f.kk, lane);
-  for (uint64_t i0 = 0; i0 < total; i0 += 256) {
-    const uint64_t i = i0 + tid;
-    uint64_t row = i;
-    if (!all && i < total) row = (uint64_t)a.cand[(size_t)b * FG_CAND_CAP + (uint32_t)(i / FG_GROUP)] * FG_GROUP + (i % FG_GROUP);
-    bool ok = i < total && row < f.n_rows;
-    float d = 0.f;
-    if (ok) {
-      d = exact_distance(sq, f.vectors, f.dtype, row, f.dim, f.metric, qq);
-      ok = d <= top.thr_d && in_range(d, f.range);
-    }
-    if (__any(ok)) {
-      uint64_t id = 0;
-      if (ok) id = f.row_ids ? f.row_ids[row] : row;
-      if (f.filter.mode != MI355_FILTER_NONE && ok) ok = row_permitted(id, f.filter);
-      top.offer(ok, d, (uint32_t)row, id, lane);
-    }
+  uint64_t* oi = a.out_ids + (size_t)b * f.kk;
+  float* od = a.out_dist + (size_t)b * f.kk;
+  for (uint32_t g = tid; g < f.kk; g += 256) {
+    oi[g] = ~0ull;
+    od[g] = __builtin_huge_valf();
   }
-  top.store(stage + (size_t)wid * f.kk, lane);
-  __syncthreads();
-  if (wid == 0) {
-    const uint32_t n = 3 * f.kk;
-    for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
-      const uint32_t t = t0 + lane;
-      Cand c;
-      c.d = 0.f;
-      c.pos = CAND_EMPTY_POS;
-      c.id = 0;
-      if (t < n) c = stage[f.kk + t];
-      top.offer(t < n && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
+  __shared__ PassFloor s_floor;
+  __shared__ uint32_t s_nout;
+  constexpr uint32_t C = KPL * MI355_WAVE;
+  bool fl_on = false;
+  float fl_d = 0.f;
+  uint64_t fl_id = 0;
+  uint32_t n_total = 0;
+  for (uint32_t base = 0; base < f.kk; base += C) {  // passes of C rows (one pass unless kk > 64 KPL)
+    const uint32_t c = min(f.kk - base, C);
+    WaveTopK<KPL> top;
+    top.init(c, lane);
+    top.set_floor(fl_on, fl_d, (uint32_t)fl_id, (uint32_t)(fl_id >> 32));
+    for (uint64_t i0 = 0; i0 < total; i0 += 256) {
+      const uint64_t i = i0 + tid;
+      uint64_t row = i;
+      if (!all && i < total) row = (uint64_t)a.cand[(size_t)b * FG_CAND_CAP + (uint32_t)(i / FG_GROUP)] * FG_GROUP + (i % FG_GROUP);
+      bool ok = i < total && row < f.n_rows;
+      float d = 0.f;
+      if (ok) {
+        d = exact_distance(sq, f.vectors, f.dtype, row, f.dim, f.metric, qq);
+        ok = d <= top.thr_d && in_range(d, f.range);
+      }
+      if (__any(ok)) {
+        uint64_t id = 0;
+        if (ok) id = f.row_ids ? f.row_ids[row] : row;
+        if (f.filter.mode != MI355_FILTER_NONE && ok) ok = row_permitted(id, f.filter);
+        top.offer(ok, d, (uint32_t)row, id, lane);
+      }
     }
-    uint64_t* oi = a.out_ids + (size_t)b * f.kk;
-    float* od = a.out_dist + (size_t)b * f.kk;
-    for (uint32_t g = lane; g < f.kk; g += MI355_WAVE) {
-      oi[g] = ~0ull;
-      od[g] = __builtin_huge_valf();
+    top.store(stage + (size_t)wid * c, lane);
+    __syncthreads();
+    if (wid == 0) {
+      const uint32_t n = 3 * c;
+      for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
+        const uint32_t t = t0 + lane;
+        Cand cd;
+        cd.d = 0.f;
+        cd.pos = CAND_EMPTY_POS;
+        cd.id = 0;
+        if (t < n) cd = stage[c + t];
+        top.offer(t < n && cd.pos != CAND_EMPTY_POS, cd.d, cd.pos, cd.id, lane);
+      }
+      const uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
+        oi[base + rk] = id;
+        od[base + rk] = d;
+      });
+      if (lane == 0) {
+        s_nout = n_out;
+        s_floor.on = n_out == c ? 1u : 0u;
+        s_floor.d = top.last_d;
+        s_floor.id = ((uint64_t)top.last_hi << 32) | top.last_lo;
+      }
     }
-    const uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
-      oi[rk] = id;
-      od[rk] = d;
-    });
-    if (lane == 0) a.out_cnt[b] = n_out;
+    __syncthreads();
+    n_total += s_nout;
+    if (!s_floor.on) break;
+    fl_on = true;
+    fl_d = s_floor.d;
+    fl_id = s_floor.id;
+    __syncthreads();
   }
+  if (tid == 0) a.out_cnt[b] = n_total;
 }

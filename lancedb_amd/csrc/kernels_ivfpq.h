@@ -17,10 +17,11 @@
 // ---------------------------------------------------------------------------
 struct IndexView {
   uint32_t dim, nlist, m, dsub, metric;
+  uint32_t nbits, mb;         // PQ bits per code (8 | 4) and code bytes per row (m * nbits / 8)
   const float* centroids;     // [nlist, dim]
   const float* cnorm;         // [nlist] chain_dot(c,c)
-  const float* codebook;      // [m, 256, dsub]
-  const uint8_t* codes;       // partition p: [m, pstride[p]] block at code_off[p]
+  const float* codebook;      // [m, 2^nbits, dsub]
+  const uint8_t* codes;       // partition p: [mb, pstride[p]] block at code_off[p]
   const uint64_t* code_off;   // [nlist] byte offset of the partition block
   const uint32_t* plen;       // [nlist] rows of p kept on this handle (0 = not owned / empty)
   const uint32_t* pstride;    // [nlist] plen rounded up to 16
@@ -29,14 +30,29 @@ struct IndexView {
   const uint64_t* row_ids;    // [n_local] or nullptr (identity: rowid = global position)
   const void* raw;            // [n_local, dim] or nullptr
   uint32_t raw_dtype;
+  uint32_t raw_by_global;     // 1: `raw` is the caller's whole column [n_rows, dim] in GLOBAL index order
+                              //    (MI355_INDEX_RAW_HOST_MAPPED), addressed by global position
 };
+
+// local row position -> global index position: the partition whose local range holds `pos`
+// (lrow0 is non-decreasing; empty / foreign partitions have zero length)
+__device__ __forceinline__ uint64_t global_pos_of(const IndexView& ix, uint32_t pos) {
+  uint32_t lo = 0, hi = ix.nlist;  // last p with lrow0[p] <= pos and plen[p] > 0 covering pos
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (ix.lrow0[mid] <= pos) lo = mid; else hi = mid;
+  }
+  // partitions sharing the same lrow0 (zero-length ones) sit before the owner: step to the one that has rows
+  while (lo > 0 && ix.plen[lo] == 0) --lo;
+  return ix.grow0[lo] + (pos - ix.lrow0[lo]);
+}
 
 // ------------------------------------------------------------------ K0 -----
 // One wave per query.  The chains of the contract are sequential in d, so one lane
 // runs them — but from LDS in 16-B reads, after the wave has copied the query in
 // coalesced (one thread per query with scalar global loads was latency-bound: 149 us
 // per 2048-query batch, a visible slice of a multi-GPU step).
-__global__ __launch_bounds__(256) void k_prep_queries(const float* __restrict__ q, uint32_t nq, uint32_t dim,
+static __global__ __launch_bounds__(256) void k_prep_queries(const float* __restrict__ q, uint32_t nq, uint32_t dim,
                                                       uint32_t metric, float* __restrict__ qp,
                                                       float* __restrict__ qq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(256) void k_prep_queries(const float* __restrict__ 
   }
 }
 
-__global__ void k_centroid_norms(const float* __restrict__ c, uint32_t nlist, uint32_t dim,
+static __global__ void k_centroid_norms(const float* __restrict__ c, uint32_t nlist, uint32_t dim,
                                  float* __restrict__ cn) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nlist) return;
@@ -100,7 +116,7 @@ __global__ void k_centroid_norms(const float* __restrict__ c, uint32_t nlist, ui
 // fma(0,0,acc) == acc for the +0-started chain).
 #define CO_T 64
 #define CO_K 16
-__global__ __launch_bounds__(256) void k_coarse_tile(
+static __global__ __launch_bounds__(256) void k_coarse_tile(
     const float* __restrict__ qp, const float* __restrict__ qq, uint32_t nq,
     const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist, uint32_t dim,
     uint32_t metric, float* __restrict__ out /*[nq, nlist]*/) {
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256) void k_coarse_tile(
 #define CM_T 64
 #define CM_K 32
 typedef __attribute__((ext_vector_type(16))) float cm_f32x16;
-__global__ __launch_bounds__(256) void k_coarse_mfma(
+static __global__ __launch_bounds__(256) void k_coarse_mfma(
     const float* __restrict__ qp, const float* __restrict__ qq, uint32_t nq,
     const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist, uint32_t dim,
     uint32_t metric, float* __restrict__ out /*[nq, nlist]*/) {
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(256) void k_coarse_mfma(
 // smallest coarse key, then emit {key < T} (any order) followed by the
 // lowest-id {key == T} rows.  Works for any nlist (C4: 65536).  Also adds the
 // query's probed rows to the stats counters.
-__global__ __launch_bounds__(256) void k_select_probes(
+static __global__ __launch_bounds__(256) void k_select_probes(
     const float* __restrict__ coarse, uint32_t nlist, uint32_t nprobe,
     const uint32_t* __restrict__ plen, uint32_t* __restrict__ probes /*[nq, nprobe]*/,
     unsigned long long* __restrict__ stat_rows) {
@@ -341,7 +357,7 @@ __global__ __launch_bounds__(256) void k_select_probes(
 
 // two-phase search helpers (mi355_coarse_topn / mi355_search_probes)
 // (partition id, distance) pairs of a slice's selected probes, in merge_topk's layout
-__global__ void k_emit_coarse_pairs(const uint32_t* __restrict__ probes, const float* __restrict__ coarse,
+static __global__ void k_emit_coarse_pairs(const uint32_t* __restrict__ probes, const float* __restrict__ coarse,
                                     uint32_t nq, uint32_t n_sel, uint32_t n_slice, uint32_t nprobe, uint32_t cent_lo,
                                     uint64_t* __restrict__ out_ids, float* __restrict__ out_dist,
                                     uint32_t* __restrict__ out_cnt) {
@@ -360,7 +376,7 @@ __global__ void k_emit_coarse_pairs(const uint32_t* __restrict__ probes, const f
 }
 
 // external probe list (u64 ids) -> the u32 list the scan reads, plus the row counter
-__global__ void k_take_probes(const uint64_t* __restrict__ in, uint32_t n, uint32_t nlist,
+static __global__ void k_take_probes(const uint64_t* __restrict__ in, uint32_t n, uint32_t nlist,
                               const uint32_t* __restrict__ plen, uint32_t* __restrict__ out,
                               unsigned long long* __restrict__ stat_rows, uint32_t* __restrict__ bad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -420,6 +436,17 @@ struct ScanArgs {
   RowFilter filter;
   Cand* cand;               // [nq, nprobe, n_slices, kk]
   uint32_t dbg;             // dev ablation mask (MI355_DBG_SKIP): 1 LUT build, 2 ADC loop, 4 top-k
+  DevCtl* ctl;              // deadline / counters of the call
+};
+
+// rows per selection pass of a scan work item when kk exceeds the per-wave list capacity
+#define SCAN_PASS_ROWS 256u
+
+// (distance, rowid) floor of a selection pass, shared through LDS
+struct PassFloor {
+  float d;
+  uint32_t on;
+  uint64_t id;
 };
 
 __device__ __forceinline__ float finalize_dist(float acc, uint32_t metric, uint32_t m) {
@@ -428,16 +455,24 @@ __device__ __forceinline__ float finalize_dist(float acc, uint32_t metric, uint3
   return acc;
 }
 
-template <int VPT, int KPL, int NTHREADS>
+// LR: per-wave list capacity in units of 64 entries (2: kk <= 64, 5: kk <= 256).
+// NBITS: 8 (256-entry tables) or 4 (16-entry tables, two codes per byte: sub-quantiser 2t in the
+// low nibble of byte t, 2t+1 in the high nibble; table/create_index.rs:96-101).
+// MULTI: kk > 256 — the work item's rows are selected in passes of SCAN_PASS_ROWS: pass p keeps
+// the best rows strictly above the last row of pass p-1 in the (distance, rowid) order and
+// writes ranks p*256 .. of the item's kk output slots; the distance table is built once.
+template <int VPT, int LR, int NTHREADS, int NBITS, bool MULTI>
 __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NTHREADS / MI355_WAVE;
+  constexpr uint32_t CB = 1u << NBITS;  // table entries per sub-quantiser
   const IndexView& ix = a.ix;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t s = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+  if (ctl_expired(a.ctl)) return;  // block-uniform enough: a late block only wastes its own time
   Cand* out = a.cand + (((size_t)b * a.nprobe + r) * a.n_slices + s) * a.kk;
   const uint32_t p = a.probes[(size_t)b * a.nprobe + r];
-  const uint32_t len = ix.plen[p];
+  const uint32_t len = p < ix.nlist ? ix.plen[p] : 0u;  // out-of-range probe ids (search_probes) are empty items
   const uint32_t v0 = s * a.slice_rows;
   if (v0 >= len) {  // nothing here: mark the slot empty
     for (uint32_t g = tid; g < a.kk; g += NTHREADS) {
@@ -450,8 +485,9 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
     return;
   }
   const uint32_t v1 = min(len, v0 + a.slice_rows);
-  float* lut = (float*)smem;                       // [m][256]
-  float* res = (float*)(smem + (size_t)ix.m * 1024);  // [dim]
+  const size_t lut_bytes = (size_t)ix.m * CB * 4;
+  float* lut = (float*)smem;                  // [m][CB]
+  float* res = (float*)(smem + lut_bytes);    // [dim]
   const float* q = a.qp + (size_t)b * ix.dim;
 
   // ---- K2: residual + distance table -------------------------------------
@@ -464,8 +500,8 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   __syncthreads();
   if (!(a.dbg & 1u)) {
     const uint32_t dsub = ix.dsub;
-    for (uint32_t e = tid; e < ix.m * 256u; e += NTHREADS) {
-      const uint32_t j = e >> 8;
+    for (uint32_t e = tid; e < ix.m * CB; e += NTHREADS) {
+      const uint32_t j = e / CB;
       const float* cb = ix.codebook + (size_t)e * dsub;  // [j][c][*], coalesced over c
       const float* rj = res + j * dsub;
       float acc = 0.f;
@@ -484,11 +520,9 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   __syncthreads();
 
   // ---- K3: ADC scan + K4 shuffle-free selection ----------------------------
-  constexpr int LR = KPL == 1 ? 2 : 5;  // per-wave list capacity 128 (kk<=64) or 320 (kk<=256)
-  ListEnt* lists = (ListEnt*)(smem + (size_t)ix.m * 1024 + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
-  uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);
-  WaveList<LR> wl;
-  wl.init(lists + (size_t)wid * LR * MI355_WAVE, a.kk);
+  ListEnt* lists = (ListEnt*)(smem + lut_bytes + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
+  uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);  // [NW]
+  PassFloor* s_floor = (PassFloor*)(((size_t)(s_cnt + NW) + 15) & ~(size_t)15);  // [1] (MULTI)
   const uint8_t* codes = ix.codes + ix.code_off[p];
   const uint32_t stride = ix.pstride[p];
   const uint32_t lrow0 = ix.lrow0[p];
@@ -498,144 +532,246 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   const bool ranged = a.range.has_lower || a.range.has_upper;
   typedef typename CodeVec<VPT>::type cvec;
 
-  // The trip count is block-uniform: the body uses wave collectives (ballots),
-  // so lanes past the end of the slice stay in the loop, re-read the slice's
-  // first rows (always mapped) and are masked out of the selection.
-  for (uint32_t base = v0; base < v1 && !(a.dbg & 2u); base += NTHREADS * VPT) {
-    const uint32_t i0r = base + tid * VPT;
-    const bool act = i0r < v1;
-    const uint32_t i0 = act ? i0r : v0;
-    float acc[VPT];
+  for (uint32_t pass_base = 0;; pass_base += SCAN_PASS_ROWS) {
+    const uint32_t kk_pass = MULTI ? min(a.kk - pass_base, SCAN_PASS_ROWS) : a.kk;
+    bool fl_on = false;
+    float fl_d = 0.f;
+    uint64_t fl_id = 0;
+    if (MULTI && pass_base) {
+      fl_on = true;
+      fl_d = s_floor->d;
+      fl_id = s_floor->id;
+    }
+    WaveList<LR> wl;
+    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass);
+
+    // The trip count is block-uniform: the body uses wave collectives (ballots),
+    // so lanes past the end of the slice stay in the loop, re-read the slice's
+    // first rows (always mapped) and are masked out of the selection.
+    for (uint32_t base = v0; base < v1 && !(a.dbg & 2u); base += NTHREADS * VPT) {
+      const uint32_t i0r = base + tid * VPT;
+      const bool act = i0r < v1;
+      const uint32_t i0 = act ? i0r : v0;
+      float acc[VPT];
 #pragma unroll
-    for (int e = 0; e < VPT; ++e) acc[e] = 0.f;
-    const uint8_t* col = codes + i0;
+      for (int e = 0; e < VPT; ++e) acc[e] = 0.f;
+      const uint8_t* col = codes + i0;
 #pragma unroll 8
-    for (uint32_t j = 0; j < ix.m; ++j) {
-      cvec cv = *(const cvec*)(col + (size_t)j * stride);
-      const float* t = lut + j * 256;
+      for (uint32_t jb = 0; jb < ix.mb; ++jb) {
+        cvec cv = *(const cvec*)(col + (size_t)jb * stride);
+        if (NBITS == 8) {
+          const float* t = lut + jb * 256;
 #pragma unroll
-      for (int e = 0; e < VPT; ++e) acc[e] = acc[e] + t[code_byte<VPT>(cv, e)];
-    }
-    if (a.dbg & 4u) {  // ablation: keep the distances live, skip the selection
-      float keep = 0.f;
+          for (int e = 0; e < VPT; ++e) acc[e] = acc[e] + t[code_byte<VPT>(cv, e)];
+        } else {  // sub-quantisers 2 jb (low nibble) then 2 jb + 1 (high nibble): j ascending
+          const float* t0 = lut + (2 * jb) * 16;
+          const float* t1 = t0 + 16;
 #pragma unroll
-      for (int e = 0; e < VPT; ++e) keep += acc[e];
-      if (keep == -1.2345f) out[0].d = keep;
-      continue;
-    }
-    // eligible rows: inside the slice, not NULL, inside the distance range
-    uint32_t elig = 0;
-    float lmin = __builtin_huge_valf();
+          for (int e = 0; e < VPT; ++e) {
+            const uint32_t by = code_byte<VPT>(cv, e);
+            acc[e] = acc[e] + t0[by & 15u];
+            acc[e] = acc[e] + t1[by >> 4];
+          }
+        }
+      }
+      if (a.dbg & 4u) {  // ablation: keep the distances live, skip the selection
+        float keep = 0.f;
 #pragma unroll
-    for (int e = 0; e < VPT; ++e) {
-      acc[e] = finalize_dist(acc[e], ix.metric, ix.m);
-      bool ok = act && (i0r + e < v1) && (ranged ? in_range(acc[e], a.range) : acc[e] == acc[e]);
-      elig |= ok ? (1u << e) : 0u;
-      lmin = ok ? fminf(lmin, acc[e]) : lmin;
-    }
-    // threshold: kk-th smallest lane minimum (>= kk rows of this wave are below it)
-    float thr = wl.t_run;
-    // (with a prefilter the lane minima include rows the filter may drop: only the list's own
-    //  running threshold, built from permitted rows, is a valid bound)
-    if (a.kk <= MI355_WAVE && a.filter.mode == MI355_FILTER_NONE) {
-      uint32_t tk = wave_kth_smallest_key(elig ? f32_sort_key(lmin) : 0xFFFFFFFFu, a.kk);
-      if (tk < 0xFF800000u) thr = fminf(thr, f32_from_sort_key(tk));  // below +inf's key
-    }
-    bool any = false;
-#pragma unroll
-    for (int e = 0; e < VPT; ++e) any |= ((elig >> e) & 1u) && acc[e] <= thr;
-    if (__any(any)) {
+        for (int e = 0; e < VPT; ++e) keep += acc[e];
+        if (keep == -1.2345f) out[0].d = keep;
+        continue;
+      }
+      // eligible rows: inside the slice, not NULL, inside the distance range (and above the pass floor)
+      uint32_t elig = 0;
+      float lmin = __builtin_huge_valf();
 #pragma unroll
       for (int e = 0; e < VPT; ++e) {
-        bool take = ((elig >> e) & 1u) && acc[e] <= thr;
-        if (a.filter.mode != MI355_FILTER_NONE && take) take = row_permitted(idof(lrow0 + i0r + e), a.filter);
-        wl.append(take, acc[e], lrow0 + i0r + e, thr, lane, idof);
+        acc[e] = finalize_dist(acc[e], ix.metric, ix.m);
+        bool ok = act && (i0r + e < v1) && (ranged ? in_range(acc[e], a.range) : acc[e] == acc[e]);
+        if (MULTI && fl_on && ok) {
+          ok = acc[e] > fl_d;
+          if (acc[e] == fl_d) ok = idof(lrow0 + i0r + e) > fl_id;  // ties on the floor distance: rare
+        }
+        elig |= ok ? (1u << e) : 0u;
+        lmin = ok ? fminf(lmin, acc[e]) : lmin;
       }
-    }
-  }
-
-  // ---- block result: exact kk best of all waves' lists, written sorted -----
-  if (wl.cnt > a.kk) wl.compact(lane, idof);
-  if (lane == 0) s_cnt[wid] = wl.cnt;
-  __syncthreads();
-  uint32_t total = 0;
+      // threshold: kk-th smallest lane minimum (>= kk rows of this wave are below it)
+      float thr = wl.t_run;
+      // (with a prefilter the lane minima include rows the filter may drop: only the list's own
+      //  running threshold, built from permitted rows, is a valid bound)
+      if (kk_pass <= MI355_WAVE && a.filter.mode == MI355_FILTER_NONE) {
+        uint32_t tk = wave_kth_smallest_key(elig ? f32_sort_key(lmin) : 0xFFFFFFFFu, kk_pass);
+        if (tk < 0xFF800000u) thr = fminf(thr, f32_from_sort_key(tk));  // below +inf's key
+      }
+      bool any = false;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) total += s_cnt[w];
-  const uint32_t n_out = min(total, a.kk);
-  for (uint32_t g = tid; g < (uint32_t)NW * a.kk; g += NTHREADS) {
-    const uint32_t w = g / a.kk, j = g % a.kk;
-    if (j >= s_cnt[w]) continue;
-    const ListEnt mine = lists[(size_t)w * LR * MI355_WAVE + j];
-    uint32_t rank = 0;
-    for (int w2 = 0; w2 < NW; ++w2) {
-      const ListEnt* l2 = lists + (size_t)w2 * LR * MI355_WAVE;
-      const uint32_t c2 = s_cnt[w2];
-      for (uint32_t j2 = 0; j2 < c2; ++j2) {
-        const ListEnt c = l2[j2];
-        bool lt = c.d < mine.d;
-        if (c.d == mine.d && c.pos != mine.pos) lt = idof(c.pos) < idof(mine.pos);
-        rank += lt ? 1u : 0u;
+      for (int e = 0; e < VPT; ++e) any |= ((elig >> e) & 1u) && acc[e] <= thr;
+      if (__any(any)) {
+#pragma unroll
+        for (int e = 0; e < VPT; ++e) {
+          bool take = ((elig >> e) & 1u) && acc[e] <= thr;
+          if (a.filter.mode != MI355_FILTER_NONE && take) take = row_permitted(idof(lrow0 + i0r + e), a.filter);
+          wl.append(take, acc[e], lrow0 + i0r + e, thr, lane, idof);
+        }
       }
     }
-    if (rank < a.kk) {
-      Cand o;
-      o.d = mine.d;
-      o.pos = mine.pos;
-      o.id = idof(mine.pos);
-      out[rank] = o;
+
+    // ---- block result: exact kk_pass best of all waves' lists, written sorted -----
+    if (wl.cnt > kk_pass) wl.compact(lane, idof);
+    if (lane == 0) s_cnt[wid] = wl.cnt;
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) total += s_cnt[w];
+    const uint32_t n_out = min(total, kk_pass);
+    for (uint32_t g = tid; g < (uint32_t)NW * kk_pass; g += NTHREADS) {
+      const uint32_t w = g / kk_pass, j = g % kk_pass;
+      if (j >= s_cnt[w]) continue;
+      const ListEnt mine = lists[(size_t)w * LR * MI355_WAVE + j];
+      uint32_t rank = 0;
+      for (int w2 = 0; w2 < NW; ++w2) {
+        const ListEnt* l2 = lists + (size_t)w2 * LR * MI355_WAVE;
+        const uint32_t c2 = s_cnt[w2];
+        for (uint32_t j2 = 0; j2 < c2; ++j2) {
+          const ListEnt c = l2[j2];
+          bool lt = c.d < mine.d;
+          if (c.d == mine.d && c.pos != mine.pos) lt = idof(c.pos) < idof(mine.pos);
+          rank += lt ? 1u : 0u;
+        }
+      }
+      if (rank < kk_pass) {
+        Cand o;
+        o.d = mine.d;
+        o.pos = mine.pos;
+        o.id = idof(mine.pos);
+        out[pass_base + rank] = o;
+        if (MULTI && rank == kk_pass - 1) {  // the next pass starts strictly above this row
+          s_floor->d = o.d;
+          s_floor->id = o.id;
+          s_floor->on = 1;
+        }
+      }
     }
-  }
-  for (uint32_t g = n_out + tid; g < a.kk; g += NTHREADS) {
-    Cand o;
-    o.d = __builtin_huge_valf();
-    o.pos = CAND_EMPTY_POS;
-    o.id = ~0ull;
-    out[g] = o;
+    const bool more = MULTI && total >= kk_pass && pass_base + kk_pass < a.kk;
+    if (!more) {
+      for (uint32_t g = pass_base + n_out + tid; g < a.kk; g += NTHREADS) {
+        Cand o;
+        o.d = __builtin_huge_valf();
+        o.pos = CAND_EMPTY_POS;
+        o.id = ~0ull;
+        out[g] = o;
+      }
+      break;
+    }
+    __syncthreads();  // the floor is published; the lists are rebuilt by the next pass
   }
 }
 
 // ------------------------------------------------------------------ K4 -----
-// Per-query reducer: one wave scans the query's n_src*kk candidate slots and
-// writes the k_out best in (distance, rowid) order.
+// Per-query reducer: one wave scans the query's candidate slots and writes the k_out best in
+// (distance, rowid) order; any k_out (k_out > 64 * KPL re-reads the slots once per pass of
+// 64 * KPL rows, device_common.h wave_select_sorted).  Source s of query b starts at
+// cand + s * src_stride + b * q_stride (scan output: [nq][n_src][kk]; gathered shard lists:
+// [world][nq][kk]).
 struct MergeArgs {
-  const Cand* cand;   // [nq, n_src, kk_in]
+  const Cand* cand;
   uint32_t n_src, kk_in;
+  uint64_t src_stride, q_stride;  // in Cand records
+  const uint32_t* src_cnt;  // valid entries per (source, query) at src_cnt[s * cnt_stride + b], or nullptr
+                            // (= kk_in, empties marked by pos)
+  uint64_t cnt_stride;      // u32 words between two sources' count arrays
+  uint32_t nq;
   uint32_t k_out;     // rows written per query (k, or k*refine_factor)
-  uint64_t* out_ids;  // [nq, k_out]
-  float* out_dist;    // [nq, k_out]
+  uint64_t* out_ids;  // [nq, k_out] or nullptr
+  float* out_dist;    // [nq, k_out] or nullptr
   uint32_t* out_pos;  // [nq, k_out] or nullptr
+  uint32_t* out_owner;  // [nq, k_out] source index of each winner, or nullptr
+  Cand* out_cand;     // [nq, k_out] packed records (distance, pos, id), or nullptr
   uint32_t* out_cnt;  // [nq]
+  const DevCtl* ctl;  // deadline flag (nullptr = none)
 };
+
+// the scan's own layout: cand [nq][n_src][kk_in], empty slots marked by pos
+static inline MergeArgs merge_args_dense(const Cand* cand, uint32_t n_src, uint32_t kk_in, uint32_t nq, uint32_t k_out) {
+  MergeArgs m;
+  m.cand = cand;
+  m.n_src = n_src;
+  m.kk_in = kk_in;
+  m.src_stride = kk_in;
+  m.q_stride = (uint64_t)n_src * kk_in;
+  m.src_cnt = nullptr;
+  m.cnt_stride = nq;
+  m.nq = nq;
+  m.k_out = k_out;
+  m.out_ids = nullptr;
+  m.out_dist = nullptr;
+  m.out_pos = nullptr;
+  m.out_owner = nullptr;
+  m.out_cand = nullptr;
+  m.out_cnt = nullptr;
+  m.ctl = nullptr;
+  return m;
+}
 
 template <int KPL>
 __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
-  WaveTopK<KPL> top;
-  top.init(a.k_out, lane);
-  const Cand* src = a.cand + (size_t)b * a.n_src * a.kk_in;
+  if (a.ctl && a.ctl->timed_out) return;
+  const Cand* src = a.cand + (size_t)b * a.q_stride;
   const uint32_t n = a.n_src * a.kk_in;
-  for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
-    uint32_t t = t0 + lane;
-    Cand c;
-    c.d = 0.f;
-    c.pos = CAND_EMPTY_POS;
-    c.id = 0;
-    if (t < n) c = src[t];
-    top.offer(t < n && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
-  }
-  uint64_t* oi = a.out_ids + (size_t)b * a.k_out;
-  float* od = a.out_dist + (size_t)b * a.k_out;
+  uint64_t* oi = a.out_ids ? a.out_ids + (size_t)b * a.k_out : nullptr;
+  float* od = a.out_dist ? a.out_dist + (size_t)b * a.k_out : nullptr;
   uint32_t* op = a.out_pos ? a.out_pos + (size_t)b * a.k_out : nullptr;
+  uint32_t* oo = a.out_owner ? a.out_owner + (size_t)b * a.k_out : nullptr;
+  Cand* oc = a.out_cand ? a.out_cand + (size_t)b * a.k_out : nullptr;
   for (uint32_t g = lane; g < a.k_out; g += MI355_WAVE) {
-    oi[g] = ~0ull;
-    od[g] = __builtin_huge_valf();
+    if (oi) oi[g] = ~0ull;
+    if (od) od[g] = __builtin_huge_valf();
     if (op) op[g] = CAND_EMPTY_POS;
+    if (oo) oo[g] = 0xFFFFFFFFu;
+    if (oc) {
+      Cand e;
+      e.d = __builtin_huge_valf();
+      e.pos = CAND_EMPTY_POS;
+      e.id = ~0ull;
+      oc[g] = e;
+    }
   }
-  uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t pos, uint64_t id) {
-    oi[rk] = id;
-    od[rk] = d;
+  // `pos` travels through the selector as the candidate's slot index t (source = t / kk_in)
+  auto gen = [&](WaveTopK<KPL>& top) {
+    for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
+      const uint32_t t = t0 + lane;
+      Cand c;
+      c.d = 0.f;
+      c.pos = CAND_EMPTY_POS;
+      c.id = 0;
+      bool ok = false;
+      if (t < n) {
+        const uint32_t sidx = t / a.kk_in, i = t % a.kk_in;
+        const uint32_t lim = a.src_cnt ? min(a.src_cnt[(size_t)sidx * a.cnt_stride + b], a.kk_in) : a.kk_in;
+        if (i < lim) {
+          c = src[(size_t)sidx * a.src_stride + i];
+          ok = c.pos != CAND_EMPTY_POS && c.d == c.d;
+        }
+      }
+      top.offer(ok, c.d, t, c.id, lane);
+    }
+  };
+  const uint32_t n_out = wave_select_sorted<KPL>(a.k_out, lane, gen, [&](uint32_t rk, float d, uint32_t t, uint64_t id) {
+    const uint32_t sidx = t / a.kk_in, i = t % a.kk_in;
+    const uint32_t pos = src[(size_t)sidx * a.src_stride + i].pos;
+    if (oi) oi[rk] = id;
+    if (od) od[rk] = d;
     if (op) op[rk] = pos;
+    if (oo) oo[rk] = sidx;
+    if (oc) {
+      Cand e;
+      e.d = d;
+      e.pos = pos;
+      e.id = id;
+      oc[rk] = e;
+    }
   });
   if (lane == 0) a.out_cnt[b] = n_out;
 }
@@ -651,33 +787,33 @@ __global__ __launch_bounds__(64) void k_merge_lists(const uint64_t* __restrict__
                                                     uint32_t* __restrict__ out_cnt) {
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
-  WaveTopK<KPL> top;
-  top.init(k, lane);
   const uint32_t n = n_lists * k;
-  for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
-    uint32_t t = t0 + lane;
-    bool ok = false;
-    float d = 0.f;
-    uint64_t id = 0;
-    if (t < n) {
-      uint32_t l = t / k, i = t % k;
-      uint32_t cnt = min(in_cnt[(size_t)l * nq + b], k);
-      if (i < cnt) {
-        size_t o = ((size_t)l * nq + b) * k + i;
-        d = in_dist[o];
-        id = in_ids[o];
-        ok = d == d;
-      }
-    }
-    top.offer(ok, d, 0u, id, lane);
-  }
   uint64_t* oi = out_ids + (size_t)b * k;
   float* od = out_dist + (size_t)b * k;
   for (uint32_t g = lane; g < k; g += MI355_WAVE) {
     oi[g] = ~0ull;
     od[g] = __builtin_huge_valf();
   }
-  uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
+  auto gen = [&](WaveTopK<KPL>& top) {
+    for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
+      uint32_t t = t0 + lane;
+      bool ok = false;
+      float d = 0.f;
+      uint64_t id = 0;
+      if (t < n) {
+        uint32_t l = t / k, i = t % k;
+        uint32_t cnt = min(in_cnt[(size_t)l * nq + b], k);
+        if (i < cnt) {
+          size_t o = ((size_t)l * nq + b) * k + i;
+          d = in_dist[o];
+          id = in_ids[o];
+          ok = d == d;
+        }
+      }
+      top.offer(ok, d, 0u, id, lane);
+    }
+  };
+  const uint32_t n_out = wave_select_sorted<KPL>(k, lane, gen, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
     oi[rk] = id;
     od[rk] = d;
   });
@@ -751,30 +887,31 @@ __device__ __forceinline__ float exact_distance(const float* __restrict__ q, con
   return dist_finish(a, metric, qq);
 }
 
-// Refine (query.rs:1313-1317): exact distance for the kk approximate winners,
-// range filter on the exact distance, (distance, rowid) sort, keep k.  One
-// 256-thread block per query; the final selection runs on wave 0.
+// Refine (query.rs:1313-1317): exact distance for the kk approximate winners, range filter
+// on the exact distance; the (distance, rowid) sort + keep k is k_merge_cands over the
+// records written here (any kk).  grid = (ceil(kk / 256), nq); a thread per candidate.
+// `owner` (sharded search): only candidates whose raw vector lives on this rank are refined,
+// the others stay empty and arrive through the second all-gather from their owner.
 struct RefineArgs {
   IndexView ix;
   const float* q;          // ORIGINAL queries [nq, dim]
-  const uint64_t* in_ids;  // [nq, kk]
-  const uint32_t* in_pos;  // [nq, kk]
+  const Cand* in;          // [nq, kk] ANN winners (pos = local row position on the OWNING handle)
   const uint32_t* in_cnt;  // [nq]
-  uint32_t kk, k;
+  const uint32_t* in_owner;  // [nq, kk] or nullptr (everything is local)
+  uint32_t my_rank;
+  uint32_t kk;
   RangeFilter range;
-  uint64_t* out_ids;  // [nq, k]
-  float* out_dist;
-  uint32_t* out_cnt;
+  Cand* out;               // [nq, kk]
+  const DevCtl* ctl;
 };
 
-template <int KPL>
-__global__ __launch_bounds__(256) void k_refine(RefineArgs a) {
+static __global__ __launch_bounds__(256) void k_refine_dist(RefineArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* sq = (float*)smem;                          // [dim]
-  Cand* sc = (Cand*)(smem + (((size_t)a.ix.dim * 4 + 15) & ~(size_t)15));  // [kk]
+  float* sq = (float*)smem;  // [dim]
   __shared__ float s_qq;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const uint32_t b = blockIdx.y;
+  if (a.ctl && a.ctl->timed_out) return;
   const float* q = a.q + (size_t)b * a.ix.dim;
   for (uint32_t d = tid; d < a.ix.dim; d += 256) sq[d] = q[d];
   __syncthreads();
@@ -785,47 +922,65 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a) {
   }
   __syncthreads();
   const uint32_t cnt = min(a.in_cnt[b], a.kk);
-  for (uint32_t c = tid; c < a.kk; c += 256) {
-    Cand o;
-    o.d = __builtin_huge_valf();
-    o.pos = CAND_EMPTY_POS;
-    o.id = ~0ull;
-    if (c < cnt) {
-      uint32_t pos = a.in_pos[(size_t)b * a.kk + c];
-      float d = exact_distance(sq, a.ix.raw, a.ix.raw_dtype, pos, a.ix.dim, a.ix.metric, s_qq);
+  const uint32_t c = blockIdx.x * 256 + tid;
+  if (c >= a.kk) return;
+  Cand o;
+  o.d = __builtin_huge_valf();
+  o.pos = CAND_EMPTY_POS;
+  o.id = ~0ull;
+  if (c < cnt && (!a.in_owner || a.in_owner[(size_t)b * a.kk + c] == a.my_rank)) {
+    const Cand in = a.in[(size_t)b * a.kk + c];
+    if (in.pos != CAND_EMPTY_POS) {
+      const uint64_t rrow = a.ix.raw_by_global ? global_pos_of(a.ix, in.pos) : (uint64_t)in.pos;
+      const float d = exact_distance(sq, a.ix.raw, a.ix.raw_dtype, rrow, a.ix.dim, a.ix.metric, s_qq);
       if (in_range(d, a.range)) {
         o.d = d;
-        o.pos = pos;
-        o.id = a.in_ids[(size_t)b * a.kk + c];
+        o.pos = in.pos;
+        o.id = in.id;
       }
     }
-    sc[c] = o;
   }
-  __syncthreads();
-  if (tid < 64) {
-    WaveTopK<KPL> top;
-    top.init(a.k, lane);
-    for (uint32_t t0 = 0; t0 < a.kk; t0 += MI355_WAVE) {
-      uint32_t t = t0 + lane;
-      Cand c;
-      c.d = 0.f;
-      c.pos = CAND_EMPTY_POS;
-      c.id = 0;
-      if (t < a.kk) c = sc[t];
-      top.offer(t < a.kk && c.pos != CAND_EMPTY_POS, c.d, c.pos, c.id, lane);
-    }
-    uint64_t* oi = a.out_ids + (size_t)b * a.k;
-    float* od = a.out_dist + (size_t)b * a.k;
-    for (uint32_t g = lane; g < a.k; g += MI355_WAVE) {
-      oi[g] = ~0ull;
-      od[g] = __builtin_huge_valf();
-    }
-    uint32_t n_out = top.drain_sorted(lane, [&](uint32_t rk, float d, uint32_t, uint64_t id) {
-      oi[rk] = id;
-      od[rk] = d;
-    });
-    if (lane == 0) a.out_cnt[b] = n_out;
+  a.out[(size_t)b * a.kk + c] = o;
+}
+
+// arrays-of-fields result lists ([nq, k] ids / distances + [nq] counts) -> packed Cand records
+// (the record the sharded search all-gathers); pos carries the slot index
+static __global__ void k_pack_cands(const uint64_t* __restrict__ ids, const float* __restrict__ dist,
+                                    const uint32_t* __restrict__ cnt, uint32_t nq, uint32_t k, Cand* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * k) return;
+  const uint32_t b = i / k, r = i % k;
+  Cand c;
+  c.d = __builtin_huge_valf();
+  c.pos = CAND_EMPTY_POS;
+  c.id = ~0ull;
+  if (r < min(cnt[b], k)) {
+    c.d = dist[i];
+    c.pos = r;
+    c.id = ids[i];
   }
+  out[i] = c;
+}
+
+// maximum_nprobes expansion: the short queries' vectors gathered into a dense batch, and their
+// second-pass results written back over the first pass's rows
+static __global__ __launch_bounds__(256) void k_gather_rows_f32(const float* __restrict__ src, const uint32_t* __restrict__ rows,
+                                                              uint32_t dim, float* __restrict__ dst) {
+  const float* s = src + (size_t)rows[blockIdx.x] * dim;
+  float* d = dst + (size_t)blockIdx.x * dim;
+  for (uint32_t i = threadIdx.x; i < dim; i += 256) d[i] = s[i];
+}
+
+static __global__ __launch_bounds__(64) void k_scatter_results(const uint32_t* __restrict__ rows, uint32_t k,
+                                                              const uint64_t* __restrict__ s_ids, const float* __restrict__ s_dist,
+                                                              const uint32_t* __restrict__ s_cnt, uint64_t* __restrict__ ids,
+                                                              float* __restrict__ dist, uint32_t* __restrict__ cnt) {
+  const uint32_t i = blockIdx.x, q = rows[i];
+  for (uint32_t g = threadIdx.x; g < k; g += 64) {
+    ids[(size_t)q * k + g] = s_ids[(size_t)i * k + g];
+    dist[(size_t)q * k + g] = s_dist[(size_t)i * k + g];
+  }
+  if (threadIdx.x == 0) cnt[q] = s_cnt[i];
 }
 
 // ------------------------------------------------------- index packing -----
@@ -845,7 +1000,7 @@ struct RepackArgs {
   uint32_t transposed;
 };
 
-__global__ __launch_bounds__(256) void k_repack_codes(RepackArgs a) {
+static __global__ __launch_bounds__(256) void k_repack_codes(RepackArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [64][m+1]
   const uint32_t p = a.part_ids[blockIdx.y];
   const uint32_t len = a.plen[p], stride = a.pstride[p];

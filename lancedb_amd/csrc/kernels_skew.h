@@ -140,7 +140,7 @@ struct SkewPackArgs {
   uint32_t transposed;        // source layout: 1 = [m][len] per partition, 0 = [len][m]
 };
 
-__global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
+static __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [2][64][m+1]
   const uint32_t p = a.part_ids[blockIdx.y];
   const uint32_t len = a.plen[p];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
 
 // codebook [m][256][dsub] -> [256][m][dsub]: the LUT builder then walks
 // consecutive j with consecutive lanes (coalesced reads, conflict-free writes)
-__global__ void k_transpose_codebook(const float* __restrict__ cb, uint32_t m, uint32_t dsub,
+static __global__ void k_transpose_codebook(const float* __restrict__ cb, uint32_t m, uint32_t dsub,
                                      float* __restrict__ out) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // over m*256*dsub
   const uint32_t total = m * 256u * dsub;
@@ -239,11 +239,11 @@ struct PlanArgs {
   uint32_t kk;
 };
 
-__global__ void k_plan_count(PlanArgs a) {
+static __global__ void k_plan_count(PlanArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_pairs) return;
   const uint32_t p = a.probes[i];
-  if (a.plen[p])
+  if (p < a.nlist && a.plen[p])  // ids outside the index (mi355_search_probes) are empty items
     atomicAdd(&a.cnt[p], 1u);
   else {  // empty / not owned here: no work item, the slot is empty
     Cand c;
@@ -255,7 +255,7 @@ __global__ void k_plan_count(PlanArgs a) {
 }
 
 // one 1024-thread block: exclusive scan of cnt[] in `order`
-__global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
+static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
   __shared__ uint32_t s_part[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (a.nlist + 1023u) / 1024u;
@@ -291,11 +291,11 @@ __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
   if (tid < 8) a.heads[tid * SK_HEAD_STRIDE] = 0;
 }
 
-__global__ void k_plan_fill(PlanArgs a) {
+static __global__ void k_plan_fill(PlanArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_pairs) return;
   const uint32_t p = a.probes[i];
-  const uint32_t len = a.plen[p];
+  const uint32_t len = p < a.nlist ? a.plen[p] : 0u;
   if (!len) return;
   SkewItem it;
   it.pair = i;
@@ -322,6 +322,7 @@ struct SkewArgs {
   RowFilter filter;
   Cand* cand;               // [nq * nprobe][kk]
   uint32_t dbg;
+  DevCtl* ctl;              // deadline / counters of the call
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -344,6 +345,7 @@ __device__ __forceinline__ void skew_plain_chunks(const uint4 (&cv)[CPT], uint32
 // workgroup currently drains (its own XCD's first, then the others in ring
 // order).  Returns the global item index or SK_NONE when every queue is dry.
 __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_t* s_q, uint32_t& q, uint32_t& tried) {
+  if (ctl_expired(a.ctl)) tried = 8;  // QueryExecutionOptions.timeout: stop taking work items
   while (tried < 8) {
     const uint32_t q0 = s_q[q], n = s_q[q + 1] - q0;
     uint32_t* head = a.heads + q * SK_HEAD_STRIDE;
@@ -357,7 +359,11 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
   return SK_NONE;
 }
 
-template <int M, int LR, int NT>
+// MULTI: kk > 256 — a work item's rows are selected in passes of SCAN_PASS_ROWS (the codes are
+// re-scanned per pass against the table built once; pass p keeps the best rows strictly above the
+// last row of pass p-1 in the (distance, rowid) order).  MULTI = false compiles to the single-pass
+// kernel unchanged.
+template <int M, int LR, int NT, bool MULTI>
 __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / MI355_WAVE;
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   uint32_t* s_thr = s_cnt + NW;                               // [1] block threshold (sort key)
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
   SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
+  PassFloor* s_floor = (PassFloor*)(s_rec + 2);                          // [1] (MULTI)
   // the gather address is (code << 9) | column bytes: the table must start at LDS address 0
   if ((uint32_t)(size_t)smem != 0u) __builtin_trap();
   const uint32_t lb = 4u * (32u - lm);  // this lane's column origin (bytes)
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
 
     // ---- pop the NEXT item now; its index arrives behind the LUT phase's loads
     uint32_t pf = SK_NONE, pf_q0 = 0, pf_n = 0;
+    if (tid == 0 && q_tried < 8 && ctl_expired(a.ctl)) q_tried = 8;
     if (tid == 0 && q_tried < 8) {
       pf_q0 = s_q[q_cur];
       pf_n = s_q[q_cur + 1] - pf_q0;
@@ -542,12 +550,24 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     __syncthreads();
 
     // ---- K3 + K4: skewed ADC scan, one stream per wave ----------------------
-    WaveList<LR> wl;
-    wl.init(lists + (size_t)wid * LR * MI355_WAVE, a.kk);
     auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
-    float thr = f32_from_sort_key(*s_thr);
-    if (*s_thr == 0xFFFFFFFFu) thr = __builtin_huge_valf();
     const uint8_t* pcodes = ix.codes + code_off;
+    const uint32_t thr0_key = *s_thr;  // the query's bound when this item started (valid for every pass)
+    for (uint32_t pass_base = 0;; pass_base += SCAN_PASS_ROWS) {
+    const uint32_t kk_pass = MULTI ? min(a.kk - pass_base, SCAN_PASS_ROWS) : a.kk;
+    const bool last_known = !MULTI;  // single pass: the item's tail work overlaps the merge below
+    bool fl_on = false;
+    float fl_d = 0.f;
+    uint64_t fl_id = 0;
+    if (MULTI && pass_base) {
+      fl_on = true;
+      fl_d = s_floor->d;
+      fl_id = s_floor->id;
+    }
+    WaveList<LR> wl;
+    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass);
+    float thr = f32_from_sort_key(thr0_key);
+    if (thr0_key == 0xFFFFFFFFu) thr = __builtin_huge_valf();
 
     // a finished row: tile position tp of stream w, this lane's row
     float published = __builtin_huge_valf();
@@ -555,6 +575,11 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       const uint32_t row = (w + SK_STREAMS * tp) * SK_TILE + lane;  // w = stream index
       const float d = finalize_dist(acc, ix.metric, ix.m);
       bool ok = row < len && (ranged ? in_range(d, a.range) : d == d);
+      if (MULTI && fl_on) {  // strictly above the previous pass's last row
+        const bool tie = ok && d == fl_d;
+        ok = ok && d >= fl_d;
+        if (__any(tie) && tie) ok = idof(lrow0 + row) > fl_id;
+      }
       // tightened by the other waves' compactions
       const uint32_t bk = __hip_atomic_load(s_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (bk != 0xFFFFFFFFu) thr = fminf(thr, f32_from_sort_key(bk));
@@ -675,11 +700,11 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
 
 #endif
 
-    // ---- block result: exact kk best of all waves' lists, written sorted ----
-    if (wl.cnt > a.kk) wl.compact(lane, idof);
+    // ---- block result: exact kk_pass best of all waves' lists, written sorted ----
+    if (wl.cnt > kk_pass) wl.compact(lane, idof);
     if (lane == 0) s_cnt[wid] = wl.cnt;
-    if (tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) {
-      if (!nxt_valid) {  // the prefetch ran off the end of its queue: move on (rare, synchronous)
+    auto next_item_fallback = [&]() {  // thread 0: the prefetch ran off the end of its queue (rare, synchronous)
+      if (!nxt_valid) {
         if (q_tried < 8) {
           q_cur = (q_cur + 1) & 7u;
           ++q_tried;
@@ -689,16 +714,17 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         if (gi != SK_NONE) nxt = a.items[gi];
       }
       s_rec[slot ^ 1u] = nxt;
-    }
+    };
+    if (last_known && tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) next_item_fallback();
     __syncthreads();
     // the next item's residual operands travel while this item's lists are merged
-    if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
+    if (last_known && s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     uint32_t total = 0;
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) total += s_cnt[w2];
-    const uint32_t n_out = min(total, a.kk);
-    for (uint32_t g = tid; g < (uint32_t)NW * a.kk; g += NT) {
-      const uint32_t w = g / a.kk, j = g % a.kk;
+    const uint32_t n_out = min(total, kk_pass);
+    for (uint32_t g = tid; g < (uint32_t)NW * kk_pass; g += NT) {
+      const uint32_t w = g / kk_pass, j = g % kk_pass;
       if (j >= s_cnt[w]) continue;
       const ListEnt mine = lists[(size_t)w * LR * MI355_WAVE + j];
       uint32_t rank = 0;
@@ -712,22 +738,51 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
           rank += lt ? 1u : 0u;
         }
       }
-      if (rank < a.kk) {
+      if (rank < kk_pass) {
         Cand o;
         o.d = mine.d;
         o.pos = mine.pos;
         o.id = idof(mine.pos);
-        out[rank] = o;
+        out[pass_base + rank] = o;
         // kk rows at or below mine.d exist: a bound for every other partition of this query
-        if (rank == a.kk - 1) atomicMin(a.qthr + b, f32_sort_key(mine.d));
+        if (pass_base + rank == a.kk - 1) atomicMin(a.qthr + b, f32_sort_key(mine.d));
+        if (MULTI && rank == kk_pass - 1) {  // the next pass starts strictly above this row
+          s_floor->d = o.d;
+          s_floor->id = o.id;
+          s_floor->on = 1;
+        }
       }
     }
-    for (uint32_t g = n_out + tid; g < a.kk; g += NT) {
-      Cand o;
-      o.d = __builtin_huge_valf();
-      o.pos = CAND_EMPTY_POS;
-      o.id = ~0ull;
-      out[g] = o;
+    const bool more = MULTI && total >= kk_pass && pass_base + kk_pass < a.kk;
+    if (!more) {
+      for (uint32_t g = pass_base + n_out + tid; g < a.kk; g += NT) {
+        Cand o;
+        o.d = __builtin_huge_valf();
+        o.pos = CAND_EMPTY_POS;
+        o.id = ~0ull;
+        out[g] = o;
+      }
+      break;
+    }
+    __syncthreads();  // the floor is published; the lists and the block threshold are rebuilt
+    if (tid == 0) *s_thr = thr0_key;
+    __syncthreads();
+    }  // passes
+    if (MULTI) {  // the tail work of the item, once (it overlaps the merge in the single-pass kernel)
+      if (tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) {
+        if (!nxt_valid) {
+          if (q_tried < 8) {
+            q_cur = (q_cur + 1) & 7u;
+            ++q_tried;
+          }
+          const uint32_t gi = sk_pop_sync(a, s_q, q_cur, q_tried);
+          nxt.pair = SK_NONE;
+          if (gi != SK_NONE) nxt = a.items[gi];
+        }
+        s_rec[slot ^ 1u] = nxt;
+      }
+      __syncthreads();
+      if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     }
     __syncthreads();  // LDS is rebuilt by the next item
   }

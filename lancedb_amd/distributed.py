@@ -4,82 +4,117 @@ SURVEY.md §8e: a query's result is the top-k of the union of its probed
 partitions, and partitions are scanned independently, so the partition list
 shards with no data-path exchange until the very end: every rank scans the
 probed partitions it owns (`IvfPqIndex(shard_count=world, shard_rank=rank)`,
-the deterministic `mi355_shard_plan`), then ONE all-gather of the per-rank
-`[B, k]` candidates (RCCL over xGMI when the tensors are on the GPU; 120 B per
-query per rank at k = 10, latency-bound) and a k-way merge on every rank
-(`mi355_merge_topk`).  The coarse quantiser is replicated.
+the deterministic `mi355_shard_plan`), then ONE packed all-gather of the per-rank
+candidate records (RCCL over xGMI, 160 B per query per rank at k = 10:
+latency-bound) and a k-way merge on every rank.
 
-`torch.distributed` is plumbing only; the reference has no collective at all
-(no communication backend), this exchange is the engine's own.
+The whole exchange lives behind the C ABI (`mi355_comm_*`,
+`mi355_search_sharded` in include/mi355_ann.h, csrc/ann_comm.hip): this module
+is a ctypes veneer, so a Rust host needs nothing from Python.
+The 128-byte communicator id travels over whatever channel the host already has;
+`exchange_id_via_file` is the dependency-free option used by the launcher test.
+The reference has no collective at all, this exchange is the
+engine's own.
 """
-from .index import SearchResult, merge_topk
+import ctypes as C
+import os
+import time
+
+from . import _abi
+from ._lib import check, lib
+from .index import SearchResult, _Handle, _run_search
 
 
 def coarse_slice(nlist, world, rank):
     """Centroid slice a rank scores in the two-phase search (contiguous, balanced)."""
-    return (nlist * rank) // world, (nlist * (rank + 1)) // world
+    lo, hi = C.c_uint32(0), C.c_uint32(0)
+    check(lib().mi355_coarse_slice(C.c_uint32(nlist), C.c_uint32(world), C.c_uint32(rank), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def unique_id():
+    """Rank 0: a fresh communicator id (ncclGetUniqueId), 128 bytes."""
+    buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+    check(lib().mi355_comm_unique_id(buf))
+    return buf.raw
+
+
+def exchange_id_via_file(path, rank, timeout_s=120.0):
+    """Rank 0 writes the id to `path` (atomically), the others wait for it."""
+    if rank == 0:
+        uid = unique_id()
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == _abi.COMM_ID_BYTES:
+                return uid
+        except OSError:
+            pass
+        time.sleep(0.02)
+    raise TimeoutError(f"no communicator id at {path} after {timeout_s} s")
+
+
+class Comm(_Handle):
+    """One rank's RCCL communicator (mi355_comm_create is collective: every rank calls it)."""
+    _close_fn = "mi355_comm_destroy"
+
+    def __init__(self, uid, rank, world, device=0):
+        super().__init__()
+        if len(uid) != _abi.COMM_ID_BYTES:
+            raise ValueError(f"communicator id must be {_abi.COMM_ID_BYTES} bytes")
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        check(lib().mi355_comm_create(C.c_char_p(uid), C.c_uint32(rank), C.c_uint32(world), C.c_int32(device),
+                                      C.byref(self._h)))
+
+    def stats(self):
+        """Load report of the last sharded search (identical on every rank): per-rank scanned
+        rows, max/mean imbalance, all-gathers issued and bytes received."""
+        s = _abi.CommStats()
+        s.struct_size = C.sizeof(_abi.CommStats)
+        check(lib().mi355_comm_last_stats(self._h, C.byref(s)))
+        return {"world": s.world, "rank": s.rank, "n_gathers": s.n_gathers, "bytes_gathered": s.bytes_gathered,
+                "rows_scanned": [int(s.rows_scanned[r]) for r in range(s.world)], "imbalance": float(s.imbalance)}
 
 
 class ShardedSearcher:
-    """Wraps one rank's shard handle.  `index.search(queries, params, out=...)`
-    must return a SearchResult of tensors living where the process group's
-    backend can reach them (CUDA tensors for nccl/RCCL)."""
+    """`index` is this rank's shard handle (`IvfPqIndex(shard_count=world, shard_rank=rank)`).
+    `search` is collective; its result is identical on every rank and identical to the
+    unsharded search — including `refine_factor` (the global k * refine_factor ANN
+    candidates are merged first, then every rank refines the ones whose raw vectors it
+    owns) and `maximum_nprobes`."""
 
-    def __init__(self, index, group=None, merge=merge_topk, stream=0, shard_coarse=False):
+    def __init__(self, index, comm, shard_coarse=False):
         """shard_coarse: two-phase search (C4, nlist = 65536): every rank scores only its
-        slice of the centroids; one extra all-gather of `nprobe` (distance, partition id)
-        pairs per query per rank selects the global probe list before the scan."""
-        import torch.distributed as dist
-        self.index, self.group, self.merge, self.stream = index, group, merge, stream
-        self.shard_coarse = shard_coarse
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._buf = None
-
-    def _buffers(self, r):
-        import torch
-        B, k = r.distances.shape
-        key = (B, k, r.distances.device)
-        if self._buf is None or self._buf[0] != key:
-            w = self.world
-            # concatenated along dim 0 (the form every backend accepts), viewed [world, B, k] for the merge
-            self._buf = (key, torch.empty((w * B, k), dtype=r.rowids.dtype, device=r.rowids.device),
-                         torch.empty((w * B, k), dtype=r.distances.dtype, device=r.distances.device),
-                         torch.empty((w * B,), dtype=r.counts.dtype, device=r.counts.device))
-        return self._buf[1:]
+        slice of the centroids; one extra all-gather of `nprobe` (partition, distance) records
+        per query per rank selects the global probe list before the scan."""
+        self.index, self.comm = index, comm
+        self.flags = _abi.SHARD_COARSE if shard_coarse else 0
 
     def search(self, queries, params, out=None):
-        """-> SearchResult identical on every rank and to the unsharded search."""
-        import torch.distributed as dist
-        if self.shard_coarse and self.world > 1:
-            r = self._search_two_phase(queries, params, out)
-        else:
-            r = self.index.search(queries, params, out=out)
-        if self.world == 1:
-            return r
-        g_ids, g_dist, g_cnt = self._buffers(r)
-        dist.all_gather_into_tensor(g_ids, r.rowids.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_dist, r.distances.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_cnt, r.counts.contiguous(), group=self.group)
-        B, k = r.distances.shape
-        w = self.world
-        ids, d, c = self.merge(g_ids.view(w, B, k), g_dist.view(w, B, k), g_cnt.view(w, B), params.k,
-                               stream=self.stream)
-        return SearchResult(ids, d, c)
+        def fn(handle, q, nq, params_ref, ids, dist, cnt):
+            return lib().mi355_search_sharded(handle, self.comm._h, q, nq, params_ref, C.c_uint32(self.flags), ids, dist, cnt)
+        return _run_search(fn, self.index._h, self.index.dim, queries, params, out)
 
-    def _search_two_phase(self, queries, params, out):
-        import torch
-        import torch.distributed as dist
-        w, nprobe = self.world, params.nprobe_min
-        lo, hi = coarse_slice(self.index.nlist, w, self.rank)
-        ids, d, c = self.index.coarse_topn(queries, nprobe, lo, hi)
-        B = d.shape[0]
-        g_ids = torch.empty((w * B, nprobe), dtype=ids.dtype, device=ids.device)
-        g_d = torch.empty((w * B, nprobe), dtype=d.dtype, device=d.device)
-        g_c = torch.empty((w * B,), dtype=c.dtype, device=c.device)
-        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_d, d.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_c, c.contiguous(), group=self.group)
-        probes, _, _ = self.merge(g_ids.view(w, B, nprobe), g_d.view(w, B, nprobe), g_c.view(w, B), nprobe,
-                                  stream=self.stream)
-        return self.index.search_probes(queries, probes, params, out=out)
+
+class ShardedFlatSearcher:
+    """Flat search with the ROWS sharded across ranks (`flat` holds this rank's slice, its
+    row_ids the global ids): same gather + merge."""
+
+    def __init__(self, flat, comm):
+        self.flat, self.comm = flat, comm
+
+    def search(self, queries, params, out=None):
+        def fn(handle, q, nq, params_ref, ids, dist, cnt):
+            return lib().mi355_flat_search_sharded(handle, self.comm._h, q, nq, params_ref, ids, dist, cnt)
+        return _run_search(fn, self.flat._h, self.flat.dim, queries, params, out)
+
+
+__all__ = ["Comm", "ShardedSearcher", "ShardedFlatSearcher", "coarse_slice", "unique_id", "exchange_id_via_file",
+           "SearchResult"]

@@ -109,7 +109,11 @@ class IvfPqIndex(_Handle):
 
     def __init__(self, centroids, codebook, part_offsets, codes, row_ids=None, raw_vectors=None,
                  metric="l2", codes_layout=_abi.CODES_ROW_MAJOR, raw_dtype=_abi.DTYPE_F32,
-                 device=0, shard_count=1, shard_rank=0):
+                 device=0, shard_count=1, shard_rank=0, nbits=8, generic_scan=False, raw_host_mapped=False):
+        """nbits: 8, or 4 (codebook [m, 16, dim/m], codes [n, m/2] with sub-quantiser 2t in the low
+        nibble of byte t; table/create_index.rs:96-101).  generic_scan: keep the generic code layout
+        (k_scan_pair) for an m the production scan supports.  raw_host_mapped: `raw_vectors` (a host
+        array the caller keeps alive) is page-locked and read zero-copy by the refine stage."""
         super().__init__()
         on_dev = _is_device(codes)
         po = np.ascontiguousarray(part_offsets, dtype=np.uint64)  # always host
@@ -129,7 +133,9 @@ class IvfPqIndex(_Handle):
         self.metric = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else int(metric)
         d = _abi.IndexDesc()
         d.struct_size = C.sizeof(_abi.IndexDesc)
-        d.dim, d.nlist, d.m, d.nbits = self.dim, self.nlist, self.m, 8
+        d.dim, d.nlist, d.m, d.nbits = self.dim, self.nlist, self.m, int(nbits)
+        d.flags = (_abi.INDEX_GENERIC_SCAN if generic_scan else 0) | (_abi.INDEX_RAW_HOST_MAPPED if raw_host_mapped else 0)
+        self.nbits = int(nbits)
         d.metric = self.metric
         d.n_rows = int(po[-1])
         d.mem = _abi.MEM_DEVICE if on_dev else _abi.MEM_HOST
@@ -142,13 +148,14 @@ class IvfPqIndex(_Handle):
         self.n_rows = d.n_rows
         self._keep = [cen, cb, po, cd, rid, raw]
         check(lib().mi355_index_open(C.byref(d), C.byref(self._h)))
-        self._keep = []  # the library copied everything it needs
+        self._keep = [raw] if raw_host_mapped else []  # the library copied everything else it needs
 
-    def configure(self, scan_variant=_abi.SCAN_AUTO, slice_rows=0, profile=0):
+    def configure(self, scan_variant=_abi.SCAN_AUTO, slice_rows=0, profile=0, graph=False, coalesce=False):
         """profile: 0 counters only, 1 per-stage times of the last search,
-        2 accumulate over searches until the next configure()."""
-        check(lib().mi355_index_configure(self._h, C.c_uint32(scan_variant), C.c_uint32(slice_rows),
-                                          C.c_uint32(int(profile))))
+        2 accumulate over searches until the next configure().  graph / coalesce:
+        the latency and concurrency modes of host-I/O searches (both on after open)."""
+        mode = int(profile) | (_abi.CFG_GRAPH if graph else 0) | (_abi.CFG_COALESCE if coalesce else 0)
+        check(lib().mi355_index_configure(self._h, C.c_uint32(scan_variant), C.c_uint32(slice_rows), C.c_uint32(mode)))
 
     def set_stream(self, hip_stream):
         check(lib().mi355_index_set_stream(self._h, C.c_void_p(hip_stream or 0)))
@@ -237,6 +244,16 @@ class FlatIndex(_Handle):
     def sync(self):
         check(lib().mi355_flat_sync(self._h))
 
+    def configure(self, gemm_variant=_abi.FLAT_GEMM_AUTO, grid_workgroups=0, checksum=False):
+        """Tuning of the GEMM filter (include/mi355_ann.h mi355_flat_configure)."""
+        check(lib().mi355_flat_configure(self._h, C.c_uint32(gemm_variant), C.c_uint32(grid_workgroups),
+                                         C.c_uint32(_abi.FLAT_CHECKSUM if checksum else 0)))
+
+    def checksum(self):
+        v = C.c_uint64(0)
+        check(lib().mi355_flat_checksum(self._h, C.byref(v)))
+        return v.value
+
     def info(self):
         """-> (last_path, has_filter): 1 = MFMA filter + exact re-rank, 2 = exact sweep."""
         a, b = C.c_uint32(0), C.c_uint32(0)
@@ -270,7 +287,7 @@ def shard_plan(part_offsets, shard_count):
     return out
 
 
-def ivfpq_encode(vectors, centroids, codebook, metric="l2", device=0, return_assign=False):
+def ivfpq_encode(vectors, centroids, codebook, metric="l2", device=0, return_assign=False, nbits=8):
     """Index population (include/mi355_ann.h mi355_ivfpq_encode): assign every row
     of `vectors` [n, dim] f32 to its IVF partition, PQ-encode its residual with the
     trained `codebook` [m, 256, dim/m] and lay the rows out partition by partition —
@@ -291,20 +308,23 @@ def ivfpq_encode(vectors, centroids, codebook, metric="l2", device=0, return_ass
         codebook = _host(codebook, np.float32)
     n, dim = int(vectors.shape[0]), int(vectors.shape[1])
     nlist, m = int(centroids.shape[0]), int(codebook.shape[0])
-    if tuple(centroids.shape) != (nlist, dim) or tuple(codebook.shape)[:2] != (m, 256) or m == 0 or dim % m \
+    if nbits not in (4, 8) or (nbits == 4 and m % 2):
+        raise ValueError("num_bits must be 8, or 4 with an even num_sub_vectors")
+    if tuple(centroids.shape) != (nlist, dim) or tuple(codebook.shape)[:2] != (m, 1 << nbits) or m == 0 or dim % m \
             or int(codebook.shape[2]) != dim // m:
-        raise ValueError("centroids must be [nlist, dim] and codebook [m, 256, dim/m]")
+        raise ValueError("centroids must be [nlist, dim] and codebook [m, 2^nbits, dim/m]")
+    mb = m * nbits // 8
     mcode = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else int(metric)
     po = np.zeros(nlist + 1, dtype=np.uint64)
     if dev_in:
         dev_index = getattr(vectors.device, "index", vectors.device) or 0
-        codes, order, assign = _device_empty_like(vectors, [((n, m), "uint8"), ((n,), "int64"), ((n,), "int32")])
+        codes, order, assign = _device_empty_like(vectors, [((n, mb), "uint8"), ((n,), "int64"), ((n,), "int32")])
     else:
         dev_index = device
-        codes = np.empty((n, m), dtype=np.uint8)
+        codes = np.empty((n, mb), dtype=np.uint8)
         order = np.empty(n, dtype=np.uint64)
         assign = np.empty(n, dtype=np.uint32)
-    desc = _abi.EncodeDesc(struct_size=C.sizeof(_abi.EncodeDesc), dim=dim, nlist=nlist, m=m, nbits=8, metric=mcode,
+    desc = _abi.EncodeDesc(struct_size=C.sizeof(_abi.EncodeDesc), dim=dim, nlist=nlist, m=m, nbits=nbits, metric=mcode,
                            mem=_abi.MEM_DEVICE if dev_in else _abi.MEM_HOST, device=dev_index,
                            centroids=_ptr(centroids), codebook=_ptr(codebook))
     check(lib().mi355_ivfpq_encode(C.byref(desc), _ptr(vectors), C.c_uint64(n), _ptr(po), _ptr(codes), _ptr(order),

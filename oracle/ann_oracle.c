@@ -19,7 +19,8 @@
  *   - metrics: rust/lancedb/src/lib.rs:236-260
  *   - result order (_distance ASC, _rowid ASC), NULL distances dropped:
  *     python/python/lancedb/query.py:1365-1370
- *   - index shape (nlist, m, 8 bits): rust/lancedb/src/index/vector.rs:266-319
+ *   - index shape (nlist, m, 8 or 4 bits; 4 bits need an even m):
+ *     rust/lancedb/src/index/vector.rs:266-319, table/create_index.rs:96-101
  * [EXT] (lance-index, restated, not verifiable here): PQ of the residual
  * q - centroid for L2/cosine, no residual for dot; distance table
  * LUT[j][c] = l2(r_j, codebook[j][c]) (or 1 - dot); ADC
@@ -44,6 +45,8 @@
  *   residual          : r[d] = q[d] - c_p[d]
  *   LUT[j][c]         : chain_l2(r_j, cb_jc, dsub)   | dot: 1 - chain_dot(q_j, cb_jc)
  *   ADC               : acc = 0; for j=0..m-1: acc = acc + LUT[j][code_j]
+ *   4-bit codes       : LUT[j] has 16 entries; byte t of a row packs code_{2t} (low nibble) and
+ *                       code_{2t+1} (high nibble); the adds stay in j order ([EXT] packing)
  *   final             : L2 acc | cosine acc*0.5f | dot acc - (float)(m-1)
  *   exact (flat/refine): L2 chain_l2(q,v) | cosine 1 - dot/(sqrtf(qq)*sqrtf(vv))
  *                        | dot 1 - chain_dot(q,v)
@@ -61,12 +64,13 @@
 
 typedef struct orc_index {
   uint32_t dim, nlist, m, ksub, dsub, metric;
+  uint32_t nbits, mb; /* bits per code (8 | 4), code bytes per row (m * nbits / 8) */
   uint64_t n_rows;
   float *centroids;   /* [nlist, dim] */
   float *cnorm;       /* [nlist] chain_dot(c,c) */
   float *codebook;    /* [m, ksub, dsub] */
   uint64_t *part_off; /* [nlist+1] */
-  uint8_t *codes_t;   /* partition p: [m, len_p] at m*part_off[p] */
+  uint8_t *codes_t;   /* partition p: [mb, len_p] at mb*part_off[p] */
   uint64_t *row_ids;  /* [n_rows] */
   void *raw;          /* [n_rows, dim] or NULL */
   uint32_t raw_dtype;
@@ -256,9 +260,10 @@ int32_t orc_index_open2(const mi355_index_desc *d, orc_index **out, int borrow) 
   if (!d || !out || d->struct_size != sizeof(mi355_index_desc))
     return MI355_ERR_INVALID_INPUT;
   if (d->mem != MI355_MEM_HOST) return MI355_ERR_INVALID_INPUT;
-  if (d->nbits != 8) return MI355_ERR_NOT_SUPPORTED;
+  if (d->nbits != 8 && d->nbits != 4) return MI355_ERR_INVALID_INPUT;
   if (d->dim == 0 || d->m == 0 || d->dim % d->m != 0 || d->nlist == 0)
     return MI355_ERR_INVALID_INPUT;
+  if (d->nbits == 4 && d->m % 2) return MI355_ERR_INVALID_INPUT; /* table/create_index.rs:96-101 */
   if (d->metric > MI355_METRIC_DOT) return MI355_ERR_INVALID_INPUT;
   if (!d->centroids || !d->codebook || !d->part_offsets ||
       (d->n_rows && !d->codes))
@@ -276,7 +281,9 @@ int32_t orc_index_open2(const mi355_index_desc *d, orc_index **out, int borrow) 
   ix->dim = d->dim;
   ix->nlist = d->nlist;
   ix->m = d->m;
-  ix->ksub = 256;
+  ix->nbits = d->nbits;
+  ix->ksub = 1u << d->nbits;
+  ix->mb = d->m * d->nbits / 8;
   ix->dsub = d->dim / d->m;
   ix->metric = d->metric;
   ix->n_rows = d->n_rows;
@@ -287,7 +294,7 @@ int32_t orc_index_open2(const mi355_index_desc *d, orc_index **out, int borrow) 
   for (uint32_t p = 0; p < d->nlist; ++p)
     ix->cnorm[p] = orc_chain_dot(ix->centroids + (size_t)p * d->dim,
                                  ix->centroids + (size_t)p * d->dim, d->dim);
-  size_t ncb = (size_t)d->m * 256 * ix->dsub;
+  size_t ncb = (size_t)d->m * ix->ksub * ix->dsub;
   ix->codebook = (float *)malloc(sizeof(float) * ncb);
   memcpy(ix->codebook, d->codebook, sizeof(float) * ncb);
   ix->part_off = (uint64_t *)malloc(sizeof(uint64_t) * (d->nlist + 1));
@@ -300,16 +307,17 @@ int32_t orc_index_open2(const mi355_index_desc *d, orc_index **out, int borrow) 
     *out = ix;
     return MI355_OK;
   }
-  ix->codes_t = (uint8_t *)malloc((size_t)d->n_rows * d->m + 1);
+  const uint32_t mb = ix->mb;
+  ix->codes_t = (uint8_t *)malloc((size_t)d->n_rows * mb + 1);
   if (d->codes_layout == MI355_CODES_PART_TRANSPOSED) {
-    memcpy(ix->codes_t, d->codes, (size_t)d->n_rows * d->m);
+    memcpy(ix->codes_t, d->codes, (size_t)d->n_rows * mb);
   } else {
     for (uint32_t p = 0; p < d->nlist; ++p) {
       uint64_t o = ix->part_off[p], len = ix->part_off[p + 1] - o;
-      uint8_t *dst = ix->codes_t + (size_t)o * d->m;
+      uint8_t *dst = ix->codes_t + (size_t)o * mb;
       for (uint64_t i = 0; i < len; ++i)
-        for (uint32_t j = 0; j < d->m; ++j)
-          dst[(size_t)j * len + i] = d->codes[(size_t)(o + i) * d->m + j];
+        for (uint32_t j = 0; j < mb; ++j)
+          dst[(size_t)j * len + i] = d->codes[(size_t)(o + i) * mb + j];
     }
   }
   ix->row_ids = (uint64_t *)malloc(sizeof(uint64_t) * (d->n_rows + 1));
@@ -356,19 +364,19 @@ void orc_select_probes(const float *dist, uint32_t nlist, uint32_t nprobe,
 
 /* E5: distance table of one (query, partition).  q is the preprocessed query. */
 void orc_build_lut(const orc_index *ix, const float *q, uint32_t part,
-                   float *lut /*[m,256]*/) {
-  uint32_t dsub = ix->dsub;
+                   float *lut /*[m,ksub]*/) {
+  uint32_t dsub = ix->dsub, ks = ix->ksub;
   float r[dsub];
   for (uint32_t j = 0; j < ix->m; ++j) {
-    const float *cb = ix->codebook + (size_t)j * 256 * dsub;
+    const float *cb = ix->codebook + (size_t)j * ks * dsub;
     if (ix->metric == MI355_METRIC_DOT) {
-      for (uint32_t c = 0; c < 256; ++c)
-        lut[j * 256 + c] = 1.0f - orc_chain_dot(q + j * dsub, cb + c * dsub, dsub);
+      for (uint32_t c = 0; c < ks; ++c)
+        lut[j * ks + c] = 1.0f - orc_chain_dot(q + j * dsub, cb + c * dsub, dsub);
     } else {
       const float *cen = ix->centroids + (size_t)part * ix->dim + j * dsub;
       for (uint32_t t = 0; t < dsub; ++t) r[t] = q[j * dsub + t] - cen[t];
-      for (uint32_t c = 0; c < 256; ++c)
-        lut[j * 256 + c] = orc_chain_l2(r, cb + c * dsub, dsub);
+      for (uint32_t c = 0; c < ks; ++c)
+        lut[j * ks + c] = orc_chain_l2(r, cb + c * dsub, dsub);
     }
   }
 }
@@ -384,12 +392,21 @@ static inline float finalize(const orc_index *ix, float acc) {
 void orc_adc_partition(const orc_index *ix, const float *lut, uint32_t part,
                        float *out) {
   uint64_t o = ix->part_off[part], len = ix->part_off[part + 1] - o;
-  const uint8_t *codes = ix->codes_t + (size_t)o * ix->m;
+  const uint8_t *codes = ix->codes_t + (size_t)o * ix->mb;
   for (uint64_t i = 0; i < len; ++i) out[i] = 0.0f;
-  for (uint32_t j = 0; j < ix->m; ++j) {
-    const float *t = lut + j * 256;
-    const uint8_t *row = codes + (size_t)j * len;
-    for (uint64_t i = 0; i < len; ++i) out[i] = out[i] + t[row[i]];
+  if (ix->nbits == 8) {
+    for (uint32_t j = 0; j < ix->m; ++j) {
+      const float *t = lut + j * 256;
+      const uint8_t *row = codes + (size_t)j * len;
+      for (uint64_t i = 0; i < len; ++i) out[i] = out[i] + t[row[i]];
+    }
+  } else { /* byte t: sub-quantiser 2t in the low nibble, 2t+1 in the high nibble; adds stay j-ascending per row */
+    for (uint32_t jb = 0; jb < ix->mb; ++jb) {
+      const float *t0 = lut + (2 * jb) * 16, *t1 = t0 + 16;
+      const uint8_t *row = codes + (size_t)jb * len;
+      for (uint64_t i = 0; i < len; ++i) out[i] = out[i] + t0[row[i] & 15u];
+      for (uint64_t i = 0; i < len; ++i) out[i] = out[i] + t1[row[i] >> 4];
+    }
   }
   for (uint64_t i = 0; i < len; ++i) out[i] = finalize(ix, out[i]);
 }
@@ -482,7 +499,7 @@ int32_t orc_search(const orc_index *ix, const float *queries, uint32_t n_queries
 #endif
 #pragma omp parallel num_threads(nthreads) reduction(+ : total_scanned)
   {
-    float *lut = (float *)malloc(sizeof(float) * ix->m * 256);
+    float *lut = (float *)malloc(sizeof(float) * ix->m * ix->ksub);
     float *dist = (float *)malloc(sizeof(float) * mpl);
     float *coarse = (float *)malloc(sizeof(float) * ix->nlist);
     uint32_t *probes = (uint32_t *)malloc(sizeof(uint32_t) * ix->nlist);
@@ -663,9 +680,11 @@ int32_t orc_ivfpq_encode(const mi355_encode_desc *d, const float *vectors, uint6
                          uint64_t *out_part_offsets, uint8_t *out_codes, uint64_t *out_order,
                          uint32_t *out_assign) {
   if (!d || d->struct_size != sizeof(mi355_encode_desc) || !vectors || !out_part_offsets || !out_codes ||
-      !out_order || d->nbits != 8 || d->dim == 0 || d->m == 0 || d->dim % d->m || d->metric > MI355_METRIC_DOT)
+      !out_order || (d->nbits != 8 && d->nbits != 4) || d->dim == 0 || d->m == 0 || d->dim % d->m ||
+      d->metric > MI355_METRIC_DOT || (d->nbits == 4 && d->m % 2))
     return MI355_ERR_INVALID_INPUT;
   const uint32_t dim = d->dim, nlist = d->nlist, m = d->m, dsub = dim / m;
+  const uint32_t ks = 1u << d->nbits, mb = m * d->nbits / 8; /* codebook entries, code bytes per row */
   float *cn = (float *)malloc(sizeof(float) * nlist);
   for (uint32_t p = 0; p < nlist; ++p)
     cn[p] = orc_chain_dot(d->centroids + (size_t)p * dim, d->centroids + (size_t)p * dim, dim);
@@ -705,8 +724,8 @@ int32_t orc_ivfpq_encode(const mi355_encode_desc *d, const float *vectors, uint6
         uint32_t bc = 0;
         float bv = 0.0f;
         int hv = 0;
-        for (uint32_t c = 0; c < 256; ++c) {
-          const float *cb = d->codebook + ((size_t)j * 256 + c) * dsub;
+        for (uint32_t c = 0; c < ks; ++c) {
+          const float *cb = d->codebook + ((size_t)j * ks + c) * dsub;
           float v = d->metric == MI355_METRIC_DOT ? 1.0f - orc_chain_dot(x + j * dsub, cb, dsub)
                                                   : orc_chain_l2(x + j * dsub, cb, dsub);
           if (v == v && (!hv || v < bv)) {
@@ -727,7 +746,13 @@ int32_t orc_ivfpq_encode(const mi355_encode_desc *d, const float *vectors, uint6
   for (uint64_t i = 0; i < n_rows; ++i) { /* stable: source order inside a partition */
     uint64_t pos = cnt[assign[i]]++;
     out_order[pos] = i;
-    memcpy(out_codes + (size_t)pos * m, codes_src + (size_t)i * m, m);
+    if (d->nbits == 8) {
+      memcpy(out_codes + (size_t)pos * m, codes_src + (size_t)i * m, m);
+    } else { /* pack two codes per byte: 2t low nibble, 2t+1 high nibble */
+      for (uint32_t t = 0; t < mb; ++t)
+        out_codes[(size_t)pos * mb + t] =
+            (uint8_t)(codes_src[(size_t)i * m + 2 * t] | (codes_src[(size_t)i * m + 2 * t + 1] << 4));
+    }
   }
   if (out_assign) memcpy(out_assign, assign, sizeof(uint32_t) * n_rows);
   free(cnt);

@@ -54,7 +54,7 @@ class OracleIndex:
 
     def __init__(self, centroids, codebook, part_offsets, codes, row_ids=None,
                  raw_vectors=None, metric="l2", codes_layout=_abi.CODES_ROW_MAJOR,
-                 raw_dtype=_abi.DTYPE_F32, borrow=False):
+                 raw_dtype=_abi.DTYPE_F32, borrow=False, nbits=8):
         self.centroids = _f32(centroids)
         self.codebook = _f32(codebook)
         self.part_offsets = np.ascontiguousarray(part_offsets, dtype=np.uint64)
@@ -66,7 +66,8 @@ class OracleIndex:
         self.metric = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else metric
         d = _abi.IndexDesc()
         d.struct_size = C.sizeof(_abi.IndexDesc)
-        d.dim, d.nlist, d.m, d.nbits = self.dim, self.nlist, self.m, 8
+        d.dim, d.nlist, d.m, d.nbits = self.dim, self.nlist, self.m, int(nbits)
+        self.nbits = int(nbits)
         d.metric = self.metric
         d.n_rows = int(self.part_offsets[-1])
         d.mem = _abi.MEM_HOST
@@ -135,7 +136,7 @@ class OracleIndex:
 
     def build_lut(self, q, part):
         q = self.preprocess(q)
-        out = np.empty((self.m, 256), dtype=np.float32)
+        out = np.empty((self.m, 1 << self.nbits), dtype=np.float32)
         lib().orc_build_lut(self._h, _ptr(q), C.c_uint32(part), _ptr(out))
         return out
 
@@ -204,20 +205,20 @@ def shard_plan(part_offsets, shard_count):
     return out
 
 
-def ivfpq_encode(vectors, centroids, codebook, metric="l2"):
-    """-> (part_offsets [nlist+1], codes [n, m] index order, order [n], assign [n])."""
+def ivfpq_encode(vectors, centroids, codebook, metric="l2", nbits=8):
+    """-> (part_offsets [nlist+1], codes [n, m * nbits / 8] index order, order [n], assign [n])."""
     v = _f32(vectors)
     cen, cb = _f32(centroids), _f32(codebook)
     n, dim = v.shape
     nlist, m = cen.shape[0], cb.shape[0]
     d = _abi.EncodeDesc()
     d.struct_size = C.sizeof(_abi.EncodeDesc)
-    d.dim, d.nlist, d.m, d.nbits = dim, nlist, m, 8
+    d.dim, d.nlist, d.m, d.nbits = dim, nlist, m, int(nbits)
     d.metric = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else metric
     d.mem, d.device = _abi.MEM_HOST, 0
     d.centroids, d.codebook = _ptr(cen), _ptr(cb)
     po = np.zeros(nlist + 1, dtype=np.uint64)
-    codes = np.empty((n, m), dtype=np.uint8)
+    codes = np.empty((n, m * int(nbits) // 8), dtype=np.uint8)
     order = np.empty(n, dtype=np.uint64)
     assign = np.empty(n, dtype=np.uint32)
     st = lib().orc_ivfpq_encode(C.byref(d), _ptr(v), C.c_uint64(n), _ptr(po), _ptr(codes), _ptr(order), _ptr(assign))

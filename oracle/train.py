@@ -69,21 +69,21 @@ def train_ivfpq(vectors, nlist, m, metric="l2", iters=8, seed=0, row_ids=None):
                 raw=np.ascontiguousarray(x[order]), assign=assign[order])
 
 
-def synthetic_index(n, dim, nlist, m, seed=0, skew=0.5, empty_parts=0):
+def synthetic_index(n, dim, nlist, m, seed=0, skew=0.5, empty_parts=0, nbits=8):
     """Random (untrained) index with the shape of the throughput datasets of
     SURVEY.md §8d: N(0,1) centroids, N(0,0.25) codebook, uniform u8 codes,
     log-normally skewed partition lengths, permuted row ids."""
     rng = np.random.default_rng(seed)
     dsub = dim // m
     centroids = rng.normal(0, 1, size=(nlist, dim)).astype(np.float32)
-    codebook = rng.normal(0, 0.5, size=(m, 256, dsub)).astype(np.float32)
+    codebook = rng.normal(0, 0.5, size=(m, 1 << nbits, dsub)).astype(np.float32)
     w = np.exp(rng.normal(0, skew, size=nlist))
     if empty_parts:
         w[rng.choice(nlist, size=empty_parts, replace=False)] = 0
     lens = rng.multinomial(n, w / w.sum())
     part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
     part_offsets[1:] = np.cumsum(lens)
-    codes = rng.integers(0, 256, size=(n, m), dtype=np.uint8)
+    codes = rng.integers(0, 256, size=(n, m * nbits // 8), dtype=np.uint8)  # 4-bit: two random nibbles per byte
     row_ids = rng.permutation(n).astype(np.uint64)
     return dict(centroids=centroids, codebook=codebook, part_offsets=part_offsets,
                 codes=codes, row_ids=row_ids)

@@ -61,7 +61,8 @@ def _desc(**over):
 
 @pytest.mark.parametrize("over,status,needle", [
     (dict(struct_size=8), _abi.ERR_INVALID_INPUT, "struct_size"),
-    (dict(nbits=4), _abi.ERR_NOT_SUPPORTED, "4-bit"),
+    (dict(nbits=4, m=1), _abi.ERR_INVALID_INPUT, "even when num_bits is 4"),  # table/create_index.rs:96-101
+    (dict(flags=64), _abi.ERR_INVALID_INPUT, "flags"),
     (dict(nbits=7), _abi.ERR_INVALID_INPUT, "num_bits"),
     (dict(m=3), _abi.ERR_INVALID_INPUT, "divisible"),
     (dict(metric=9), _abi.ERR_INVALID_INPUT, "metric"),
@@ -122,7 +123,8 @@ def test_encode_validates_before_touching_a_device(L):
 
     assert call(struct_size=8) == _abi.ERR_INVALID_INPUT and "ABI mismatch" in _lib.last_error()
     assert call(m=3) == _abi.ERR_INVALID_INPUT
-    assert call(nbits=4) == _abi.ERR_NOT_SUPPORTED
+    assert call(nbits=5) == _abi.ERR_INVALID_INPUT and "num_bits" in _lib.last_error()
+    assert call(nbits=4, m=1, dim=8) == _abi.ERR_INVALID_INPUT and "even" in _lib.last_error()
     assert call(metric=7) == _abi.ERR_INVALID_INPUT
     assert call(centroids=None) == _abi.ERR_INVALID_INPUT
     with pytest.raises(ValueError):
@@ -154,11 +156,11 @@ def test_kmeans_validates_before_touching_a_device(L):
 
 
 def test_builder_parameter_defaults_follow_the_reference():
-    """index/vector.rs:306-319 (sub-vectors) and :64-66 (partitions = sqrt(rows))."""
+    """index/vector.rs:306-319 (sub-vectors); partitions = rows / 8192, the default partition size
+    pinned by table/create_index.rs:733-795."""
     assert [lancedb_amd.suggested_num_sub_vectors(d) for d in (768, 1536, 24, 7, 16, 8)] == [48, 96, 3, 1, 1, 1]
-    assert lancedb_amd.suggested_num_partitions(1_000_000) == 1000
-    with pytest.raises(NotImplementedError):
-        lancedb_amd.IvfPqBuilder(num_bits=4)
+    assert lancedb_amd.suggested_num_partitions(1_000_000) == 122
+    assert lancedb_amd.IvfPqBuilder(num_bits=4).num_bits == 4
     b = lancedb_amd.IvfPqBuilder()
     assert (b.sample_rate, b.max_iterations, b.distance_type) == (256, 50, "l2")
     with pytest.raises(ValueError):

@@ -1,0 +1,158 @@
+"""Concurrent callers, latency mode and the device-side timeout of one index handle
+(SURVEY.md §8b threading: callers are tokio workers, python/src/runtime.rs:31-37; BaseTable is
+Send + Sync, table.rs:549; QueryExecutionOptions.timeout, query.rs:626-658, utils/mod.rs:328-392)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import lancedb_amd
+from lancedb_amd import _abi
+from oracle import train
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sixty_four_threads_single_queries_are_coalesced_and_exact(oracle):
+    s = train.synthetic_index(120000, 128, 64, 32, seed=4, skew=0.8)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    rng = np.random.default_rng(1)
+    n_threads, per_thread = 64, 12
+    qs = rng.normal(size=(n_threads, per_thread, 128)).astype(np.float32)
+    # two parameter sets in flight at once: only calls with equal parameters share a device batch
+    kws = [dict(k=10, nprobe_min=16, nprobe_max=16), dict(k=25, nprobe_min=8, nprobe_max=8)]
+    exp = {}
+    for t in range(n_threads):
+        exp[t] = [o.search(qs[t, i:i + 1], **kws[t % 2]) for i in range(per_thread)]
+    errors, coalesced = [], []
+    barrier = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            barrier.wait()
+            for i in range(per_thread):
+                got = ix.search(qs[t, i:i + 1], **kws[t % 2])
+                ids, dist, cnt, _ = exp[t][i]
+                assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    wall = time.perf_counter() - t0
+    assert not errors, errors[:3]
+    # the same calls one after another on one thread, for the record (no assertion on speed)
+    t1 = time.perf_counter()
+    for i in range(per_thread):
+        ix.search(qs[0, i:i + 1], **kws[0])
+    serial = (time.perf_counter() - t1) / per_thread
+    print(f"64 threads x {per_thread} single-query calls: {n_threads * per_thread / wall:.0f} QPS; "
+          f"one thread: {1 / serial:.0f} QPS")
+
+
+def test_graph_replay_serves_small_batches_and_stays_exact(oracle):
+    s = train.synthetic_index(60000, 128, 32, 32, seed=5)
+    raw = np.random.default_rng(3).normal(size=(60000, 128)).astype(np.float32)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
+    rng = np.random.default_rng(2)
+    for kw in (dict(k=10, nprobe_min=8, nprobe_max=8), dict(k=10, nprobe_min=8, nprobe_max=8, refine_factor=5),
+               dict(k=10, nprobe_min=8, nprobe_max=8, upper_bound=30.0)):
+        for rep in range(5):  # 1st eager (sizes the workspace), 2nd captures, 3rd.. replay
+            q = rng.normal(size=(1, 128)).astype(np.float32)
+            got = ix.search(q, **kw)
+            ids, dist, cnt, _ = o.search(q, **kw)
+            assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all(), (kw, rep)
+    replays = ix.stats()["graph_replays"]
+    assert replays >= 6, replays  # >= 2 replays per parameter set (the stats survive the per-call reset)
+    # a different batch size re-sizes the workspace: stale graphs are re-captured, results stay exact
+    q = rng.normal(size=(48, 128)).astype(np.float32)
+    for _ in range(3):
+        got = ix.search(q, k=10, nprobe_min=8, nprobe_max=8)
+        ids, dist, cnt, _ = o.search(q, k=10, nprobe_min=8, nprobe_max=8)
+        assert (got.rowids == ids).all() and (got.distances == dist).all()
+    # graph / coalescing off: the eager path
+    ix.configure(graph=False, coalesce=False)
+    q1 = rng.normal(size=(1, 128)).astype(np.float32)
+    before = ix.stats()["graph_replays"]
+    for _ in range(3):
+        got = ix.search(q1, k=10, nprobe_min=8, nprobe_max=8)
+    assert (got.rowids == o.search(q1, k=10, nprobe_min=8, nprobe_max=8)[0]).all()
+    assert ix.stats()["graph_replays"] == 0 and before >= 0
+
+
+def test_timeout_stops_the_scan_on_the_device(oracle):
+    """A deadline far shorter than the scan: the persistent scan stops popping work items and the
+    call returns Timeout (host I/O) / reports it at sync (device I/O); the handle stays usable."""
+    s = train.synthetic_index(3_000_000, 128, 64, 32, seed=8, skew=0.3)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    q = np.random.default_rng(1).normal(size=(4096, 128)).astype(np.float32)
+    t0 = time.perf_counter()
+    full = ix.search(q, k=10, nprobe_min=64, nprobe_max=64)
+    t_full = time.perf_counter() - t0
+    assert ix.stats()["timed_out"] == 0
+    with pytest.raises(lancedb_amd.QueryTimeout, match="Query timeout"):
+        ix.search(q, k=10, nprobe_min=64, nprobe_max=64, timeout_ms=1)
+    st = ix.stats()
+    assert st["timed_out"] == 1
+    assert st["vectors_scanned"] < 0.9 * 4096 * 3_000_000, "the scan ran to completion"
+    # device I/O: the call returns at once, the timeout surfaces at sync
+    DA = lancedb_amd.DeviceArray
+    dq = DA.from_numpy(q)
+    out = (DA((4096, 10), np.int64), DA((4096, 10), np.float32), DA((4096,), np.int32))
+    ix.search(dq, _abi.make_params(k=10, nprobe_min=64, nprobe_max=64, timeout_ms=1), out=out)
+    with pytest.raises(lancedb_amd.QueryTimeout):
+        ix.sync()
+    # and the handle is fine afterwards: a generous deadline returns the full result
+    again = ix.search(q, k=10, nprobe_min=64, nprobe_max=64, timeout_ms=max(60_000, int(t_full * 20_000)))
+    assert (again.rowids == full.rowids).all() and (again.distances == full.distances).all()
+    # the generic scan kernel honours the deadline too
+    s2 = train.synthetic_index(2_000_000, 32, 32, 8, seed=9, skew=0.3)
+    ix2 = lancedb_amd.IvfPqIndex(s2["centroids"], s2["codebook"], s2["part_offsets"], s2["codes"], s2["row_ids"])
+    q2 = np.random.default_rng(2).normal(size=(2048, 32)).astype(np.float32)
+    with pytest.raises(lancedb_amd.QueryTimeout):
+        ix2.search(q2, k=10, nprobe_min=32, nprobe_max=32, timeout_ms=1)
+
+
+def test_refine_from_host_mapped_raw_vectors(oracle):
+    """MI355_INDEX_RAW_HOST_MAPPED (C5: a raw column that does not fit HBM): the refine stage gathers
+    its k * refine_factor rows per query from the caller's page-locked host memory; also on shard
+    handles, whose local positions are converted to global index positions."""
+    rng = np.random.default_rng(12)
+    for m, dim in ((8, 64), (32, 128)):
+        s = train.synthetic_index(50000, dim, 40, m, seed=m, skew=0.8, empty_parts=3)
+        for dt, code in ((np.float32, _abi.DTYPE_F32), (np.float16, _abi.DTYPE_F16)):
+            raw = rng.normal(size=(50000, dim)).astype(dt)
+            raw_bits = raw if dt is np.float32 else raw.view(np.uint16)
+            o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                                   raw_vectors=raw_bits, metric="cosine", raw_dtype=code)
+            g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                                       raw_vectors=raw_bits, metric="cosine", raw_dtype=code, raw_host_mapped=True)
+            q = rng.normal(size=(24, dim)).astype(np.float32)
+            for kw in (dict(k=10, nprobe_min=16, nprobe_max=16, refine_factor=10), dict(k=10, nprobe_min=4, nprobe_max=4, refine_factor=50)):
+                got = g.search(q, **kw)
+                ids, dist, cnt, _ = o.search(q, **kw)
+                assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()
+            g.close()
+    # a shard handle addresses the caller's column by GLOBAL index position: its own search (local
+    # refine of its local candidates) equals the oracle over the rows the shard keeps
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_model import shard_local
+    s = train.synthetic_index(30000, 64, 24, 8, seed=77, skew=0.9, empty_parts=2)
+    raw = rng.normal(size=(30000, 64)).astype(np.float32)
+    s["raw"] = raw
+    owner = lancedb_amd.shard_plan(s["part_offsets"], 3)
+    q = rng.normal(size=(16, 64)).astype(np.float32)
+    for r in range(3):
+        loc = shard_local(s, owner, r)
+        o = oracle.OracleIndex(loc["centroids"], loc["codebook"], loc["part_offsets"], loc["codes"], loc["row_ids"], raw_vectors=loc["raw"])
+        g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw,
+                                   raw_host_mapped=True, shard_count=3, shard_rank=r)
+        got = g.search(q, k=10, nprobe_min=12, nprobe_max=12, refine_factor=6)
+        ids, dist, cnt, _ = o.search(q, k=10, nprobe_min=12, nprobe_max=12, refine_factor=6)
+        assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()

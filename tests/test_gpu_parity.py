@@ -180,11 +180,11 @@ def test_ivfpq_skew_ties_ranges_and_batches(oracle):
                  o3.search(q2[:16], k=10, nprobe_min=4, nprobe_max=4, refine_factor=10))
 
 
-def test_generic_layout_still_serves_m96(oracle, monkeypatch):
-    """MI355_LAYOUT=pair keeps the generic [m][rows] layout for a supported m."""
-    monkeypatch.setenv("MI355_LAYOUT", "pair")
+def test_generic_layout_still_serves_m96(oracle):
+    """MI355_INDEX_GENERIC_SCAN keeps the generic [m][rows] layout for a supported m."""
     s = train.synthetic_index(20000, 192, 8, 96, seed=5)
-    g, o = _both(oracle, s)
+    g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], generic_scan=True)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
     q = np.random.default_rng(1).normal(size=(5, 192)).astype(np.float32)
     _assert_same(g.search(q, k=10, nprobe_min=4, nprobe_max=4), o.search(q, k=10, nprobe_min=4, nprobe_max=4))
     assert g.stats()["scan_variant"] == _abi.SCAN_PAIR
@@ -240,8 +240,11 @@ def test_ivfpq_errors_mirror_reference(oracle):
         g.search(q, k=5, metric=_abi.METRIC_COSINE)
     with pytest.raises(lancedb_amd.InvalidInput, match="refine_factor"):
         g.search(q, k=5, refine_factor=2)
-    with pytest.raises(lancedb_amd.NotSupported):
-        g.search(q, k=300)
+    with pytest.raises(lancedb_amd.InvalidInput, match="approx_mode"):
+        g.search(q, k=5, approx_mode=9)
+    for mode in ("fast", "normal", "accurate"):  # carried, validated, ignored by IVF-PQ (lib.rs:298-313)
+        assert (g.search(q, k=5, nprobe_min=4, nprobe_max=4, approx_mode=mode).rowids ==
+                g.search(q, k=5, nprobe_min=4, nprobe_max=4).rowids).all()
 
 
 def test_sharded_handles_merge_to_unsharded_result(oracle):
@@ -482,43 +485,90 @@ def test_c5_config_shape_1536d_cosine_refine10(oracle, raw_dtype):
         _assert_same(g.search(q, **kw), o.search(q, **kw))
 
 
-@pytest.mark.parametrize("tile", ["128", "256", "3"])
-def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, monkeypatch, tile):
+GEMM_VARIANTS = {"128": _abi.FLAT_GEMM_128, "256": _abi.FLAT_GEMM_256, "3": _abi.FLAT_GEMM_256x128_3,
+                 "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF}
+
+
+@pytest.mark.parametrize("tile", ["128", "256", "3", "8phase", "8phase_ref"])
+def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     """A grid of 8 workgroups (one per XCD) walks every tile of the column: the cross-tile
-    path of the flat GEMM (next tile's first stage issued under the last k-step, ragged last
+    path of the flat GEMM (next tile's first stages issued under the last k-steps, ragged last
     row tile, virtual blocks that map to no row tile) against the exact sweep."""
-    monkeypatch.setenv("MI355_FLAT_PERSIST", "8")
-    monkeypatch.setenv("MI355_FLAT_TILE", tile)
     rng = np.random.default_rng(99)
     n, dim = 9000 + 37, 136  # 36 row tiles of 256 (last one ragged), dim padded to 192 -> 3 k-tiles
     v = rng.normal(size=(n, dim)).astype(np.float32)
     q = rng.normal(size=(300, dim)).astype(np.float32)  # 2 query tiles of 256 / 3 of 128
     f = lancedb_amd.FlatIndex(v)
+    f.configure(gemm_variant=GEMM_VARIANTS[tile], grid_workgroups=8)
     for metric in ("l2", "cosine", "dot"):
         mt = _abi.METRIC_NAMES[metric]
         _assert_same(f.search(q, k=10, metric=mt), oracle.flat_search(v, q, k=10, metric=mt))
         assert f.info()[0] == 1
     # a single k-tile per row tile (dim <= 64): the first stage of the next tile is the only stage
+    # (the 8-phase walk needs two k-tiles and hands such columns to the two-barrier kernel)
     v1, q1 = np.ascontiguousarray(v[:, :40]), np.ascontiguousarray(q[:, :40])
     f1 = lancedb_amd.FlatIndex(v1)
+    f1.configure(gemm_variant=GEMM_VARIANTS[tile], grid_workgroups=8)
     _assert_same(f1.search(q1, k=5), oracle.flat_search(v1, q1, k=5))
     assert f1.info()[0] == 1
 
 
-@pytest.mark.skipif(__import__("os").environ.get("MI355_TEST_EXPERIMENTAL") != "1",
-                    reason="experimental 8-phase flat GEMM (csrc/kernels_flat_mfma8.h): opt in with MI355_TEST_EXPERIMENTAL=1")
-def test_flat_mfma_eight_phase_schedule_experimental(oracle, monkeypatch):
-    """Screen of the not-yet-validated 8-phase schedule (MI355_FLAT_TILE=8) against the exact
-    sweep: ragged last row tile, 1 / 2 / 3 / 12 k-tiles, three metrics.  Follow with
-    scripts/ab_flat.sh (group-minimum checksum must equal the other tiles')."""
-    monkeypatch.setenv("MI355_FLAT_TILE", "8")
+@pytest.mark.parametrize("variant", ["8phase", "8phase_ref"])
+@pytest.mark.parametrize("grid", [0, 1, 16])
+def test_flat_mfma_eight_phase_schedule(oracle, variant, grid):
+    """The persistent 8-phase schedule against the exact sweep: ragged last row tile, 2 / 3 / 12
+    k-tiles, three metrics, one workgroup per tile (grid 1), per CU slot (0) and a 16-workgroup
+    walk; every search repeated (a staging race would come and go)."""
     rng = np.random.default_rng(123)
-    for n, dim in ((9000 + 37, 40), (9000 + 37, 100), (5000, 136), (6000, 768)):
+    for n, dim in ((9000 + 37, 100), (5000, 136), (6000, 768)):
         v = rng.normal(size=(n, dim)).astype(np.float32)
         q = rng.normal(size=(300, dim)).astype(np.float32)
         f = lancedb_amd.FlatIndex(v)
+        f.configure(gemm_variant=GEMM_VARIANTS[variant], grid_workgroups=grid)
         for metric in ("l2", "cosine", "dot"):
             mt = _abi.METRIC_NAMES[metric]
-            for _ in range(3):  # repeated: a race would come and go
-                _assert_same(f.search(q, k=10, metric=mt), oracle.flat_search(v, q, k=10, metric=mt))
+            exp = oracle.flat_search(v, q, k=10, metric=mt)
+            for _ in range(3):
+                _assert_same(f.search(q, k=10, metric=mt), exp)
+            assert f.info()[0] == 1
+
+
+def test_flat_mfma_eight_phase_reference_epilogue_matches_two_barrier_kernel_bit_for_bit(oracle):
+    """Same operands, same MFMA k-order, same epilogue arithmetic: the 8-phase schedule with the
+    reference epilogue must produce the group-minimum matrix of the two-barrier kernel exactly
+    (order-independent checksum), whatever the grid."""
+    rng = np.random.default_rng(7)
+    v = rng.normal(size=(20000 + 11, 320)).astype(np.float32)
+    q = rng.normal(size=(512, 320)).astype(np.float32)
+    f = lancedb_amd.FlatIndex(v)
+    sums = {}
+    for name, var, grid in (("256", _abi.FLAT_GEMM_256, 0), ("8ref", _abi.FLAT_GEMM_8PHASE_REF, 0),
+                            ("8ref_g1", _abi.FLAT_GEMM_8PHASE_REF, 1), ("8ref_g24", _abi.FLAT_GEMM_8PHASE_REF, 24)):
+        for metric in ("l2", "cosine", "dot"):
+            f.configure(gemm_variant=var, grid_workgroups=grid, checksum=True)
+            f.search(q, k=10, metric=_abi.METRIC_NAMES[metric])
+            sums[(name, metric)] = f.checksum()
+    for metric in ("l2", "cosine", "dot"):
+        assert len({sums[(n, metric)] for n in ("256", "8ref", "8ref_g1", "8ref_g24")}) == 1, sums
+
+
+def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):
+    """The fast epilogue's "never filter" rule (non-finite sum of a group's terms) on duplicates,
+    near-duplicates inside the bf16 error, zero / NaN / 3e38 rows and a zero query."""
+    rng = np.random.default_rng(17)
+    n, dim = 20000, 128
+    v = rng.normal(size=(n, dim)).astype(np.float32)
+    v[100:4100] = v[100]
+    v[5000:5200] = v[5000] + rng.normal(0, 1e-4, size=(200, dim)).astype(np.float32)
+    v[6000] = 0.0
+    v[6001, 3] = np.nan
+    v[6002] = 3e38
+    q = np.concatenate([v[[100, 5000, 6000, 6002]], np.zeros((1, dim), np.float32),
+                        rng.normal(size=(251, dim)).astype(np.float32)])
+    f = lancedb_amd.FlatIndex(v)
+    f.configure(gemm_variant=_abi.FLAT_GEMM_8PHASE)
+    for metric in ("l2", "cosine", "dot"):
+        mt = _abi.METRIC_NAMES[metric]
+        for k in (1, 10, 200):
+            _assert_same(f.search(q, k=k, metric=mt), oracle.flat_search(v, q, k=k, metric=mt))
             assert f.info()[0] == 1

@@ -341,7 +341,8 @@ enum {
   MI355_FLAT_GEMM_256x128_3 = 3, /* 256 x 128, three LDS stages, one barrier per k-step */
   MI355_FLAT_GEMM_8PHASE = 4,    /* 256 x 256, persistent 8-phase schedule (counted vmcnt,
                                     staggered wave groups), fast epilogue */
-  MI355_FLAT_GEMM_8PHASE_REF = 5 /* the same schedule with variant 2's epilogue arithmetic */
+  MI355_FLAT_GEMM_8PHASE_REF = 5,/* the same schedule with variant 2's epilogue arithmetic */
+  MI355_FLAT_GEMM_8PHASE_M = 6   /* variant 4 with the LDS-DMA pieces issued among the MFMAs */
 };
 enum { MI355_FLAT_CHECKSUM = 1u };
 int32_t mi355_flat_configure(mi355_flat *flat, uint32_t gemm_variant,

@@ -56,6 +56,7 @@ FLAT_GEMM_256 = 2
 FLAT_GEMM_256x128_3 = 3
 FLAT_GEMM_8PHASE = 4
 FLAT_GEMM_8PHASE_REF = 5
+FLAT_GEMM_8PHASE_M = 6
 FLAT_CHECKSUM = 1
 
 SHARD_COARSE = 1

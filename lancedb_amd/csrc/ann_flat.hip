@@ -109,9 +109,9 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
   uint32_t variant = f->gemm_variant;
   const uint32_t KT = f->dimp / FG_BK;
   if (variant == MI355_FLAT_GEMM_AUTO) variant = nq <= 128 ? MI355_FLAT_GEMM_128 : MI355_FLAT_GEMM_AUTO_BIG;
-  if ((variant == MI355_FLAT_GEMM_8PHASE || variant == MI355_FLAT_GEMM_8PHASE_REF) && KT < 2)
+  if (variant >= MI355_FLAT_GEMM_8PHASE && KT < 2)
     variant = MI355_FLAT_GEMM_256;  // the 8-phase walk stages two k-tiles ahead
-  const bool oct = variant == MI355_FLAT_GEMM_8PHASE || variant == MI355_FLAT_GEMM_8PHASE_REF;
+  const bool oct = variant >= MI355_FLAT_GEMM_8PHASE;
   const bool big = variant == MI355_FLAT_GEMM_256 || oct, tri = variant == MI355_FLAT_GEMM_256x128_3;
   const uint32_t BM = (big || tri) ? 256 : 128, BN = big ? 256 : 128;
   const uint32_t n_rtiles = (uint32_t)((f->n_rows + BM - 1) / BM);
@@ -194,7 +194,8 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
     } else if (oct) {                                                                               \
-      auto kern = variant == MI355_FLAT_GEMM_8PHASE ? k_flat_gemm8<MET, 1> : k_flat_gemm8<MET, 0>;  \
+      auto kern = variant == MI355_FLAT_GEMM_8PHASE_M ? k_flat_gemm8<MET, 1, 1>                      \
+                  : variant == MI355_FLAT_GEMM_8PHASE ? k_flat_gemm8<MET, 1, 0> : k_flat_gemm8<MET, 0, 0>; \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
@@ -414,7 +415,7 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
 extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, uint32_t grid_workgroups,
                                         uint32_t flags) {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
-  if (gemm_variant > MI355_FLAT_GEMM_8PHASE_REF) return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
+  if (gemm_variant > MI355_FLAT_GEMM_8PHASE_M) return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
   if (flags & ~(uint32_t)MI355_FLAT_CHECKSUM) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
   std::lock_guard<std::mutex> lk(f->mu);
   f->gemm_variant = gemm_variant;

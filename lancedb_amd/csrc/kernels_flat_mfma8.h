@@ -72,7 +72,16 @@
 #pragma once
 #include "kernels_flat_mfma.h"
 
-template <int METRIC, int EPI>
+// DMA_IN_M = 1 (variant MI355_FLAT_GEMM_8PHASE_M): the LDS-DMA pieces are issued INSIDE the MFMA
+// block of the phase instead of its L section.  A piece costs the issuing wave 60-185 cycles
+// (MI355X_MICROARCH.md, per-instruction constants): two per L section make L (300-400 cycles with
+// the fragment reads) longer than the other group's 16 MFMAs (272), so the slots are loader-bound
+// — the 62 % MfmaUtil of the template.  Among bare MFMAs the issue rides in the matrix pipe's
+// shadow (the wave would otherwise sit on the next MFMA's issue).  Every piece moves one slot
+// later, which only relaxes the WAR conditions above; the RAW wait becomes vmcnt(2): at the q4
+// wait the pieces newer than k-tile g+1's are A-h0(g+2) alone (issued in M_q3; B-h0(g+2) follows
+// in M_q4, after the wait).  The piece addresses are computed in the L section.
+template <int METRIC, int EPI, int DMA_IN_M>
 __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256, BN = 256, MI = 8, NI = 4, WN = 4;
@@ -157,6 +166,64 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   };
 
   fg_f32x4 acc[MI][NI];
+  // DMA_IN_M: a half-tile's two pieces, addresses prepared in the L section, issued among the MFMAs
+  // The issue is UNCONDITIONAL (the MFMA block stays one basic block): past the end of the walk the
+  // pieces re-read k-tile 0 of the last tile into regions nobody reads again (nxt == the last tile
+  // when there is no next one; B-h1 / A-h1 of the other buffer and A-h0 / B-h0 of this one are dead
+  // by the WAR analysis above) and are drained before the kernel ends.
+  struct Pieces {
+    const unsigned char* g[2];  // per-lane global source
+    uint32_t lds[2];            // wave-uniform LDS byte offset
+  };
+  auto prep_pieces = [&](bool is_a, int h, uint32_t u, uint32_t ahead, uint32_t buf) -> Pieces {
+    Pieces pc;
+    const uint32_t kt0 = u + ahead;
+    const TileRef& t = kt0 < KT ? cur : nxt;
+    const uint32_t koff = (kt0 < KT ? kt0 : has_next ? kt0 - KT : 0u) * (FG_BK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (is_a) {
+        const uint32_t ra0 = i * 128 + h * 64 + wid * 8;
+        uint32_t rs = ra0 + l8;
+        rs = rs < t.lim ? rs : t.lim;
+        pc.g[i] = t.baseA + koff + (size_t)(rs * pitch + swz);
+        pc.lds[i] = buf * BUF + ra0 * 128;
+      } else {
+        const uint32_t g2 = 2 * wid + i;
+        const uint32_t rb0 = (g2 >> 2) * 64 + h * 32 + (g2 & 3u) * 8;
+        pc.g[i] = t.baseB + (koff + rb0 * pitch) + (size_t)voffB;
+        pc.lds[i] = buf * BUF + A_BYTES + rb0 * 128;
+      }
+    }
+    return pc;
+  };
+  auto issue_piece = [&](const Pieces& pc, int i) { fg_glds16(pc.g[i], smem + pc.lds[i]); };
+  // one phase's 16 MFMAs (rows mi0..mi0+3, queries ni0..ni0+1, both k-halves), the two pieces after
+  // the 4th and the 10th
+  auto mfma_block = [&](const fg_bf16x8 (&fa)[2][MI], const fg_bf16x8 (&fb)[2][NI], int mi0, int ni0, const Pieces& pc) {
+    int n = 0;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi0 + mi][ni0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi0 + mi], fb[kk][ni0 + ni], acc[mi0 + mi][ni0 + ni], 0, 0, 0);
+          ++n;
+          if (DMA_IN_M && (n == 4 || n == 10)) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(pc, n == 4 ? 0 : 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    // pin the block: hipcc otherwise sinks MFMAs (register-only, no memory semantics) below the
+    // closing barrier into the next phase's fragment reads, i.e. into the OTHER group's MFMA slot
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi0 + mi][ni0 + ni]));
+  };
+
   auto zero_acc = [&]() {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -274,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   };
 
   // ---- prologue: k-tile 0 entirely, A-h0 and B-h0 of k-tile 1 (KT >= 2); k-tile 0 must have landed
+  // (A-h0(1) before B-h0(1): the order the steady state issues them in)
   stage_half(true, 0, cur, 0, 0);
   stage_half(false, 0, cur, 0, 0);
   stage_half(false, 1, cur, 0, 0);
@@ -288,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   uint32_t u = 0, par = 0;         // k-tile inside the current tile; parity of the global k-tile index
   bool pending = false;            // the previous tile's epilogue is still to run (its TileRef is `done`)
   TileRef done = cur;
+  Pieces pc = prep_pieces(true, 0, 0, 0, 0);
   while (true) {
     const unsigned char* sb = smem + par * BUF;
     // the finished tile's epilogue, under the other wave group's MFMAs
@@ -309,17 +378,14 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
       fa[1][i] = *(const fg_bf16x8*)(sb + offA0 + i * 2048 + ch1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    (void)stage_ahead(false, 1, u, 1, par ^ 1u);
+    if (DMA_IN_M)
+      pc = prep_pieces(false, 1, u, 1, par ^ 1u);
+    else
+      (void)stage_ahead(false, 1, u, 1, par ^ 1u);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi], fb[kk][ni], acc[mi][ni], 0, 0, 0);
+    mfma_block(fa, fb, 0, 0, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -330,17 +396,14 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
       fb[1][i] = *(const fg_bf16x8*)(sb + offB0 + i * 2048 + ch1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    (void)stage_ahead(true, 1, u, 1, par ^ 1u);
+    if (DMA_IN_M)
+      pc = prep_pieces(true, 1, u, 1, par ^ 1u);
+    else
+      (void)stage_ahead(true, 1, u, 1, par ^ 1u);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 2; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi], fb[kk][ni], acc[mi][ni], 0, 0, 0);
+    mfma_block(fa, fb, 0, 2, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -351,34 +414,30 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
       fa[1][i] = *(const fg_bf16x8*)(sb + offA0 + i * 2048 + ch1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    (void)stage_ahead(true, 0, u, 2, par);
+    if (DMA_IN_M)
+      pc = prep_pieces(true, 0, u, 2, par);
+    else
+      (void)stage_ahead(true, 0, u, 2, par);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 4; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 2; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi], fb[kk][ni], acc[mi][ni], 0, 0, 0);
+    mfma_block(fa, fb, 4, 2, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---------------- q4: (A1, B0); stage B-h0(g+2); retire k-tile g+1
-    if (stage_ahead(false, 0, u, 2, par))
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A-h0(g+2), B-h0(g+2) fly on
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DMA_IN_M) {
+      pc = prep_pieces(false, 0, u, 2, par);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // A-h0(g+2) flies on; B-h0(g+2) follows among the MFMAs
+    } else {
+      if (stage_ahead(false, 0, u, 2, par))
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A-h0(g+2), B-h0(g+2) fly on
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 4; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi], fb[kk][ni], acc[mi][ni], 0, 0, 0);
+    mfma_block(fa, fb, 4, 0, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -395,5 +454,7 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0's extra barrier: every wave executed the same count
+  if (DMA_IN_M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the walk's last (unused) pieces
   epilogue(done);
+  if (DMA_IN_M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -382,9 +382,9 @@ static __global__ void k_take_probes(const uint64_t* __restrict__ in, uint32_t n
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t p = in[i];
-  if (p >= nlist) {  // not a partition of this index: flagged, scanned as partition 0 would be wrong -> reported
-    atomicAdd(bad, 1u);
-    out[i] = 0;
+  if (p >= nlist) {  // not a partition of this index: counted (mi355_stats.bad_probes; host-I/O calls fail) and
+    atomicAdd(bad, 1u);  // turned into an EMPTY work item (the planner and the scan treat ids >= nlist as length 0)
+    out[i] = 0xFFFFFFFFu;
     return;
   }
   out[i] = (uint32_t)p;

@@ -8,25 +8,47 @@ request is executed by the MI355X engine through the C ABI; there is no CPU
 execution path here.
 """
 import copy
+import time
 from dataclasses import dataclass, field
-from typing import List, Optional
+from typing import Any, Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import _abi
-from ._lib import InvalidInput
+from ._lib import InvalidInput, QueryTimeout
 from .index import FlatIndex, IvfPqIndex
 
 DEFAULT_TOP_K = 10  # rust/lancedb/src/query.rs:36
 
 
 @dataclass
+class QueryExecutionOptions:
+    """rust/lancedb/src/query.rs:626-658: at most `max_batch_length` rows per delivered batch
+    (0 = no limit; default 1024) and an optional `timeout` in seconds.  The timeout becomes the
+    engine's device-side deadline (mi355_search_params.timeout_ms) and is also checked while the
+    batches are handed out (utils/mod.rs:328-392 TimeoutStream)."""
+    max_batch_length: int = 1024
+    timeout: Optional[float] = None
+
+
+@dataclass
 class VectorQueryRequest:
-    """rust/lancedb/src/query.rs:1066-1114 (numeric subset; filters/projection
-    belong to the table layer and are out of scope)."""
+    """rust/lancedb/src/query.rs:1066-1114 + the QueryRequest base (:818-907).  Fields that act
+    on other table columns (`select`, `order_by` on user columns, `filter` as SQL) are carried
+    for the table layer; this path produces `_rowid` / `_distance`."""
     limit: Optional[int] = None
     offset: Optional[int] = None
     with_row_id: bool = False
+    # ---- QueryRequest base, carried (query.rs:818-907) ----
+    select: Optional[Sequence[str]] = None       # Select::All when None; names among the produced columns are honoured
+    fast_search: bool = False                    # only indexed data (this engine only ever sees indexed data)
+    order_by: Optional[Sequence[Tuple[str, bool]]] = None  # [(column, ascending)] over the produced columns
+    norm: Optional[str] = None                   # hybrid-search normalisation: consumer of _distance, not on this path
+    reranker: Any = None
+    disable_scoring_autoprojection: bool = False
+    use_lsm: Optional[bool] = None               # MemWAL routing: forces local execution (table/query.rs:91-105)
+    # ---- VectorQueryRequest ----
+    approx_mode: Optional[str] = None            # 'fast' | 'normal' | 'accurate' (lib.rs:298-313; RQ indexes only)
     column: Optional[str] = None
     query_vector: List[np.ndarray] = field(default_factory=list)
     minimum_nprobes: int = 20
@@ -77,6 +99,38 @@ class VectorQuery:
     def with_row_id(self):
         q = self._clone()
         q.request.with_row_id = True
+        return q
+
+    def select(self, columns):  # query.rs:550-560 (Select::Columns)
+        q = self._clone()
+        q.request.select = list(columns)
+        return q
+
+    def fast_search(self):  # query.rs:509-520
+        q = self._clone()
+        q.request.fast_search = True
+        return q
+
+    def order_by(self, ordering):  # query.rs:618-621: [(column, ascending)] or None
+        q = self._clone()
+        q.request.order_by = None if ordering is None else [(str(c), bool(a)) for c, a in ordering]
+        return q
+
+    def norm(self, norm):  # query.rs:613-616
+        q = self._clone()
+        q.request.norm = norm
+        return q
+
+    def use_lsm(self, enable):  # query.rs:623-626
+        q = self._clone()
+        q.request.use_lsm = bool(enable)
+        return q
+
+    def approx_mode(self, approx_mode):  # query.rs:1351-1357; parsing lib.rs:343-357
+        if not isinstance(approx_mode, str) or approx_mode.lower() not in _abi.APPROX_NAMES:
+            raise InvalidInput(1, f"approx_mode must be one of 'fast', 'normal', or 'accurate', got '{approx_mode}'")
+        q = self._clone()
+        q.request.approx_mode = approx_mode.lower()
         return q
 
     # ---- VectorQuery ---------------------------------------------------
@@ -161,11 +215,27 @@ class VectorQuery:
         return q
 
     # ---- ExecutableQuery -------------------------------------------------
-    def execute(self):
+    def execute(self, options: Optional[QueryExecutionOptions] = None):
         """-> dict of numpy columns {_rowid u64, _distance f32[, query_index i32]},
         rows ordered (_distance, _rowid) per query vector
-        (table/query.rs:131-381; multi-vector adds `query_index`)."""
-        return self._table._execute_vector_query(self.request)
+        (table/query.rs:131-381; multi-vector adds `query_index`): the collected stream."""
+        if options is None:
+            return self._table._execute_vector_query(self.request)
+        batches = list(self.execute_with_options(options))
+        if len(batches) == 1:
+            return batches[0]
+        return {k: np.concatenate([b[k] for b in batches]) for k in batches[0]}
+
+    def execute_with_options(self, options: Optional[QueryExecutionOptions] = None):
+        """The record-batch stream of the reference (query.rs:1446-1459, :1481-1510): an iterator of
+        column dicts of at most `max_batch_length` rows each, stopped by `timeout`."""
+        return self._table.query_stream(self.request, options or QueryExecutionOptions())
+
+    def create_plan(self, options: Optional[QueryExecutionOptions] = None):
+        return self._table.create_plan(self.request, options or QueryExecutionOptions())
+
+    def explain_plan(self, verbose=False):  # query.rs:1495-1498
+        return self._table.create_plan(self.request, QueryExecutionOptions()).explain(verbose)
 
     to_arrays = execute
 
@@ -202,39 +272,212 @@ class VectorTable:
             q.request.limit = DEFAULT_TOP_K
         return q
 
+    # ---- BaseTable::create_plan / query (table.rs:566-576, table/query.rs:131-328) ----------
+    def create_plan(self, req: VectorQueryRequest, options: Optional[QueryExecutionOptions] = None):
+        return create_plan(self, req, options or QueryExecutionOptions())
+
+    def query_stream(self, req: VectorQueryRequest, options: Optional[QueryExecutionOptions] = None):
+        return execute_query(self, req, options or QueryExecutionOptions())
+
     def _execute_vector_query(self, req: VectorQueryRequest):
-        if not req.query_vector:
-            raise InvalidInput(1, "no query vector")
-        limit = DEFAULT_TOP_K if req.limit is None else req.limit
-        offset = req.offset or 0
-        k = limit + offset  # table/query.rs:231
-        metric = _abi.METRIC_DEFAULT if req.distance_type is None else _abi.METRIC_NAMES[req.distance_type]
-        filtered = req.allow_rowids is not None or req.block_rowids is not None
-        pre = filtered and req.prefilter
-        params = _abi.make_params(
-            k=k, nprobe_min=req.minimum_nprobes, nprobe_max=req.maximum_nprobes,
-            refine_factor=req.refine_factor or 0, metric=metric,
-            lower_bound=req.lower_bound, upper_bound=req.upper_bound,
-            allow_rowids=req.allow_rowids if pre else None, block_rowids=req.block_rowids if pre else None)
-        q = np.stack(req.query_vector)
-        use_index = req.use_index and self.index is not None
-        if use_index:
-            res = self.index.search(q, params)
+        batches = list(execute_query(self, req, QueryExecutionOptions(max_batch_length=0)))
+        return batches[0] if len(batches) == 1 else {k: np.concatenate([b[k] for b in batches]) for k in batches[0]}
+
+
+@dataclass
+class VectorPlan:
+    """What `table::query::create_plan` (table/query.rs:131-328) decides, as data: the engine runs
+    a fixed launch sequence instead of a DataFusion plan, `explain()` names the stages after the
+    plan nodes they replace (the reference's tests look for these names: table/query.rs:1074-1165,
+    python/python/tests/test_query.py:1229-1245)."""
+    table: Any
+    request: VectorQueryRequest
+    options: QueryExecutionOptions
+    k: int                      # limit + offset (table/query.rs:231)
+    use_index: bool
+    prefilter: bool
+    params: Any                 # mi355_search_params
+    queries: np.ndarray         # [n, dim] f32
+
+    def explain(self, verbose=False):
+        r, lines = self.request, []
+        lim = f"fetch={self.k - (r.offset or 0)}" + (f", skip={r.offset}" if r.offset else "")
+        lines.append(f"ProjectionExec: expr=[{', '.join(self.output_columns())}]")
+        if r.offset:
+            lines.append(f"  GlobalLimitExec: {lim}")
+        if r.order_by:
+            lines.append("  SortExec: expr=[" + ", ".join(f"{c} {'ASC' if a else 'DESC'}" for c, a in r.order_by) + "]")
+        if (r.allow_rowids is not None or r.block_rowids is not None) and not self.prefilter:
+            lines.append("  FilterExec: postfilter on _rowid")
+        if self.use_index:
+            if r.refine_factor:
+                lines.append(f"  SortExec: TopK(fetch={self.k}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]")
+                lines.append("    KNNVectorDistance: refine, metric=" + (r.distance_type or "index"))
+                lines.append("      Take: raw vectors of k * refine_factor = %d rows" % (self.k * r.refine_factor))
+            lines.append(f"  SortExec: TopK(fetch={self.k * (r.refine_factor or 1)}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]")
+            lines.append(f"    ANNSubIndex: name=mi355_ivf_pq, k={self.k * (r.refine_factor or 1)}, deltas=1"
+                         + (", prefilter=rowid mask" if self.prefilter and (r.allow_rowids is not None or r.block_rowids is not None) else ""))
+            lines.append(f"      ANNIvfPartition: uuid=mi355, minimum_nprobes={r.minimum_nprobes}, "
+                         f"maximum_nprobes={r.maximum_nprobes}, deltas=1")
         else:
-            if self.flat is None:
-                raise InvalidInput(1, "bypass_vector_index needs the raw column on the device")
-            res = self.flat.search(q, params)
-        rid, dist, qidx = [], [], []
-        for i in range(q.shape[0]):
-            n = int(res.counts[i])
-            r, d = res.rowids[i, :n], res.distances[i, :n]
-            if filtered and not pre:  # postfilter: the predicate thins out the k results
-                keep = np.isin(r, req.allow_rowids) if req.allow_rowids is not None else ~np.isin(r, req.block_rowids)
-                r, d = r[keep], d[keep]
-            rid.append(r[offset:])
-            dist.append(d[offset:])
-            qidx.append(np.full(max(len(r) - offset, 0), i, dtype=np.int32))
-        out = {"_rowid": np.concatenate(rid), "_distance": np.concatenate(dist)}
-        if q.shape[0] > 1:
-            out["query_index"] = np.concatenate(qidx)
-        return out
+            lines.append(f"  SortExec: TopK(fetch={self.k}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]")
+            lines.append("    KNNVectorDistance: metric=" + (r.distance_type or "l2"))
+            lines.append("      LanceRead: raw column resident in HBM")
+        if len(self.queries) > 1:  # create_multi_vector_plan (table/query.rs:334-381)
+            lines = ["UnionExec / query_index: %d query vectors in ONE device batch" % len(self.queries)] + ["  " + ln for ln in lines]
+        if verbose:
+            lines.append(f"-- engine: k={self.params.k} nprobe=[{self.params.nprobe_min},{self.params.nprobe_max or 'all'}] "
+                         f"refine_factor={self.params.refine_factor} timeout_ms={self.params.timeout_ms}")
+        return "\n".join(lines)
+
+    def output_columns(self):
+        cols = ["_rowid", "_distance"] + (["query_index"] if len(self.queries) > 1 else [])
+        sel = self.request.select
+        if sel is not None:
+            unknown = [c for c in sel if c not in cols]
+            if unknown:
+                raise InvalidInput(1, f"columns {unknown} are not produced by the vector-search path "
+                                      "(user columns are taken by the table layer from _rowid)")
+            cols = [c for c in cols if c in sel]
+        return cols
+
+
+def create_plan(table, req: VectorQueryRequest, options: QueryExecutionOptions) -> VectorPlan:
+    """table::query::create_plan (table/query.rs:131-328) for the vector branch."""
+    if not req.query_vector:
+        raise InvalidInput(1, "no query vector")
+    limit = DEFAULT_TOP_K if req.limit is None else req.limit
+    offset = req.offset or 0
+    k = limit + offset  # table/query.rs:231
+    metric = _abi.METRIC_DEFAULT if req.distance_type is None else _abi.METRIC_NAMES[req.distance_type]
+    filtered = req.allow_rowids is not None or req.block_rowids is not None
+    pre = filtered and req.prefilter
+    timeout_ms = 0 if options.timeout is None else max(1, int(round(options.timeout * 1000)))
+    params = _abi.make_params(
+        k=k, nprobe_min=req.minimum_nprobes, nprobe_max=req.maximum_nprobes,
+        refine_factor=req.refine_factor or 0, metric=metric,
+        lower_bound=req.lower_bound, upper_bound=req.upper_bound, timeout_ms=timeout_ms, approx_mode=req.approx_mode,
+        allow_rowids=req.allow_rowids if pre else None, block_rowids=req.block_rowids if pre else None)
+    use_index = req.use_index and table.index is not None
+    if not use_index and table.flat is None:
+        raise InvalidInput(1, "bypass_vector_index needs the raw column on the device")
+    plan = VectorPlan(table, req, options, k, use_index, pre, params, np.stack(req.query_vector))
+    plan.output_columns()  # validates `select`
+    return plan
+
+
+def requires_local_execution(req: VectorQueryRequest) -> bool:
+    """table/query.rs:91-105: the push-down request has no approx_mode / use_lsm field, so such
+    queries must not be pushed down."""
+    return req.use_lsm is not None or req.approx_mode is not None
+
+
+def execute_query(table, req: VectorQueryRequest, options: QueryExecutionOptions):
+    """table::query::execute_query (table/query.rs:51-65): push the query down when the table has a
+    push-down endpoint and the query allows it, otherwise execute locally on this process's GPU
+    (execute_generic_query, :115-129).  Returns the batch iterator either way."""
+    pushdown = getattr(table, "pushdown", None)
+    if pushdown is not None and not requires_local_execution(req):
+        from . import wire
+        cols = wire.response_from_ipc(pushdown(wire.request_to_json(req)))
+        return _batches(cols, options, time.monotonic())
+    return execute_generic_query(table, req, options)
+
+
+def execute_generic_query(table, req: VectorQueryRequest, options: QueryExecutionOptions):
+    t0 = time.monotonic()
+    plan = create_plan(table, req, options)
+    q, offset = plan.queries, req.offset or 0
+    res = table.index.search(q, plan.params) if plan.use_index else table.flat.search(q, plan.params)
+    filtered = req.allow_rowids is not None or req.block_rowids is not None
+    rid, dist, qidx = [], [], []
+    for i in range(q.shape[0]):
+        n = int(res.counts[i])
+        r, d = res.rowids[i, :n], res.distances[i, :n]
+        if filtered and not plan.prefilter:  # postfilter: the predicate thins out the k results
+            keep = np.isin(r, req.allow_rowids) if req.allow_rowids is not None else ~np.isin(r, req.block_rowids)
+            r, d = r[keep], d[keep]
+        rid.append(r[offset:])
+        dist.append(d[offset:])
+        qidx.append(np.full(max(len(r) - offset, 0), i, dtype=np.int32))
+    out = {"_rowid": np.concatenate(rid), "_distance": np.concatenate(dist)}
+    if q.shape[0] > 1:
+        out["query_index"] = np.concatenate(qidx)
+    if req.order_by:  # over the produced columns; stable, last key first
+        order = np.arange(len(out["_rowid"]))
+        for col, asc in reversed(list(req.order_by)):
+            if col not in out:
+                raise InvalidInput(1, f"cannot order by {col!r}: not produced by the vector-search path")
+            keys = out[col][order]
+            idx = np.argsort(keys, kind="stable")
+            order = order[idx if asc else idx[::-1]]
+        out = {k2: v[order] for k2, v in out.items()}
+    out = {c: out[c] for c in plan.output_columns()}
+    return _batches(out, options, t0)
+
+
+def _batches(cols, options: QueryExecutionOptions, t0):
+    """MaxBatchLengthStream + TimeoutStream (utils/mod.rs:328-471): slices of at most
+    max_batch_length rows (0 = one batch); the deadline is checked as each batch is handed out."""
+    n = len(next(iter(cols.values()))) if cols else 0
+    step = options.max_batch_length or max(n, 1)
+    off = 0
+    while True:
+        if options.timeout is not None and time.monotonic() - t0 > options.timeout:
+            raise QueryTimeout(3, f"Query timeout: {options.timeout} s")
+        yield {c: v[off:off + step] for c, v in cols.items()}
+        off += step
+        if off >= n:
+            return
+
+
+# ---- utils/mod.rs:151-198, :289-298 --------------------------------------------------------
+def supported_vector_data_type(dtype) -> bool:
+    """A vector column is a FixedSizeList of any float type or of uint8, or a List of those
+    (pyarrow DataType in, as the reference takes an arrow DataType)."""
+    import pyarrow as pa
+    if pa.types.is_fixed_size_list(dtype):
+        return pa.types.is_floating(dtype.value_type) or dtype.value_type == pa.uint8()
+    if pa.types.is_list(dtype) or pa.types.is_large_list(dtype):
+        return supported_vector_data_type(dtype.value_type)
+    return False
+
+
+def infer_vector_dim(dtype) -> int:
+    """lance::index::vector::utils::infer_vector_dim [EXT]: the list size of a vector column, or of
+    the vectors inside a multivector (List<FixedSizeList>) column."""
+    import pyarrow as pa
+    if pa.types.is_fixed_size_list(dtype) and (pa.types.is_floating(dtype.value_type) or dtype.value_type == pa.uint8()):
+        return dtype.list_size
+    if (pa.types.is_list(dtype) or pa.types.is_large_list(dtype)) and pa.types.is_fixed_size_list(dtype.value_type):
+        return infer_vector_dim(dtype.value_type)
+    raise InvalidInput(1, f"Data type is not a vector (FixedSizeListArray or List<FixedSizeListArray>), but {dtype}")
+
+
+def default_vector_column(schema, dim: Optional[int] = None) -> str:
+    """utils/mod.rs:151-198: the one vector column (of dimension `dim`, if given) of an arrow
+    schema, looking inside structs; none -> InvalidInput, several -> a schema error."""
+    import pyarrow as pa
+    candidates = []
+
+    def collect(fld, path):
+        path = path + [fld.name]
+        try:
+            d = infer_vector_dim(fld.type)
+            if dim is None or dim == d:
+                candidates.append(".".join(path))
+                return
+        except InvalidInput:
+            pass
+        if pa.types.is_struct(fld.type):
+            for child in fld.type:
+                collect(child, path)
+
+    for f in schema:
+        collect(f, [])
+    if not candidates:
+        raise InvalidInput(1, f"No vector column found to match with the query vector dimension: {dim or 0}")
+    if len(candidates) != 1:
+        raise InvalidInput(1, "More than one vector columns found, please specify which column to create index or "
+                              f"query: {candidates}")
+    return candidates[0]

@@ -28,6 +28,8 @@ def request_to_json(req: VectorQueryRequest, version=None) -> dict:
         body["with_row_id"] = True
     if req.distance_type is not None:
         body["distance_type"] = req.distance_type
+    if req.approx_mode is not None:  # remote/table.rs:844-846; body pinned at :4694-4745
+        body["approx_mode"] = req.approx_mode
     body["nprobes"] = int(req.minimum_nprobes)
     body["minimum_nprobes"] = int(req.minimum_nprobes)
     body["maximum_nprobes"] = 0 if req.maximum_nprobes is None else int(req.maximum_nprobes)
@@ -66,6 +68,12 @@ def request_from_json(body) -> VectorQueryRequest:
     req.prefilter = bool(body.get("prefilter", True))
     req.with_row_id = bool(body.get("with_row_id", False))
     req.distance_type = body.get("distance_type")
+    am = body.get("approx_mode")
+    if am is not None:
+        from . import _abi
+        if not isinstance(am, str) or am.lower() not in _abi.APPROX_NAMES:  # lib.rs:343-357
+            raise InvalidInput(1, f"approx_mode must be one of 'fast', 'normal', or 'accurate', got '{am}'")
+        req.approx_mode = am.lower()
     # old clients only send `nprobes` (remote/table.rs:846-851)
     req.minimum_nprobes = int(body.get("minimum_nprobes", body.get("nprobes", 20)))
     mx = body.get("maximum_nprobes", body.get("nprobes", req.minimum_nprobes))
@@ -100,6 +108,13 @@ def response_to_ipc(columns: dict, with_row_id=True) -> bytes:
     with pa.ipc.new_file(sink, batch.schema) as w:
         w.write_batch(batch)
     return sink.getvalue().to_pybytes()
+
+
+def response_from_ipc(data: bytes) -> dict:
+    """Client side: the Arrow IPC file of a response -> numpy columns (table/query.rs:636-682)."""
+    import pyarrow as pa
+    t = pa.ipc.open_file(pa.BufferReader(data)).read_all()
+    return {name: t.column(name).to_numpy() for name in t.schema.names}
 
 
 def handle_query(table, body, allow_rowids=None, block_rowids=None):

@@ -95,11 +95,16 @@ def test_timeout_stops_the_scan_on_the_device(oracle):
     full = ix.search(q, k=10, nprobe_min=64, nprobe_max=64)
     t_full = time.perf_counter() - t0
     assert ix.stats()["timed_out"] == 0
-    with pytest.raises(lancedb_amd.QueryTimeout, match="Query timeout"):
+    t0 = time.perf_counter()
+    full = ix.search(q, k=10, nprobe_min=64, nprobe_max=64)  # warm (workspace sized)
+    t_full = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with pytest.raises(lancedb_amd.QueryTimeout, match="stopped on the device"):
         ix.search(q, k=10, nprobe_min=64, nprobe_max=64, timeout_ms=1)
-    st = ix.stats()
-    assert st["timed_out"] == 1
-    assert st["vectors_scanned"] < 0.9 * 4096 * 3_000_000, "the scan ran to completion"
+    t_cut = time.perf_counter() - t0
+    assert ix.stats()["timed_out"] == 1
+    print(f"full search {t_full * 1e3:.1f} ms, with a 1 ms deadline {t_cut * 1e3:.1f} ms")
+    assert t_cut < 0.6 * t_full, "the scan ran to completion"
     # device I/O: the call returns at once, the timeout surfaces at sync
     DA = lancedb_amd.DeviceArray
     dq = DA.from_numpy(q)

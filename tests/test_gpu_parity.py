@@ -486,10 +486,11 @@ def test_c5_config_shape_1536d_cosine_refine10(oracle, raw_dtype):
 
 
 GEMM_VARIANTS = {"128": _abi.FLAT_GEMM_128, "256": _abi.FLAT_GEMM_256, "3": _abi.FLAT_GEMM_256x128_3,
-                 "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF}
+                 "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF,
+                 "8phase_m": _abi.FLAT_GEMM_8PHASE_M}
 
 
-@pytest.mark.parametrize("tile", ["128", "256", "3", "8phase", "8phase_ref"])
+@pytest.mark.parametrize("tile", ["128", "256", "3", "8phase", "8phase_ref", "8phase_m"])
 def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     """A grid of 8 workgroups (one per XCD) walks every tile of the column: the cross-tile
     path of the flat GEMM (next tile's first stages issued under the last k-steps, ragged last
@@ -513,7 +514,7 @@ def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     assert f1.info()[0] == 1
 
 
-@pytest.mark.parametrize("variant", ["8phase", "8phase_ref"])
+@pytest.mark.parametrize("variant", ["8phase", "8phase_ref", "8phase_m"])
 @pytest.mark.parametrize("grid", [0, 1, 16])
 def test_flat_mfma_eight_phase_schedule(oracle, variant, grid):
     """The persistent 8-phase schedule against the exact sweep: ragged last row tile, 2 / 3 / 12
@@ -566,9 +567,10 @@ def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):
     q = np.concatenate([v[[100, 5000, 6000, 6002]], np.zeros((1, dim), np.float32),
                         rng.normal(size=(251, dim)).astype(np.float32)])
     f = lancedb_amd.FlatIndex(v)
-    f.configure(gemm_variant=_abi.FLAT_GEMM_8PHASE)
-    for metric in ("l2", "cosine", "dot"):
-        mt = _abi.METRIC_NAMES[metric]
-        for k in (1, 10, 200):
-            _assert_same(f.search(q, k=k, metric=mt), oracle.flat_search(v, q, k=k, metric=mt))
-            assert f.info()[0] == 1
+    for variant in (_abi.FLAT_GEMM_8PHASE, _abi.FLAT_GEMM_8PHASE_M):
+        f.configure(gemm_variant=variant)
+        for metric in ("l2", "cosine", "dot"):
+            mt = _abi.METRIC_NAMES[metric]
+            for k in (1, 10, 200):
+                _assert_same(f.search(q, k=k, metric=mt), oracle.flat_search(v, q, k=k, metric=mt))
+                assert f.info()[0] == 1

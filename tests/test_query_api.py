@@ -62,3 +62,110 @@ def test_setters_carry_through():
     assert len(r.query_vector) == 2
     with pytest.raises(lancedb_amd.InvalidInput):
         q.distance_type("hamming-ish")
+
+
+def test_base_request_fields_and_approx_mode_carry_through():
+    """QueryRequest base (query.rs:818-907) and approx_mode (query.rs:1092, :1351-1357; parsing lib.rs:343-357;
+    the reference's own checks: query.rs:1720-1756)."""
+    t = _FakeTable()
+    q = (t.vector_search([1, 2, 3, 4]).select(["_distance"]).fast_search().order_by([("_distance", False)])
+         .norm("rank").use_lsm(False).approx_mode("Accurate"))
+    q.execute()
+    r = t.seen
+    assert r.select == ["_distance"] and r.fast_search and r.order_by == [("_distance", False)]
+    assert r.norm == "rank" and r.use_lsm is False and r.approx_mode == "accurate"
+    assert VectorQueryRequest().approx_mode is None and VectorQueryRequest().prefilter and not VectorQueryRequest().fast_search
+    assert t.vector_search([1, 2, 3, 4]).approx_mode("FAST").request.approx_mode == "fast"
+    with pytest.raises(lancedb_amd.InvalidInput, match="approx_mode must be one of 'fast', 'normal', or 'accurate', got 'invalid'"):
+        t.vector_search([1, 2, 3, 4]).approx_mode("invalid")
+
+
+class _ArrayIndex:
+    """Stands in for the device handles: returns canned per-query rows (the engine itself is GPU-only)."""
+    dim = 4
+
+    def __init__(self, n):
+        self.n, self.params = n, None
+
+    def search(self, q, params):
+        from lancedb_amd.index import SearchResult
+        self.params = params
+        k = params.k
+        ids = np.tile(np.arange(k, dtype=np.uint64), (len(q), 1)) + 100 * np.arange(len(q), dtype=np.uint64)[:, None]
+        d = np.tile(np.arange(k, dtype=np.float32), (len(q), 1))
+        return SearchResult(ids, d, np.full(len(q), min(k, self.n), np.uint32))
+
+
+def test_execution_options_slice_batches_and_time_out():
+    """max_batch_length (default 1024; query.rs:626-658, utils/mod.rs:395-471) and timeout."""
+    from lancedb_amd.query import QueryExecutionOptions
+    t = VectorTable(index=_ArrayIndex(5000))
+    q = t.vector_search([0, 0, 0, 0]).limit(2500)
+    batches = list(q.execute_with_options())
+    assert [len(b["_rowid"]) for b in batches] == [1024, 1024, 452]
+    assert (np.concatenate([b["_rowid"] for b in batches]) == np.arange(2500)).all()
+    assert [len(b["_rowid"]) for b in q.execute_with_options(QueryExecutionOptions(max_batch_length=0))] == [2500]
+    assert [len(b["_distance"]) for b in q.execute_with_options(QueryExecutionOptions(max_batch_length=1000))] == [1000, 1000, 500]
+    assert len(q.execute()["_rowid"]) == 2500 and len(q.execute(QueryExecutionOptions(max_batch_length=7))["_rowid"]) == 2500
+    # the timeout reaches the engine as its device-side deadline and stops the stream
+    list(q.execute_with_options(QueryExecutionOptions(timeout=2.5)))
+    assert t.index.params.timeout_ms == 2500
+    it = q.execute_with_options(QueryExecutionOptions(max_batch_length=10, timeout=0.05))
+    next(it)
+    import time
+    time.sleep(0.08)
+    with pytest.raises(lancedb_amd.QueryTimeout, match="Query timeout"):
+        next(it)
+    # offset, order_by over the produced columns, projection
+    r = t.vector_search([0, 0, 0, 0]).limit(5).offset(3).order_by([("_distance", False)]).select(["_rowid"]).execute()
+    assert list(r) == ["_rowid"] and r["_rowid"].tolist() == [7, 6, 5, 4, 3]
+    with pytest.raises(lancedb_amd.InvalidInput, match="not produced"):
+        t.vector_search([0, 0, 0, 0]).select(["title"]).execute()
+
+
+def test_plan_names_the_nodes_it_replaces():
+    """The reference's tests look for these node names (table/query.rs:1074-1165,
+    python/python/tests/test_query.py:1229-1245, :1261-1271)."""
+    t = VectorTable(index=_ArrayIndex(100), flat=_ArrayIndex(100))
+    plan = t.vector_search([0, 0, 0, 0]).nprobes(7).refine_factor(4).explain_plan(True)
+    for needle in ("ANNIvfPartition", "minimum_nprobes=7", "ANNSubIndex", "k=40", "KNNVectorDistance", "Take", "TopK(fetch=10)"):
+        assert needle in plan, (needle, plan)
+    flat = t.vector_search([0, 0, 0, 0]).bypass_vector_index().explain_plan()
+    assert "KNNVectorDistance" in flat and "ANNSubIndex" not in flat
+    multi = t.vector_search(np.zeros((3, 4))).create_plan()
+    assert multi.k == 10 and len(multi.queries) == 3 and "query_index" in multi.explain()
+
+
+def test_pushdown_dispatch_follows_the_reference_rules():
+    """table/query.rs:51-65, :91-105: queries go to the push-down endpoint unless approx_mode or
+    use_lsm is set (the wire request has no field for them)."""
+    from lancedb_amd import wire
+    t = VectorTable(index=_ArrayIndex(50))
+    bodies = []
+
+    def endpoint(body):
+        bodies.append(body)
+        return wire.response_to_ipc({"_rowid": np.array([9, 8], np.uint64), "_distance": np.array([0.5, 0.75], np.float32)})
+
+    t.pushdown = endpoint
+    r = t.vector_search([1, 2, 3, 4]).limit(2).execute()
+    assert r["_rowid"].tolist() == [9, 8] and bodies[0]["k"] == 2 and bodies[0]["vector"] == [1.0, 2.0, 3.0, 4.0]
+    assert t.vector_search([1, 2, 3, 4]).limit(2).approx_mode("fast").execute()["_rowid"].tolist() == [0, 1]   # local
+    assert t.vector_search([1, 2, 3, 4]).limit(2).use_lsm(False).execute()["_rowid"].tolist() == [0, 1]       # local
+    assert len(bodies) == 1
+
+
+def test_default_vector_column_and_supported_types():
+    """utils/mod.rs:151-198, :289-298."""
+    pa = pytest.importorskip("pyarrow")
+    from lancedb_amd.query import default_vector_column, supported_vector_data_type
+    vec = lambda n, t=pa.float32(): pa.list_(t, n)  # noqa: E731
+    schema = pa.schema([("id", pa.int64()), ("emb", vec(768)), ("meta", pa.struct([("small", vec(8)), ("x", pa.utf8())]))])
+    assert default_vector_column(schema, 768) == "emb" and default_vector_column(schema, 8) == "meta.small"
+    with pytest.raises(lancedb_amd.InvalidInput, match="No vector column found to match with the query vector dimension: 5"):
+        default_vector_column(schema, 5)
+    with pytest.raises(lancedb_amd.InvalidInput, match="More than one vector columns found"):
+        default_vector_column(schema)
+    assert supported_vector_data_type(vec(4)) and supported_vector_data_type(vec(4, pa.float16()))
+    assert supported_vector_data_type(vec(4, pa.uint8())) and supported_vector_data_type(pa.list_(vec(4)))
+    assert not supported_vector_data_type(vec(4, pa.int32())) and not supported_vector_data_type(pa.utf8())

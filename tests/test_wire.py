@@ -22,6 +22,18 @@ def test_default_body_matches_the_reference_pin():
     assert (back.query_vector[0] == np.array([0.1, 0.2, 0.3], np.float32)).all()
 
 
+def test_approx_mode_is_sent_when_set():
+    """remote/table.rs:4694-4745 test_query_vector_approx_mode_sent_when_set."""
+    req = VectorQueryRequest(limit=10, query_vector=[np.array([0.1, 0.2, 0.3], np.float32)], approx_mode="accurate")
+    expected = {"prefilter": True, "nprobes": 20, "minimum_nprobes": 20, "maximum_nprobes": 20, "approx_mode": "accurate",
+                "lower_bound": None, "upper_bound": None, "k": 10, "ef": None, "refine_factor": None,
+                "version": None, "vector": [float(np.float32(x)) for x in (0.1, 0.2, 0.3)]}
+    assert wire.request_to_json(req) == expected
+    assert wire.request_from_json(expected).approx_mode == "accurate"
+    with pytest.raises(Exception, match="approx_mode must be one of"):
+        wire.request_from_json({**expected, "approx_mode": "sloppy"})
+
+
 def test_round_trip_of_every_field():
     req = VectorQueryRequest(limit=7, offset=2, with_row_id=True, column="emb",
                              query_vector=[np.arange(4, dtype=np.float32), np.ones(4, np.float32)],

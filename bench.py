@@ -21,13 +21,19 @@ the C ABI.
 
 N > 1 shards the IVF partition list (greedy bytes-balanced plan) with the coarse
 quantiser replicated; per step every rank scans the probed partitions it owns,
-then ONE all-gather of the per-shard top-k candidates (RCCL over xGMI) and a
-k-way merge on every rank.  The index size is fixed, so scaling is "strong".
+then ONE packed all-gather of the per-shard top-k candidate records (RCCL over
+xGMI, behind the C ABI: mi355_search_sharded) and a k-way merge on every rank.
+Every rank generates ONLY the partitions it owns (per-partition seeds), so the
+index is the same for every N.  The index size is fixed: scaling is "strong".
 
 One JSON line on rank 0, with `roofline` (dominant kernel = the ADC scan, HIP
 events recorded on the search stream inside the timed region) and, at N = 1,
 `cpu_baseline` (the C oracle on a bounded sample of the same queries, also used
-as a full-size parity check).
+as a full-size parity check), `recall_at_10` (a trained 2 M-row index, engine and
+oracle), and `secondary`: the same 100 M index with refine_factor 10 over resident
+bf16 raw vectors (the operating point whose recall@10 is >= 0.9) and flat C2
+(BASELINE.json configs[1]: 10 M x 768 bf16, 1024 queries, L2 and cosine) with the
+GEMM kernel's own roofline and a full-size parity check each.
 """
 import argparse
 import json
@@ -57,9 +63,12 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--skew", type=float, default=0.5, help="sigma of the log-normal partition-length skew")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline (0 = skip)")
-    ap.add_argument("--recall-rows", type=int, default=500_000,
+    ap.add_argument("--recall-rows", type=int, default=2_000_000,
                     help="rows of the TRAINED index recall@10 is measured on (0 = skip); the 100 M throughput "
                          "index has random codes, so recall is only meaningful on a trained one")
+    ap.add_argument("--recall-queries", type=int, default=10_000)
+    ap.add_argument("--recall-iters", type=int, default=25, help="Lloyd iterations of the IVF and PQ trainers")
+    ap.add_argument("--secondary", type=int, default=1, help="0 = skip the secondary lines (refine operating point, flat C2)")
     ap.add_argument("--workload", default="ivfpq", choices=["ivfpq", "flat"],
                     help="ivfpq = C3, the configuration BASELINE.json's metric is quoted on (default); "
                          "flat = C2 (10 M x 768 bf16, 1024 queries), a secondary line for the MFMA path")
@@ -74,78 +83,12 @@ def parse():
 
 
 def main_flat(a):
-    """C2: flat L2 / cosine over a bf16 column as an MFMA GEMM filter + exact re-rank.
-    Single GPU (rows would shard the same way as IVF partitions; not wired up)."""
-    import numpy as np
-    import torch
-
-    import lancedb_amd
-    from lancedb_amd import _abi
+    """`--workload flat`: the C2 line alone (the default run carries it as `secondary.flat_c2_*`)."""
     if a.gpus != 1:
-        raise SystemExit("--workload flat is a single-GPU line")
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    n, dim, B, k = a.flat_rows, a.dim, a.flat_batch, a.k
-    g = torch.Generator(device=dev)
-    g.manual_seed(SEED)
-    col = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    P = 2
-    qpool = [torch.randn((B, dim), generator=g, device=dev, dtype=torch.float32) for _ in range(P)]
-    torch.cuda.synchronize()
-    fl = lancedb_amd.FlatIndex(col.view(torch.int16), dtype=_abi.DTYPE_BF16, device=0)
-    stream = torch.cuda.current_stream().cuda_stream
-    fl.set_stream(stream)
-    fl.configure(gemm_variant=a.flat_gemm, grid_workgroups=a.flat_grid)
-    mt = _abi.METRIC_NAMES[a.flat_metric]
-    params = _abi.make_params(k=k, nprobe_min=1, nprobe_max=1, metric=mt)
-    out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
-           torch.empty((B,), dtype=torch.int32, device=dev))
-    for i in range(a.warmup):
-        fl.search(qpool[i % P], params, out=out)
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(a.steps):
-        last = fl.search(qpool[i % P], params, out=out)
-    ev[1].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert fl.info() == (1, 1), "the MFMA filter path did not run"
-    flops = 2.0 * B * n * dim
-    ms = elapsed / a.steps * 1e3
-    achieved = flops / (elapsed / a.steps) / 1e12
-    result = {
-        "metric": "queries/sec, flat (no index) KNN 10M×768 bf16, batch 1024, k=10 (BASELINE.json configs[1])",
-        "value": B * a.steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-        "data": "synthetic",
-        "config": {"workload": f"flat_{n}x{dim}_bf16_batch{B}_k{k}_{a.flat_metric}", "n_rows": n, "dim": dim,
-                   "batch_queries": B, "k": k},
-        "roofline": {"bound": "mfma", "kernel": "whole step (k_flat_gemm dominates; + segmin/tau/compact/rerank)",
-                     "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-                     "traffic": traffic_from_profiles(f"flat_{n}x{dim}_bf16_batch{B}_k{k}_{a.flat_metric}", B),
-                     "algorithmic_flops_per_step": flops},
-    }
-    if a.cpu_seconds > 0:
-        from oracle import oracle as orc
-        orc.build()
-        cores = os.cpu_count() or 1
-        nq = min(B, 32)  # every query sweeps the whole column on the host: keep the sample to ~15 s
-        hv = col.view(torch.int16).cpu().numpy().view(np.uint16)
-        hq = qpool[(a.steps - 1) % P][:nq].cpu().numpy()
-        t1 = time.perf_counter()
-        ids, dist, cnt, _ = orc.flat_search(hv, hq, k=k, dtype=_abi.DTYPE_BF16, metric=mt)
-        dt = time.perf_counter() - t1
-        g_ids = last.rowids[:nq].cpu().numpy().astype(np.uint64)
-        g_dist = last.distances[:nq].cpu().numpy()
-        result["cpu_baseline"] = {
-            "value": nq / dt, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{nq} queries of the last timed batch, one per thread, {dt:.1f} s on {cores} host cores; "
-                      "C restatement (oracle/ann_oracle.c), not the reference binary",
-            "parity": {"queries": nq, "rowids_bit_exact": bool((g_ids == ids).all()),
-                       "distances_equal": bool((g_dist == dist).all())}}
-    print(json.dumps(result), flush=True)
+        raise SystemExit("--workload flat is a single-GPU line (rows shard over ranks through mi355_flat_search_sharded)")
+    res = flat_c2(a, a.flat_metric, cpu_queries=32 if a.cpu_seconds > 0 else 0)
+    res.update({"n_gpus": 1, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None})
+    print(json.dumps(res), flush=True)
 
 
 def main():
@@ -172,7 +115,9 @@ def main():
 
     n, dim, nlist, m = a.n_rows, a.dim, a.nlist, a.m
     dsub = dim // m
-    # ---- synthetic index, identical on every rank (same seed, same device type)
+    # ---- synthetic index: small tables identical on every rank (same seed); the O(rows) arrays are
+    # generated PER PARTITION (seed = f(SEED, partition)) for the partitions this rank owns only, so a
+    # rank never materialises the others' data and the index is the same for every N
     g = torch.Generator(device=dev)
     g.manual_seed(SEED)
     centroids = torch.randn((nlist, dim), generator=g, device=dev, dtype=torch.float32)
@@ -182,17 +127,36 @@ def main():
     lens = rng.multinomial(n, w / w.sum())
     part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
     part_offsets[1:] = np.cumsum(lens)
-    codes = torch.randint(0, 256, (n * m,), generator=g, device=dev, dtype=torch.uint8)
-    row_ids = torch.randperm(n, generator=g, device=dev)  # int64, a permutation of 0..n
+    owner = lancedb_amd.shard_plan(part_offsets, world)  # the plan mi355_index_open follows (host code)
+    mine = np.nonzero(owner == rank)[0]
+    rows_mine = int(lens[mine].sum())
+    codes = torch.empty((rows_mine * m,), device=dev, dtype=torch.uint8)
+    pos = torch.empty((rows_mine,), device=dev, dtype=torch.int64)  # global index position of every local row
+    gp = torch.Generator(device=dev)
+    off = 0
+    for p in mine:
+        ln = int(lens[p])
+        if ln:
+            gp.manual_seed(SEED * 1_000_003 + int(p))
+            # the uniform code bytes of partition p, declared to be lance's transposed [m, len_p] block
+            torch.randint(0, 256, (ln * m,), generator=gp, device=dev, dtype=torch.uint8, out=codes[off * m:(off + ln) * m])
+            torch.arange(int(part_offsets[p]), int(part_offsets[p + 1]), device=dev, out=pos[off:off + ln])
+            off += ln
+    # _rowid of global position i: an affine permutation of 0..n (no n-sized table on any rank)
+    mult = 982_451_653
+    while np.gcd(mult, n) != 1:
+        mult += 2
+    row_ids = (pos * mult + 12_345) % n
+    del pos
     torch.cuda.synchronize()
 
     t_open = time.time()
-    # the uniform code bytes are declared to be in lance's per-partition transposed layout
     ix = lancedb_amd.IvfPqIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
                                 codes_layout=_abi.CODES_PART_TRANSPOSED, device=local_rank,
-                                shard_count=world, shard_rank=rank)
+                                shard_count=world, shard_rank=rank, local_arrays=True)
     t_open = time.time() - t_open
     rows_local, parts_local = ix.info()
+    assert rows_local == rows_mine
 
     want_cpu = rank == 0 and world == 1 and a.cpu_seconds > 0
     h_codes = h_rowids = None
@@ -286,26 +250,194 @@ def main():
             "scan_variant": st["scan_variant"], "rows_on_rank0": rows_local, "partitions_on_rank0": parts_local,
             "index_open_s": round(t_open, 2),
         },
-        "roofline": {
-            "bound": "hbm", "kernel": "k_scan (LUT build + ADC scan + top-k)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
-            "launches": int(float(stat[2])),
-            "stage_us_per_step": {s: st["us_" + s] / a.steps for s in ("coarse", "select", "scan", "merge")},
-        },
+        "roofline": scan_roofline(achieved, bytes_per_launch, us_per_launch, int(float(stat[2])), traffic,
+                                  traffic_source_from_profiles(workload, a.batch) if world == 1 else None,
+                                  torch.cuda.get_device_properties(dev).multi_processor_count,
+                                  {s: st["us_" + s] / a.steps for s in ("coarse", "select", "scan", "merge")}),
     }
+    if world > 1:
+        cs = comm.stats()  # identical on every rank: the per-rank scanned rows travel in the gathered slabs
+        result["multi_gpu"] = {
+            "exchange": "RCCL behind the C ABI (mi355_search_sharded): one packed all-gather per step + k-way merge",
+            "rccl_ranks": cs["world"], "gathers_per_step": cs["n_gathers"], "bytes_gathered_per_step": cs["bytes_gathered"],
+            "rows_scanned_per_rank_last_step": cs["rows_scanned"], "load_imbalance_max_over_mean": cs["imbalance"],
+            "rows_on_rank": [int(lens[owner == r].sum()) for r in range(world)],
+        }
 
     if rank == 0 and world == 1 and a.recall_rows > 0:
         result["recall_at_10"] = recall_at_10(a, np, dim, m)
+    if rank == 0 and world == 1 and a.secondary:
+        result["secondary"] = {"c3_refine10": refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev)}
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(a, np, h_centroids, h_codebook, part_offsets, h_codes, h_rowids,
                                               qpool[(a.steps - 1) % P], last, params)
+    if rank == 0 and world == 1 and a.secondary:
+        # flat C2 needs 15 GB for its column: drop the 100 M index first
+        ix.close()
+        del ix
+        torch.cuda.empty_cache()
+        for metric in ("l2", "cosine"):
+            result["secondary"]["flat_c2_" + metric] = flat_c2(a, metric, cpu_queries=32 if metric == "l2" else 16)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scan_roofline(achieved, bytes_per_launch, us_per_launch, launches, traffic, traffic_source, n_cus, stage_us):
+    """`frac` is the NO-REUSE algorithmic byte rate (m bytes per scanned row per query)
+    over the scan kernel's own time against HBM peak — it exceeds 1 because the XCD-local work queues
+    serve a partition's codes to many queries from L2.  The ceilings that actually bind the kernel
+    are reported beside it: the LDS gather rate (one 4-byte table gather per code byte; 32 gathers
+    per clock per CU conflict-free, MI355X_MICROARCH.md §LDS) and the measured HBM traffic."""
+    gathers_per_s = bytes_per_launch / (us_per_launch * 1e-6) if us_per_launch else 0.0
+    gather_peak = n_cus * 32 * 2.4e9
+    r = {
+        "bound": "hbm", "kernel": "k_scan (LUT build + ADC scan + top-k)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "frac_definition": "no-reuse algorithmic code bytes / scan-kernel time / 8 TB/s (SURVEY.md §8d); > 1 = cross-query reuse in L2",
+        "traffic": traffic, "traffic_source": traffic_source,
+        "hbm_measured_frac": (traffic / (us_per_launch * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and us_per_launch) else None,
+        "lds_gather": {"achieved": gathers_per_s / 1e12, "peak": gather_peak / 1e12, "unit": "T gathers/s",
+                       "frac": gathers_per_s / gather_peak,
+                       "peak_definition": f"{n_cus} CUs x 32 ds_read_b32 lanes/clk x 2.4 GHz, conflict-free"},
+        "algorithmic_bytes_per_launch": bytes_per_launch, "us_per_launch": us_per_launch,
+        "launches": launches, "stage_us_per_step": stage_us,
+    }
+    return r
+
+
+def refine_operating_point(a, torch, ix, qpool, n_rows, dim, dev):
+    """The SAME 100 M index with refine_factor 10 (query.rs:1302-1332): k * 10 ANN candidates per query,
+    exact re-rank on raw bf16 vectors resident in HBM (100 M x 768 x 2 B = 154 GB).  This is the
+    operating point whose recall@10 is >= 0.9 on the trained index of the recall leg; the raw
+    vectors are random finite bf16 values (the gather / exact-distance work does not depend on them)."""
+    import lancedb_amd
+    from lancedb_amd import _abi
+    free, _ = torch.cuda.mem_get_info(dev)
+    need = n_rows * dim * 2
+    if free < need + (24 << 30):
+        return {"skipped": f"{need / 1e9:.0f} GB of raw vectors do not fit ({free / 1e9:.0f} GB free)"}
+    raw = torch.empty((n_rows, dim), dtype=torch.int16, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 7)
+    step = 8_000_000
+    for r0 in range(0, n_rows, step):  # bf16 bit patterns below 0x4000: finite values in (0, 2)
+        raw[r0:r0 + step].random_(0, 0x4000, generator=g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ix.attach_raw_vectors(raw, _abi.DTYPE_BF16)
+    t_attach = time.perf_counter() - t0
+    B, k, rf = a.batch, a.k, 10
+    params = _abi.make_params(k=k, nprobe_min=a.nprobe, nprobe_max=a.nprobe, refine_factor=rf)
+    out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+           torch.empty((B,), dtype=torch.int32, device=dev))
+    ix.configure(profile=0)
+    for i in range(2):
+        ix.search(qpool[i % len(qpool)], params, out=out)
+    torch.cuda.synchronize()
+    ix.configure(profile=2)
+    steps = max(3, a.steps // 2)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ix.search(qpool[i % len(qpool)], params, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = ix.stats()
+    ix.detach_raw_vectors()
+    del raw
+    torch.cuda.empty_cache()
+    refine_bytes = B * k * rf * dim * 2  # algorithmic: k * rf raw rows per query (SURVEY.md §8d)
+    return {"value": B * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "config": {"workload": f"ivfpq C3 + refine_factor {rf}, raw bf16 vectors resident", "k": k, "refine_factor": rf,
+                       "nprobe": a.nprobe, "batch_queries": B, "raw_vectors_gb": need / 1e9, "attach_s": round(t_attach, 2)},
+            "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge", "refine")},
+            "refine_gather": {"algorithmic_bytes_per_step": refine_bytes,
+                              "gb_per_s": refine_bytes / max(st["us_refine"] / steps, 1e-9) / 1e3},
+            "recall_at_10": "see recall_at_10.nprobe64_refine10 (trained index)"}
+
+
+def flat_c2(a, metric, cpu_queries):
+    """BASELINE.json configs[1]: flat KNN over 10 M x 768 bf16, 1024 queries per step, as the bf16 MFMA
+    GEMM filter + exact re-rank.  `roofline` is the GEMM kernel's own (HIP events around its launches,
+    mi355_flat_last_stats); the CPU leg sweeps the whole column for `cpu_queries` queries of the last
+    timed batch and doubles as the full-size parity check."""
+    import numpy as np
+    import torch
+
+    import lancedb_amd
+    from lancedb_amd import _abi
+    dev = torch.device("cuda", 0)
+    n, dim, B, k = a.flat_rows, a.dim, a.flat_batch, a.k
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED)
+    col = torch.empty((n, dim), device=dev, dtype=torch.bfloat16)
+    step = 2_000_000
+    for r0 in range(0, n, step):
+        col[r0:r0 + step] = torch.randn((min(step, n - r0), dim), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    P = 2
+    qpool = [torch.randn((B, dim), generator=g, device=dev, dtype=torch.float32) for _ in range(P)]
+    torch.cuda.synchronize()
+    fl = lancedb_amd.FlatIndex(col.view(torch.int16), dtype=_abi.DTYPE_BF16, device=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    fl.set_stream(stream)
+    mt = _abi.METRIC_NAMES[metric]
+    params = _abi.make_params(k=k, nprobe_min=1, nprobe_max=1, metric=mt)
+    out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+           torch.empty((B,), dtype=torch.int32, device=dev))
+    fl.configure(gemm_variant=a.flat_gemm, grid_workgroups=a.flat_grid)
+    for i in range(max(a.warmup, 1)):
+        fl.search(qpool[i % P], params, out=out)
+    torch.cuda.synchronize()
+    fl.configure(gemm_variant=a.flat_gemm, grid_workgroups=a.flat_grid, profile=True)
+    steps = a.steps
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = fl.search(qpool[i % P], params, out=out)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert fl.info() == (1, 1), "the MFMA filter path did not run"
+    fs = fl.stats()
+    flops = 2.0 * B * n * dim
+    gemm_tf = fs["gemm_flops"] / max(fs["us_gemm"], 1e-9) / 1e6
+    res = {
+        "metric": "queries/sec, flat (no index) KNN 10M×768 bf16, batch 1024, k=10 (BASELINE.json configs[1])",
+        "value": B * steps / elapsed, "unit": "queries/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"flat_{n}x{dim}_bf16_batch{B}_k{k}_{metric}", "n_rows": n, "dim": dim, "batch_queries": B, "k": k,
+                   "metric": metric, "gemm_variant": fs["gemm_variant"]},
+        "roofline": {"bound": "mfma", "kernel": "k_flat_gemm (bf16 MFMA filter GEMM, own HIP events)",
+                     "achieved": gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": gemm_tf / 2500.0,
+                     "us_per_launch": fs["us_gemm"] / max(fs["gemm_launches"], 1), "launches": fs["gemm_launches"],
+                     "algorithmic_flops_per_launch": fs["gemm_flops"] / max(fs["gemm_launches"], 1),
+                     "rest_of_step_us": fs["us_rest"] / max(fs["gemm_launches"], 1),
+                     "whole_step_tflops": flops / (elapsed / steps) / 1e12,
+                     "traffic": traffic_from_profiles(f"flat_{n}x{dim}_bf16_batch{B}_k{k}_l2", B),
+                     "traffic_source": traffic_source_from_profiles(f"flat_{n}x{dim}_bf16_batch{B}_k{k}_l2", B)},
+    }
+    if a.cpu_seconds > 0 and cpu_queries:
+        from oracle import oracle as orc
+        orc.build()
+        cores = os.cpu_count() or 1
+        nq = min(B, cpu_queries)  # every query sweeps the whole column on the host
+        hv = col.view(torch.int16).cpu().numpy().view(np.uint16)
+        hq = qpool[(steps - 1) % P][:nq].cpu().numpy()
+        t1 = time.perf_counter()
+        ids, dist, cnt, _ = orc.flat_search(hv, hq, k=k, dtype=_abi.DTYPE_BF16, metric=mt)
+        dt = time.perf_counter() - t1
+        g_ids = last.rowids[:nq].cpu().numpy().astype(np.uint64)
+        g_dist = last.distances[:nq].cpu().numpy()
+        res["cpu_baseline"] = {
+            "value": nq / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{nq} queries of the last timed batch, one per thread, {dt:.1f} s on {cores} host cores; "
+                      "C restatement (oracle/ann_oracle.c), not the reference binary",
+            "parity": {"queries": nq, "rowids_bit_exact": bool((g_ids == ids).all()),
+                       "distances_equal": bool((g_dist == dist).all())}}
+    fl.close()
+    del fl, col
+    torch.cuda.empty_cache()
+    return res
 
 
 def recall_at_10(a, np, dim, m):
@@ -368,6 +500,21 @@ def recall_at_10(a, np, dim, m):
         out[f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")] = round(rec, 4)
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
+
+
+def traffic_source_from_profiles(workload, batch):
+    """Which committed file `traffic` came from (it is NOT measured in the run it is printed in: PMC
+    counters need their own rocprofv3 pass)."""
+    import glob
+    src = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")) + glob.glob(os.path.join(ROOT, "profiles", "*fetch_size*.json"))):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if t.get("workload") == workload and t.get("batch_queries") == batch:
+            src = "profiles/" + os.path.basename(path) + " (committed rocprofv3 --pmc FETCH_SIZE x 2 pass of the same workload, not this run)"
+    return src
 
 
 def traffic_from_profiles(workload, batch):

@@ -91,7 +91,12 @@ enum {
      library page-locks the range and the refine kernel gathers the k*refine_factor
      candidate rows over PCIe (zero copy).  For columns that do not fit HBM (C5:
      100 M x 1536).  Requires mem == MI355_MEM_HOST. */
-  MI355_INDEX_RAW_HOST_MAPPED = 2u
+  MI355_INDEX_RAW_HOST_MAPPED = 2u,
+  /* shard handles: codes, row_ids and raw_vectors hold ONLY the partitions this shard owns
+     (mi355_shard_plan), concatenated in partition order — a rank never materialises the
+     partitions of the others.  part_offsets stays the GLOBAL array (it defines the plan and
+     the global positions); row_ids must then be given (identity ids would be global). */
+  MI355_INDEX_LOCAL_ARRAYS = 4u
 };
 
 /* layout of the PQ code block handed to mi355_index_open */
@@ -273,6 +278,12 @@ int32_t mi355_index_sync(mi355_index *index);
    them as given). */
 int32_t mi355_index_configure(mi355_index *index, uint32_t scan_variant,
                               uint32_t slice_rows, uint32_t profile);
+/* Attach (or replace) the raw vector column of an open handle WITHOUT copying it: a DEVICE array
+   [rows kept on this handle, dim] in the handle's local row order (= index order for an unsharded
+   handle) that the caller keeps alive until detach / close.  For columns that should not exist
+   twice in HBM (100 M x 768 bf16 = 154 GB).  Detach restores the column given at open, if any. */
+int32_t mi355_index_attach_raw(mi355_index *index, const void *raw_vectors, uint32_t raw_dtype);
+int32_t mi355_index_detach_raw(mi355_index *index);
 /* rows kept on this handle and how many partitions are non-empty here */
 int32_t mi355_index_info(const mi355_index *index, uint64_t *out_rows,
                          uint32_t *out_partitions_owned);
@@ -344,10 +355,27 @@ enum {
   MI355_FLAT_GEMM_8PHASE_REF = 5,/* the same schedule with variant 2's epilogue arithmetic */
   MI355_FLAT_GEMM_8PHASE_M = 6   /* variant 4 with the LDS-DMA pieces issued among the MFMAs */
 };
-enum { MI355_FLAT_CHECKSUM = 1u };
+enum {
+  MI355_FLAT_CHECKSUM = 1u,
+  /* accumulate the GEMM kernel's own device time (HIP events recorded around its launches on the
+     search stream, no host synchronisation) until the next configure(): mi355_flat_last_stats */
+  MI355_FLAT_PROFILE = 2u
+};
 int32_t mi355_flat_configure(mi355_flat *flat, uint32_t gemm_variant,
                              uint32_t grid_workgroups, uint32_t flags);
 int32_t mi355_flat_checksum(mi355_flat *flat, uint64_t *out_checksum);
+
+typedef struct mi355_flat_stats {
+  uint32_t struct_size;
+  uint32_t gemm_variant;   /* MI355_FLAT_GEMM_* the last search ran */
+  uint32_t gemm_launches;  /* GEMM launches folded into us_gemm */
+  uint32_t reserved;
+  float us_gemm;           /* summed device time of those launches */
+  float us_rest;           /* query prep + thresholds + compaction + exact re-rank of the same searches */
+  uint64_t gemm_flops;     /* algorithmic flops of those launches: 2 * queries (padded) * rows * dim (padded) */
+} mi355_flat_stats;
+/* waits for the handle's stream, then returns the accumulated numbers */
+int32_t mi355_flat_last_stats(mi355_flat *flat, mi355_flat_stats *out);
 
 /* which kernels served the last mi355_flat_search: 1 = bf16 MFMA GEMM filter +
    exact re-rank, 2 = exact scalar sweep (small columns, lower-bounded ranges);
@@ -428,6 +456,21 @@ typedef struct mi355_kmeans_desc {
 int32_t mi355_kmeans_train(const mi355_kmeans_desc *desc, const float *vectors, uint64_t n_rows,
                            float *centroids /*[k, dim] in: initial, out: trained*/,
                            uint64_t *out_counts /*[k] rows per centroid at the last assignment, or NULL*/);
+
+/* All m PQ sub-quantisers of PQBuildParams in ONE call: sub-quantiser j is exactly
+   mi355_kmeans_train (k = 2^nbits, plain L2 — dot for dot indexes — `iters` Lloyd iterations) on
+   columns [j * dim/m, (j+1) * dim/m) of the residual matrix, but the matrix crosses to the device
+   once and the m trainers share one stream and one scratch set. */
+typedef struct mi355_pq_train_desc {
+  uint32_t struct_size;
+  uint32_t dim, m, nbits;
+  uint32_t metric;  /* the INDEX metric (MI355_METRIC_*) */
+  uint32_t iters;
+  uint32_t mem;     /* MI355_MEM_*: residuals and codebook */
+  int32_t device;
+} mi355_pq_train_desc;
+int32_t mi355_pq_train(const mi355_pq_train_desc *desc, const float *residuals /*[n_rows, dim]*/, uint64_t n_rows,
+                       float *codebook /*[m, 2^nbits, dim/m] in: initial entries, out: trained*/);
 
 /* Residuals of the rows to their partition centroid, the training set of the PQ
    codebooks: out[i] = x_i - c[assign(x_i)] (cosine: x normalised first; dot: out = x).

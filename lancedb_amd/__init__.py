@@ -9,7 +9,7 @@ from ._lib import (EngineError, InvalidInput, NotSupported, QueryTimeout, build,
                    lib)
 from ._hip import DeviceArray, synchronize  # noqa: F401
 from .index import (FlatIndex, IvfPqIndex, SearchResult, ivf_residuals, ivfpq_encode, kmeans_train,  # noqa: F401
-                    merge_topk, shard_plan)
+                    merge_topk, pq_train, shard_plan)
 from .build import IvfPqBuilder, suggested_num_partitions, suggested_num_sub_vectors  # noqa: F401
 from .query import DEFAULT_TOP_K, VectorQuery, VectorQueryRequest, VectorTable  # noqa: F401
 

@@ -45,6 +45,7 @@ APPROX_NAMES = {"fast": APPROX_FAST, "normal": APPROX_NORMAL, "accurate": APPROX
 
 INDEX_GENERIC_SCAN = 1
 INDEX_RAW_HOST_MAPPED = 2
+INDEX_LOCAL_ARRAYS = 4
 
 PROFILE_MASK = 0xFF
 CFG_GRAPH = 0x100
@@ -58,6 +59,7 @@ FLAT_GEMM_8PHASE = 4
 FLAT_GEMM_8PHASE_REF = 5
 FLAT_GEMM_8PHASE_M = 6
 FLAT_CHECKSUM = 1
+FLAT_PROFILE = 2
 
 SHARD_COARSE = 1
 COMM_ID_BYTES = 128
@@ -156,6 +158,19 @@ class KmeansDesc(C.Structure):
     ]
 
 
+class PqTrainDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("dim", C.c_uint32),
+        ("m", C.c_uint32),
+        ("nbits", C.c_uint32),
+        ("metric", C.c_uint32),
+        ("iters", C.c_uint32),
+        ("mem", C.c_uint32),
+        ("device", C.c_int32),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -178,6 +193,18 @@ class Stats(C.Structure):
         ("coalesced_calls", C.c_uint32),
         ("graph_replays", C.c_uint32),
         ("reserved", C.c_uint32),
+    ]
+
+
+class FlatStats(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("gemm_variant", C.c_uint32),
+        ("gemm_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("us_gemm", C.c_float),
+        ("us_rest", C.c_float),
+        ("gemm_flops", C.c_uint64),
     ]
 
 
@@ -205,6 +232,8 @@ EXPORTED_SYMBOLS = (
     "mi355_index_sync",
     "mi355_index_configure",
     "mi355_index_info",
+    "mi355_index_attach_raw",
+    "mi355_index_detach_raw",
     "mi355_search",
     "mi355_coarse_topn",
     "mi355_search_probes",
@@ -217,6 +246,7 @@ EXPORTED_SYMBOLS = (
     "mi355_flat_info",
     "mi355_flat_configure",
     "mi355_flat_checksum",
+    "mi355_flat_last_stats",
     "mi355_comm_unique_id",
     "mi355_comm_create",
     "mi355_comm_destroy",
@@ -224,7 +254,7 @@ EXPORTED_SYMBOLS = (
     "mi355_search_sharded",
     "mi355_flat_search_sharded",
     "mi355_coarse_slice",
-    "mi355_ivfpq_encode", "mi355_kmeans_train", "mi355_ivf_residuals",
+    "mi355_ivfpq_encode", "mi355_kmeans_train", "mi355_ivf_residuals", "mi355_pq_train",
     "mi355_merge_topk",
     "mi355_shard_plan",
 )

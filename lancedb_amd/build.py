@@ -10,7 +10,7 @@ import math
 
 import numpy as np
 
-from .index import IvfPqIndex, ivf_residuals, ivfpq_encode, kmeans_train
+from .index import IvfPqIndex, ivf_residuals, ivfpq_encode, kmeans_train, pq_train
 
 
 DEFAULT_PARTITION_SIZE = 8192  # rows per partition of IvfBuildParams::default() [EXT], pinned by
@@ -92,14 +92,11 @@ class IvfPqBuilder:
         pq_sample = self._sample(x, self.sample_rate * ks, rng)
         resid, _ = ivf_residuals(pq_sample, centroids, metric=metric)
         dsub = dim // m
-        codebook = np.empty((m, ks, dsub), dtype=np.float32)
         pick = np.sort(rng.choice(resid.shape[0], size=ks, replace=False))
-        # residuals are already normalised / centred: the sub-quantisers are plain L2 (dot: dot) k-means
-        sub_metric = "dot" if metric == "dot" else "l2"
-        for j in range(m):
-            cols = (j * dsub, (j + 1) * dsub)
-            codebook[j], _ = kmeans_train(resid, resid[pick, cols[0]:cols[1]], metric=sub_metric,
-                                          iters=self.max_iterations, cols=cols)
+        # the seeds of sub-quantiser j: its column range of `ks` sampled residuals.  Residuals are already
+        # normalised / centred: the sub-quantisers are plain L2 (dot: dot) k-means, all m in one call
+        init = np.ascontiguousarray(resid[pick].reshape(ks, m, dsub).transpose(1, 0, 2))
+        codebook = pq_train(resid, init, metric=metric, iters=self.max_iterations, nbits=self.num_bits)
         return centroids, codebook
 
     def build(self, vectors, row_ids=None, keep_vectors=True):

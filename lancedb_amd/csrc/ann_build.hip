@@ -257,6 +257,37 @@ static int32_t train_assign(TrainScratch& w, const mi355_kmeans_desc* d, uint64_
   return MI355_OK;
 }
 
+// Lloyd iterations on scratch `w` (its stream): rows at `vectors` (memory per d->mem, stride d->ld),
+// centroids already in w.cen; leaves the trained centroids in w.cen and the last histogram in `hist`
+static int32_t lloyd_on_scratch(TrainScratch& w, const mi355_kmeans_desc* d, const float* vectors, uint64_t n_rows,
+                                std::vector<uint32_t>& hist) {
+  hipStream_t st = w.st;
+  const uint32_t dim = d->dim, k = d->k;
+  hist.assign(k, 0);
+  if (!n_rows || !d->iters) return MI355_OK;
+  ST_TRY(train_load_rows(w, d, vectors, n_rows));
+  ST_TRY(w.order.ensure(sizeof(uint64_t) * n_rows));
+  ST_TRY(w.po.ensure(sizeof(unsigned long long) * ((size_t)k + 1)));
+  std::vector<unsigned long long> base((size_t)k + 1);
+  for (uint32_t it = 0; it < d->iters; ++it) {
+    ST_TRY(train_assign(w, d, n_rows));
+    HIP_TRY(hipMemcpyAsync(hist.data(), w.hist.p, sizeof(uint32_t) * k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long run = 0;
+    for (uint32_t p = 0; p < k; ++p) {
+      base[p] = run;
+      run += hist[p];
+    }
+    base[k] = run;
+    HIP_TRY(hipMemcpyAsync(w.po.p, base.data(), sizeof(unsigned long long) * ((size_t)k + 1), hipMemcpyHostToDevice, st));
+    ST_TRY(stable_order(st, w.assign.as<uint32_t>(), n_rows, k, base, w.cntB, w.lrank, w.run, w.order.as<uint64_t>()));
+    hipLaunchKernelGGL(k_centroid_update, dim3(k, (dim + 255) / 256), dim3(256), 0, st, w.xp.as<float>(),
+                       w.order.as<uint64_t>(), w.po.as<unsigned long long>(), dim, w.cen.as<float>());
+    HIP_TRY(hipGetLastError());
+  }
+  return MI355_OK;
+}
+
 extern "C" int32_t mi355_kmeans_train(const mi355_kmeans_desc* d, const float* vectors, uint64_t n_rows,
                                       float* centroids, uint64_t* out_counts) {
   ST_TRY(check_kmeans_desc(d));
@@ -270,31 +301,11 @@ extern "C" int32_t mi355_kmeans_train(const mi355_kmeans_desc* d, const float* v
   hipStream_t st = w.st;
   ST_TRY(w.cen.ensure(sizeof(float) * (size_t)k * dim));
   HIP_TRY(copy_in(w.cen.p, centroids, sizeof(float) * (size_t)k * dim, d->mem, st));
-  std::vector<uint32_t> hist(k, 0);
-  if (n_rows && d->iters) {
-    ST_TRY(train_load_rows(w, d, vectors, n_rows));
-    ST_TRY(w.order.ensure(sizeof(uint64_t) * n_rows));
-    ST_TRY(w.po.ensure(sizeof(unsigned long long) * ((size_t)k + 1)));
-    std::vector<unsigned long long> base((size_t)k + 1);
-    for (uint32_t it = 0; it < d->iters; ++it) {
-      ST_TRY(train_assign(w, d, n_rows));
-      HIP_TRY(hipMemcpyAsync(hist.data(), w.hist.p, sizeof(uint32_t) * k, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      unsigned long long run = 0;
-      for (uint32_t p = 0; p < k; ++p) {
-        base[p] = run;
-        run += hist[p];
-      }
-      base[k] = run;
-      HIP_TRY(hipMemcpyAsync(w.po.p, base.data(), sizeof(unsigned long long) * ((size_t)k + 1), hipMemcpyHostToDevice, st));
-      ST_TRY(stable_order(st, w.assign.as<uint32_t>(), n_rows, k, base, w.cntB, w.lrank, w.run, w.order.as<uint64_t>()));
-      hipLaunchKernelGGL(k_centroid_update, dim3(k, (dim + 255) / 256), dim3(256), 0, st, w.xp.as<float>(),
-                         w.order.as<uint64_t>(), w.po.as<unsigned long long>(), dim, w.cen.as<float>());
-      HIP_TRY(hipGetLastError());
-    }
+  std::vector<uint32_t> hist;
+  ST_TRY(lloyd_on_scratch(w, d, vectors, n_rows, hist));
+  if (n_rows && d->iters)
     HIP_TRY(hipMemcpyAsync(centroids, w.cen.p, sizeof(float) * (size_t)k * dim,
                            host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
-  }
   if (out_counts) {
     std::vector<uint64_t> c64(hist.begin(), hist.end());
     HIP_TRY(hipStreamSynchronize(st));
@@ -303,6 +314,59 @@ extern "C" int32_t mi355_kmeans_train(const mi355_kmeans_desc* d, const float* v
     else
       HIP_TRY(hipMemcpy(out_counts, c64.data(), sizeof(uint64_t) * k, hipMemcpyHostToDevice));
   }
+  HIP_TRY(hipStreamSynchronize(st));
+  return MI355_OK;
+}
+
+// All m PQ sub-quantisers in one call: the residual matrix crosses to the device once and the m
+// trainers share one scratch set and one stream (sub-quantiser j = mi355_kmeans_train on columns
+// [j * dsub, (j + 1) * dsub) with ld = dim, bit for bit).
+extern "C" int32_t mi355_pq_train(const mi355_pq_train_desc* d, const float* residuals, uint64_t n_rows, float* codebook) {
+  if (!d) return fail(MI355_ERR_INVALID_INPUT, "desc is NULL");
+  if (d->struct_size != sizeof(mi355_pq_train_desc))
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_pq_train_desc.struct_size %u != %zu (ABI mismatch)", d->struct_size,
+                sizeof(mi355_pq_train_desc));
+  if (d->dim == 0 || d->m == 0 || d->dim % d->m) return fail(MI355_ERR_INVALID_INPUT, "dim %u is not a multiple of m %u", d->dim, d->m);
+  if (d->nbits != 8 && d->nbits != 4) return fail(MI355_ERR_INVALID_INPUT, "num_bits must be 4 or 8, got %u", d->nbits);
+  if (d->metric > MI355_METRIC_DOT || d->mem > MI355_MEM_DEVICE) return fail(MI355_ERR_INVALID_INPUT, "bad metric / mem enum");
+  if (!codebook || (n_rows && !residuals)) return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
+  if (n_rows >> 40) return fail(MI355_ERR_NOT_SUPPORTED, "too many training rows");
+  ST_TRY(need_device(d->device));
+  const uint32_t dim = d->dim, m = d->m, dsub = dim / m, ks = 1u << d->nbits;
+  const bool host = d->mem == MI355_MEM_HOST;
+  TrainScratch w;
+  HIP_TRY(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+  hipStream_t st = w.st;
+  ScratchBuf d_res, d_cb;
+  const float* res = residuals;
+  if (host && n_rows) {
+    ST_TRY(d_res.ensure(sizeof(float) * n_rows * dim));
+    HIP_TRY(hipMemcpyAsync(d_res.p, residuals, sizeof(float) * n_rows * dim, hipMemcpyHostToDevice, st));
+    res = d_res.as<float>();
+  }
+  ST_TRY(d_cb.ensure(sizeof(float) * (size_t)m * ks * dsub));
+  HIP_TRY(copy_in(d_cb.p, codebook, sizeof(float) * (size_t)m * ks * dsub, d->mem, st));
+  mi355_kmeans_desc kd{};
+  kd.struct_size = sizeof(kd);
+  kd.dim = dsub;
+  kd.k = ks;
+  // residuals are already centred / normalised: plain L2 k-means, or dot for dot indexes
+  kd.metric = d->metric == MI355_METRIC_DOT ? MI355_METRIC_DOT : MI355_METRIC_L2;
+  kd.iters = d->iters;
+  kd.mem = MI355_MEM_DEVICE;
+  kd.device = d->device;
+  kd.ld = dim;
+  ST_TRY(check_kmeans_desc(&kd));
+  ST_TRY(w.cen.ensure(sizeof(float) * (size_t)ks * dsub));
+  std::vector<uint32_t> hist;
+  for (uint32_t j = 0; j < m; ++j) {
+    float* cbj = d_cb.as<float>() + (size_t)j * ks * dsub;
+    HIP_TRY(hipMemcpyAsync(w.cen.p, cbj, sizeof(float) * (size_t)ks * dsub, hipMemcpyDeviceToDevice, st));
+    ST_TRY(lloyd_on_scratch(w, &kd, res + (size_t)j * dsub, n_rows, hist));
+    HIP_TRY(hipMemcpyAsync(cbj, w.cen.p, sizeof(float) * (size_t)ks * dsub, hipMemcpyDeviceToDevice, st));
+  }
+  HIP_TRY(hipMemcpyAsync(codebook, d_cb.p, sizeof(float) * (size_t)m * ks * dsub,
+                         host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
   return MI355_OK;
 }

@@ -144,6 +144,17 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t n = std::min(chunk, nq - q0);
     const uint32_t n_pad = (n + BN - 1) / BN * BN;
+    const bool prof = (f->cfg_flags & MI355_FLAT_PROFILE) != 0;
+    mi355_flat::FlatEv fe{};
+    if (prof) {
+      if (!f->ev_free.empty()) {
+        fe = f->ev_free.back();
+        f->ev_free.pop_back();
+      } else {
+        for (auto& e : fe.ev) HIP_TRY(hipEventCreate(&e));
+      }
+      HIP_TRY(hipEventRecord(fe.ev[0], st));
+    }
     FlatQueryPrepArgs qa;
     qa.q = d_q + (size_t)q0 * f->dim;
     qa.nq = n;
@@ -211,11 +222,17 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(256), gemm_lds, st, ga);                     \
     }                                                                                               \
   }
+    if (prof) HIP_TRY(hipEventRecord(fe.ev[1], st));
     if (metric == MI355_METRIC_L2) LAUNCH_FG(MI355_METRIC_L2)
     else if (metric == MI355_METRIC_COSINE) LAUNCH_FG(MI355_METRIC_COSINE)
     else LAUNCH_FG(MI355_METRIC_DOT)
 #undef LAUNCH_FG
     HIP_TRY(hipGetLastError());
+    if (prof) {
+      HIP_TRY(hipEventRecord(fe.ev[2], st));
+      f->fstats.gemm_flops += 2ull * n_pad * (uint64_t)f->n_rows * f->dimp;
+    }
+    f->fstats.gemm_variant = variant;
     ST_TRY(stage_ok("gemm"));
     if (want_sum) {
       // only whole tiles' groups of real rows are defined; padding queries are computed too
@@ -269,6 +286,10 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     launch_by_kpl(kpl, k_flat_rerank<1>, k_flat_rerank<2>, k_flat_rerank<4>, dim3(n), dim3(256), rl, st, ra);
     HIP_TRY(hipGetLastError());
     ST_TRY(stage_ok("rerank"));
+    if (prof) {
+      HIP_TRY(hipEventRecord(fe.ev[3], st));
+      f->ev_pending.push_back(fe);
+    }
   }
   return MI355_OK;
 }
@@ -280,6 +301,9 @@ extern "C" int32_t mi355_flat_close(mi355_flat* f) {
                     &f->shadow,  &f->vv,      &f->vmax, &f->g_qb,   &f->g_qa,   &f->g_qg,   &f->g_slack,
                     &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand, &f->w_filter, &f->w_sum};
   for (DevBuf* b : bufs) b->release();
+  for (auto* v : {&f->ev_free, &f->ev_pending})
+    for (auto& fe : *v)
+      for (auto& e : fe.ev) (void)hipEventDestroy(e);
   if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
   return MI355_OK;
@@ -416,11 +440,36 @@ extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, ui
                                         uint32_t flags) {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   if (gemm_variant > MI355_FLAT_GEMM_8PHASE_M) return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
-  if (flags & ~(uint32_t)MI355_FLAT_CHECKSUM) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
+  if (flags & ~(uint32_t)(MI355_FLAT_CHECKSUM | MI355_FLAT_PROFILE)) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
   std::lock_guard<std::mutex> lk(f->mu);
   f->gemm_variant = gemm_variant;
   f->grid_workgroups = grid_workgroups;
   f->cfg_flags = flags;
+  HIP_TRY(hipSetDevice(f->device));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  for (auto& fe : f->ev_pending) f->ev_free.push_back(fe);
+  f->ev_pending.clear();
+  f->fstats = mi355_flat_stats{};
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_flat_last_stats(mi355_flat* f, mi355_flat_stats* out) {
+  if (!f || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
+  if (out->struct_size != sizeof(mi355_flat_stats)) return fail(MI355_ERR_INVALID_INPUT, "mi355_flat_stats.struct_size mismatch");
+  std::lock_guard<std::mutex> lk(f->mu);
+  HIP_TRY(hipSetDevice(f->device));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  for (auto& fe : f->ev_pending) {
+    float ms[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], fe.ev[i], fe.ev[i + 1]));
+    f->fstats.us_gemm += ms[1] * 1000.f;
+    f->fstats.us_rest += (ms[0] + ms[2]) * 1000.f;
+    f->fstats.gemm_launches += 1;
+    f->ev_free.push_back(fe);
+  }
+  f->ev_pending.clear();
+  *out = f->fstats;
+  out->struct_size = sizeof(mi355_flat_stats);
   return MI355_OK;
 }
 

@@ -12,6 +12,58 @@
 
 
 
+// Page-locked caller ranges (MI355_INDEX_RAW_HOST_MAPPED), reference counted per process: several
+// handles (e.g. the shard handles of one column) may map the same range, which must stay registered
+// until the last of them closes.
+namespace {
+struct HostMap {
+  size_t bytes;
+  uint32_t refs;
+  void* dev;
+};
+std::mutex g_hostmap_mu;
+std::map<void*, HostMap> g_hostmap;
+}  // namespace
+
+static int32_t hostmap_acquire(void* host, size_t bytes, const void** out_dev) {
+  std::lock_guard<std::mutex> lk(g_hostmap_mu);
+  auto it = g_hostmap.find(host);
+  if (it != g_hostmap.end()) {
+    if (it->second.bytes < bytes)
+      return fail(MI355_ERR_INVALID_INPUT, "host range %p is already mapped with %zu B, now %zu B are asked for", host,
+                  it->second.bytes, bytes);
+    ++it->second.refs;
+    *out_dev = it->second.dev;
+    return MI355_OK;
+  }
+  hipError_t e = hipHostRegister(host, bytes, hipHostRegisterMapped);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(MI355_ERR_RUNTIME, "hipHostRegister of %zu B of raw vectors failed: %s", bytes, hipGetErrorString(e));
+  }
+  void* dp = nullptr;
+  e = hipHostGetDevicePointer(&dp, host, 0);
+  if (e != hipSuccess) {
+    (void)hipHostUnregister(host);
+    (void)hipGetLastError();
+    return fail(MI355_ERR_RUNTIME, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+  }
+  g_hostmap[host] = HostMap{bytes, 1u, dp};
+  *out_dev = dp;
+  return MI355_OK;
+}
+
+static void hostmap_release(void* host) {
+  std::lock_guard<std::mutex> lk(g_hostmap_mu);
+  auto it = g_hostmap.find(host);
+  if (it == g_hostmap.end()) return;
+  if (--it->second.refs == 0) {
+    (void)hipHostUnregister(host);
+    (void)hipGetLastError();  // never leave a sticky error behind for the next call's hipGetLastError()
+    g_hostmap.erase(it);
+  }
+}
+
 IndexView make_view(const mi355_index* ix) {
   IndexView v;
   v.dim = ix->dim;
@@ -33,7 +85,12 @@ IndexView make_view(const mi355_index* ix) {
   v.row_ids = ix->has_row_ids ? ix->row_ids.as<uint64_t>() : nullptr;
   v.raw = ix->has_raw ? (ix->raw_mapped_dev ? ix->raw_mapped_dev : ix->raw.p) : nullptr;
   v.raw_dtype = ix->raw_dtype;
-  v.raw_by_global = ix->raw_mapped_dev ? 1u : 0u;
+  v.raw_by_global = (ix->raw_mapped_dev && !ix->local_arrays) ? 1u : 0u;
+  if (ix->raw_attached) {  // a borrowed device column in local row order takes precedence
+    v.raw = ix->raw_attached;
+    v.raw_dtype = ix->raw_attached_dtype;
+    v.raw_by_global = 0;
+  }
   return v;
 }
 // ------------------------------------------------------------- index open ---
@@ -50,8 +107,10 @@ static int32_t validate_index_desc(const mi355_index_desc* d) {
   // table/create_index.rs:96-101: 4-bit codes are packed two per byte
   if (d->nbits == 4 && d->m % 2 != 0)
     return fail(MI355_ERR_INVALID_INPUT, "num_sub_vectors must be even when num_bits is 4, got %u", d->m);
-  if (d->flags & ~(uint32_t)(MI355_INDEX_GENERIC_SCAN | MI355_INDEX_RAW_HOST_MAPPED))
+  if (d->flags & ~(uint32_t)(MI355_INDEX_GENERIC_SCAN | MI355_INDEX_RAW_HOST_MAPPED | MI355_INDEX_LOCAL_ARRAYS))
     return fail(MI355_ERR_INVALID_INPUT, "unknown index flags 0x%x", d->flags);
+  if ((d->flags & MI355_INDEX_LOCAL_ARRAYS) && d->n_rows && !d->row_ids)
+    return fail(MI355_ERR_INVALID_INPUT, "MI355_INDEX_LOCAL_ARRAYS needs row_ids (identity ids would be global positions)");
   if ((d->flags & MI355_INDEX_RAW_HOST_MAPPED) && (d->mem != MI355_MEM_HOST || !d->raw_vectors))
     return fail(MI355_ERR_INVALID_INPUT, "MI355_INDEX_RAW_HOST_MAPPED needs host raw_vectors (mem = MI355_MEM_HOST)");
   if (d->metric > MI355_METRIC_DOT)
@@ -98,7 +157,7 @@ static int32_t index_free(mi355_index* ix) {
       for (auto& e : es.ev) (void)hipEventDestroy(e);
   for (auto& kv : ix->graphs)
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-  if (ix->raw_mapped_host) (void)hipHostUnregister(ix->raw_mapped_host);
+  if (ix->raw_mapped_host) hostmap_release(ix->raw_mapped_host);
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
   delete ix;
   return MI355_OK;
@@ -113,6 +172,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   ix->nbits = d->nbits;
   ix->mb = d->m * d->nbits / 8;
   ix->metric = d->metric;
+  ix->local_arrays = (d->flags & MI355_INDEX_LOCAL_ARRAYS) != 0;
   ix->shard_count = d->shard_count > 1 ? d->shard_count : 1;
   ix->shard_rank = d->shard_count > 1 ? d->shard_rank : 0;
   HIP_TRY(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
@@ -140,6 +200,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
                      : MI355_SCAN_PAIR;
   }
   const bool skew = ix->layout == MI355_SCAN_SKEW;
+  const bool local_arrays = (d->flags & MI355_INDEX_LOCAL_ARRAYS) != 0;
   for (uint32_t p = 0; p < nlist; ++p) {
     uint64_t len = d->part_offsets[p + 1] - d->part_offsets[p];
     bool mine = owner[p] == ix->shard_rank;
@@ -244,7 +305,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     for (uint32_t p = 0; p < nlist; ++p) {
       if (!plen[p]) continue;
       size_t pbytes = (size_t)mb * plen[p];
-      uint64_t soff = (uint64_t)mb * d->part_offsets[p];
+      uint64_t soff = (uint64_t)mb * (local_arrays ? (uint64_t)lrow0[p] : d->part_offsets[p]);
       if (d->mem == MI355_MEM_HOST) {
         if (pbytes > STAGE) {  // a partition larger than the staging buffer: grow once
           ST_TRY(flush(bmax));
@@ -319,6 +380,10 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   // -- row ids and raw vectors: owned partitions, concatenated in local order
   auto gather_rows = [&](DevBuf& dst, const void* src, size_t row_bytes) -> int32_t {
     ST_TRY(dst.ensure(std::max<size_t>(row_bytes * rows, 16)));
+    if (local_arrays) {  // already this shard's rows in local order
+      HIP_TRY(copy_in(dst.p, src, row_bytes * rows, d->mem, st));
+      return MI355_OK;
+    }
     uint32_t p = 0;
     while (p < nlist) {
       if (!plen[p]) {
@@ -346,17 +411,10 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     // the column stays where it is (C5: 100 M x 1536 does not fit HBM): page-lock the caller's
     // range and let the refine kernel gather its k * refine_factor rows per query over PCIe.
     // Rows are addressed by GLOBAL index position (k_refine_dist converts local positions).
-    const size_t bytes = dtype_size(d->raw_dtype) * (size_t)d->dim * d->n_rows;
+    const size_t bytes = dtype_size(d->raw_dtype) * (size_t)d->dim * (local_arrays ? rows : d->n_rows);
     if (bytes) {
-      hipError_t e = hipHostRegister(const_cast<void*>(d->raw_vectors), bytes, hipHostRegisterMapped);
-      if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(MI355_ERR_RUNTIME, "hipHostRegister of %zu B of raw vectors failed: %s", bytes, hipGetErrorString(e));
-      }
+      ST_TRY(hostmap_acquire(const_cast<void*>(d->raw_vectors), bytes, &ix->raw_mapped_dev));
       ix->raw_mapped_host = const_cast<void*>(d->raw_vectors);
-      void* dp = nullptr;
-      HIP_TRY(hipHostGetDevicePointer(&dp, ix->raw_mapped_host, 0));
-      ix->raw_mapped_dev = dp;
     }
     ix->has_raw = true;
     ix->raw_dtype = d->raw_dtype;
@@ -435,6 +493,28 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   ST_TRY(drain_events(ix, true));
   reset_stats(ix);
   HIP_TRY(hipMemset(ix->w_ctl.p, 0, sizeof(DevCtl)));
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_index_attach_raw(mi355_index* ix, const void* raw_vectors, uint32_t raw_dtype) {
+  if (!ix || !raw_vectors) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
+  if (raw_dtype > MI355_DTYPE_F16) return fail(MI355_ERR_INVALID_INPUT, "bad raw_dtype enum");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ix->raw_attached = raw_vectors;
+  ix->raw_attached_dtype = raw_dtype;
+  ++ix->ws_gen;  // captured graphs hold the old column's address
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_index_detach_raw(mi355_index* ix) {
+  if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ix->raw_attached = nullptr;
+  ++ix->ws_gen;
   return MI355_OK;
 }
 
@@ -861,7 +941,7 @@ int32_t check_search(mi355_index* ix, const float* queries, uint32_t n_queries, 
                 "distance type %u does not match the metric the index was trained with (%u)", p->metric, ix->metric);
   if (n_queries && (!queries || !out_counts || (p->k && (!out_rowids || !out_dist))))
     return fail(MI355_ERR_INVALID_INPUT, "NULL query / output buffer");
-  if (p->refine_factor && !ix->has_raw)
+  if (p->refine_factor && !ix->has_raw && !ix->raw_attached)
     return fail(MI355_ERR_INVALID_INPUT, "refine_factor needs raw vectors on the index handle");
   // neither `limit` (query.rs:818-907) nor `refine_factor` (query.rs:1302-1332) is bounded by the
   // reference; the only limit here is the 32-bit slot arithmetic of one query's candidate slots

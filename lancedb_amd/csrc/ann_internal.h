@@ -175,8 +175,10 @@ struct mi355_index {
   uint32_t shard_count = 1, shard_rank = 0;
   // device data
   DevBuf centroids, cnorm, codebook, codes, code_off, plen, pstride, lrow0, grow0, row_ids, raw;
-  bool has_row_ids = false, has_raw = false;
+  bool has_row_ids = false, has_raw = false, local_arrays = false;
   uint32_t raw_dtype = 0;
+  const void* raw_attached = nullptr;  // mi355_index_attach_raw: borrowed device column (local row order)
+  uint32_t raw_attached_dtype = 0;
   void* raw_mapped_host = nullptr;  // MI355_INDEX_RAW_HOST_MAPPED: registered caller memory
   const void* raw_mapped_dev = nullptr;
   std::vector<uint64_t> raw_row_of_local;  // unused unless mapped (see ann_index.hip)
@@ -223,6 +225,12 @@ struct mi355_flat {
   uint32_t last_path = 0;  // 1 = MFMA filter, 2 = exact sweep (reported by mi355_flat_info)
   uint32_t gemm_variant = MI355_FLAT_GEMM_AUTO, grid_workgroups = 0, cfg_flags = 0;
   uint64_t checksum = 0;
+  // MI355_FLAT_PROFILE: events {before prep, before GEMM, after GEMM, after re-rank} per launch sequence
+  struct FlatEv {
+    hipEvent_t ev[4];
+  };
+  std::vector<FlatEv> ev_free, ev_pending;
+  mi355_flat_stats fstats{};
 };
 
 // ------------------------------------------------- cross-TU entry points ----

@@ -72,6 +72,19 @@
 #pragma once
 #include "kernels_flat_mfma.h"
 
+// Dev ablations (scripts/build_flat_ablations.sh builds one side-by-side library per mask; never in
+// the product build): 1 = no LDS-DMA after the prologue, 2 = no fragment reads in the loop,
+// 4 = no MFMAs, 8 = no epilogue, 16 = no barriers.  Results are wrong by construction; only the
+// time is read (cdna guide §5.4 rule 17: values are kept live with empty asm so nothing is DCE'd).
+#ifndef MI355_FLAT_ABLATE
+#define MI355_FLAT_ABLATE 0
+#endif
+#define FG_ABL(bit) ((MI355_FLAT_ABLATE & (bit)) != 0)
+#define FG_BARRIER()                                     \
+  do {                                                   \
+    if (!FG_ABL(16)) __builtin_amdgcn_s_barrier();       \
+  } while (0)
+
 // DMA_IN_M = 1 (variant MI355_FLAT_GEMM_8PHASE_M): the LDS-DMA pieces are issued INSIDE the MFMA
 // block of the phase instead of its L section.  A piece costs the issuing wave 60-185 cycles
 // (MI355X_MICROARCH.md, per-instruction constants): two per L section make L (300-400 cycles with
@@ -136,7 +149,9 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   const uint32_t swz = (((uint32_t)lane & 7u) ^ l8) * 16u;
   const uint32_t voffB = l8 * pitch + swz;  // B rows are never clamped (queries are padded)
   // kt: k-tile inside tile `t`; buf: LDS buffer (parity of the GLOBAL k-tile index)
+  bool abl_dma_off = false;  // ablation 1: set after the prologue
   auto stage_half = [&](bool is_a, int h, const TileRef& t, uint32_t kt, uint32_t buf) {
+    if (FG_ABL(1) && abl_dma_off) return;
     unsigned char* dst = smem + buf * BUF;
     const uint32_t koff = kt * (FG_BK * 2);
 #pragma unroll
@@ -197,7 +212,13 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     }
     return pc;
   };
-  auto issue_piece = [&](const Pieces& pc, int i) { fg_glds16(pc.g[i], smem + pc.lds[i]); };
+  auto issue_piece = [&](const Pieces& pc, int i) {
+    if (FG_ABL(1)) {
+      asm volatile("" ::"v"(pc.g[i]), "s"(pc.lds[i]));
+      return;
+    }
+    fg_glds16(pc.g[i], smem + pc.lds[i]);
+  };
   // one phase's 16 MFMAs (rows mi0..mi0+3, queries ni0..ni0+1, both k-halves), the two pieces after
   // the 4th and the 10th
   auto mfma_block = [&](const fg_bf16x8 (&fa)[2][MI], const fg_bf16x8 (&fb)[2][NI], int mi0, int ni0, const Pieces& pc) {
@@ -208,7 +229,10 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          acc[mi0 + mi][ni0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi0 + mi], fb[kk][ni0 + ni], acc[mi0 + mi][ni0 + ni], 0, 0, 0);
+          if (FG_ABL(4))
+            asm volatile("" ::"v"(fa[kk][mi0 + mi]), "v"(fb[kk][ni0 + ni]));
+          else
+            acc[mi0 + mi][ni0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi0 + mi], fb[kk][ni0 + ni], acc[mi0 + mi][ni0 + ni], 0, 0, 0);
           ++n;
           if (DMA_IN_M && (n == 4 || n == 10)) {
             __builtin_amdgcn_sched_barrier(0);
@@ -349,23 +373,28 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   stage_half(true, 0, cur, 1, 1);
   stage_half(false, 0, cur, 1, 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind
+  abl_dma_off = true;
+  FG_BARRIER();
+  if (wr == 1) FG_BARRIER();  // group 1 runs one barrier behind
 
   fg_bf16x8 fa[2][MI], fb[2][NI];  // [k-half][tile]; A0 = fa[.][0..3], A1 = fa[.][4..7]
   uint32_t u = 0, par = 0;         // k-tile inside the current tile; parity of the global k-tile index
   bool pending = false;            // the previous tile's epilogue is still to run (its TileRef is `done`)
   TileRef done = cur;
   Pieces pc = prep_pieces(true, 0, 0, 0, 0);
+  bool first = true;  // (ablation 2 reads the fragments once)
   while (true) {
     const unsigned char* sb = smem + par * BUF;
     // the finished tile's epilogue, under the other wave group's MFMAs
     if (pending) {
-      epilogue(done);
-      zero_acc();
+      if (!FG_ABL(8)) {
+        epilogue(done);
+        zero_acc();
+      }
       pending = false;
     }
     // ---------------- q1: (A0, B0); stage B-h1(g+1)
+    if (!FG_ABL(2) || first) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       fb[0][i] = *(const fg_bf16x8*)(sb + offB0 + i * 2048 + ch0);
@@ -377,23 +406,26 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
       fa[0][i] = *(const fg_bf16x8*)(sb + offA0 + i * 2048 + ch0);
       fa[1][i] = *(const fg_bf16x8*)(sb + offA0 + i * 2048 + ch1);
     }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (DMA_IN_M)
       pc = prep_pieces(false, 1, u, 1, par ^ 1u);
     else
       (void)stage_ahead(false, 1, u, 1, par ^ 1u);
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
     mfma_block(fa, fb, 0, 0, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     // ---------------- q2: (A0, B1); stage A-h1(g+1)
+    if (!FG_ABL(2) || first) {
 #pragma unroll
     for (int i = 2; i < 4; ++i) {
       fb[0][i] = *(const fg_bf16x8*)(sb + offB0 + i * 2048 + ch0);
       fb[1][i] = *(const fg_bf16x8*)(sb + offB0 + i * 2048 + ch1);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (DMA_IN_M)
@@ -401,17 +433,19 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     else
       (void)stage_ahead(true, 1, u, 1, par ^ 1u);
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
     mfma_block(fa, fb, 0, 2, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     // ---------------- q3: (A1, B1); stage A-h0(g+2)
+    if (!FG_ABL(2) || first) {
 #pragma unroll
     for (int i = 4; i < 8; ++i) {
       fa[0][i] = *(const fg_bf16x8*)(sb + offA0 + i * 2048 + ch0);
       fa[1][i] = *(const fg_bf16x8*)(sb + offA0 + i * 2048 + ch1);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (DMA_IN_M)
@@ -419,12 +453,12 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     else
       (void)stage_ahead(true, 0, u, 2, par);
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
     mfma_block(fa, fb, 4, 2, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     // ---------------- q4: (A1, B0); stage B-h0(g+2); retire k-tile g+1
     if (DMA_IN_M) {
       pc = prep_pieces(false, 0, u, 2, par);
@@ -435,13 +469,14 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
     mfma_block(fa, fb, 4, 0, pc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    FG_BARRIER();
     par ^= 1u;
+    first = false;
     if (++u == KT) {  // tile finished: its epilogue runs at the head of the next phase (or below)
       done = cur;
       pending = true;
@@ -453,8 +488,8 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
       has_next = nvb < total_vb;
     }
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0's extra barrier: every wave executed the same count
+  if (wr == 0) FG_BARRIER();  // group 0's extra barrier: every wave executed the same count
   if (DMA_IN_M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the walk's last (unused) pieces
-  epilogue(done);
+  if (!FG_ABL(8)) epilogue(done);
   if (DMA_IN_M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -109,11 +109,14 @@ class IvfPqIndex(_Handle):
 
     def __init__(self, centroids, codebook, part_offsets, codes, row_ids=None, raw_vectors=None,
                  metric="l2", codes_layout=_abi.CODES_ROW_MAJOR, raw_dtype=_abi.DTYPE_F32,
-                 device=0, shard_count=1, shard_rank=0, nbits=8, generic_scan=False, raw_host_mapped=False):
+                 device=0, shard_count=1, shard_rank=0, nbits=8, generic_scan=False, raw_host_mapped=False,
+                 local_arrays=False):
         """nbits: 8, or 4 (codebook [m, 16, dim/m], codes [n, m/2] with sub-quantiser 2t in the low
         nibble of byte t; table/create_index.rs:96-101).  generic_scan: keep the generic code layout
         (k_scan_pair) for an m the production scan supports.  raw_host_mapped: `raw_vectors` (a host
-        array the caller keeps alive) is page-locked and read zero-copy by the refine stage."""
+        array the caller keeps alive) is page-locked and read zero-copy by the refine stage.
+        local_arrays: `codes` / `row_ids` / `raw_vectors` hold only the partitions this shard owns
+        (`shard_plan(part_offsets, shard_count) == shard_rank`), concatenated in partition order."""
         super().__init__()
         on_dev = _is_device(codes)
         po = np.ascontiguousarray(part_offsets, dtype=np.uint64)  # always host
@@ -134,7 +137,8 @@ class IvfPqIndex(_Handle):
         d = _abi.IndexDesc()
         d.struct_size = C.sizeof(_abi.IndexDesc)
         d.dim, d.nlist, d.m, d.nbits = self.dim, self.nlist, self.m, int(nbits)
-        d.flags = (_abi.INDEX_GENERIC_SCAN if generic_scan else 0) | (_abi.INDEX_RAW_HOST_MAPPED if raw_host_mapped else 0)
+        d.flags = ((_abi.INDEX_GENERIC_SCAN if generic_scan else 0) | (_abi.INDEX_RAW_HOST_MAPPED if raw_host_mapped else 0)
+                   | (_abi.INDEX_LOCAL_ARRAYS if local_arrays else 0))
         self.nbits = int(nbits)
         d.metric = self.metric
         d.n_rows = int(po[-1])
@@ -162,6 +166,18 @@ class IvfPqIndex(_Handle):
 
     def sync(self):
         check(lib().mi355_index_sync(self._h))
+
+    def attach_raw_vectors(self, raw, raw_dtype=_abi.DTYPE_F32):
+        """Borrow a DEVICE array [rows on this handle, dim] (local row order) as the refine column,
+        without copying it; the caller keeps it alive until detach_raw_vectors() / close()."""
+        if not _is_device(raw):
+            raise ValueError("attach_raw_vectors takes a device array (open with raw_host_mapped for host columns)")
+        check(lib().mi355_index_attach_raw(self._h, _ptr(raw), C.c_uint32(raw_dtype)))
+        self._attached = raw
+
+    def detach_raw_vectors(self):
+        check(lib().mi355_index_detach_raw(self._h))
+        self._attached = None
 
     def info(self):
         rows, parts = C.c_uint64(0), C.c_uint32(0)
@@ -244,10 +260,17 @@ class FlatIndex(_Handle):
     def sync(self):
         check(lib().mi355_flat_sync(self._h))
 
-    def configure(self, gemm_variant=_abi.FLAT_GEMM_AUTO, grid_workgroups=0, checksum=False):
+    def configure(self, gemm_variant=_abi.FLAT_GEMM_AUTO, grid_workgroups=0, checksum=False, profile=False):
         """Tuning of the GEMM filter (include/mi355_ann.h mi355_flat_configure)."""
-        check(lib().mi355_flat_configure(self._h, C.c_uint32(gemm_variant), C.c_uint32(grid_workgroups),
-                                         C.c_uint32(_abi.FLAT_CHECKSUM if checksum else 0)))
+        flags = (_abi.FLAT_CHECKSUM if checksum else 0) | (_abi.FLAT_PROFILE if profile else 0)
+        check(lib().mi355_flat_configure(self._h, C.c_uint32(gemm_variant), C.c_uint32(grid_workgroups), C.c_uint32(flags)))
+
+    def stats(self):
+        """GEMM kernel time accumulated since configure(profile=True) (mi355_flat_last_stats)."""
+        s = _abi.FlatStats()
+        s.struct_size = C.sizeof(_abi.FlatStats)
+        check(lib().mi355_flat_last_stats(self._h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in _abi.FlatStats._fields_ if name not in ("struct_size", "reserved")}
 
     def checksum(self):
         v = C.c_uint64(0)
@@ -368,6 +391,31 @@ def kmeans_train(vectors, init_centroids, metric="l2", iters=50, cols=None, devi
         return cen, dcounts
     check(lib().mi355_kmeans_train(C.byref(desc), base, C.c_uint64(n), _ptr(cen), _ptr(counts)))
     return cen, counts
+
+
+def pq_train(residuals, init_codebook, metric="l2", iters=50, nbits=8, device=0):
+    """All PQ sub-quantisers in one call (include/mi355_ann.h mi355_pq_train): `residuals` [n, dim],
+    `init_codebook` [m, 2^nbits, dim/m] -> trained codebook of the same shape.  Equal, bit for bit, to
+    m kmeans_train(..., cols=(j*dsub, (j+1)*dsub)) calls."""
+    dev_in = _is_device(residuals)
+    if dev_in != _is_device(init_codebook):
+        raise ValueError("residuals and init_codebook must live in the same memory")
+    if not dev_in:
+        residuals = _host(residuals, np.float32)
+        cb = np.array(init_codebook, dtype=np.float32, order="C", copy=True)
+    else:
+        cb, = _device_empty_like(residuals, [(tuple(init_codebook.shape), "float32")])
+        _copy_device(cb, init_codebook)
+    n, dim = int(residuals.shape[0]), int(residuals.shape[1])
+    m = int(cb.shape[0])
+    if m == 0 or dim % m or tuple(cb.shape) != (m, 1 << nbits, dim // m):
+        raise ValueError("init_codebook must be [m, 2^nbits, dim/m]")
+    mcode = _abi.METRIC_NAMES[metric] if isinstance(metric, str) else int(metric)
+    dev_index = (getattr(residuals.device, "index", residuals.device) or 0) if dev_in else device
+    desc = _abi.PqTrainDesc(struct_size=C.sizeof(_abi.PqTrainDesc), dim=dim, m=m, nbits=nbits, metric=mcode, iters=iters,
+                            mem=_abi.MEM_DEVICE if dev_in else _abi.MEM_HOST, device=dev_index)
+    check(lib().mi355_pq_train(C.byref(desc), _ptr(residuals), C.c_uint64(n), _ptr(cb)))
+    return cb
 
 
 def ivf_residuals(vectors, centroids, metric="l2", device=0):

@@ -28,6 +28,17 @@ def oracle_backend(oracle, monkeypatch):
         po, codes, order, assign = oracle.ivfpq_encode(vectors, centroids, codebook, metric, nbits=nbits)
         return (po, codes, order, assign) if return_assign else (po, codes, order)
 
+    def pq_train(residuals, init_codebook, metric="l2", iters=50, nbits=8, device=0):
+        # the definition of mi355_pq_train: sub-quantiser j = kmeans_train on its column range
+        m, ks, dsub = init_codebook.shape
+        calls.append(("pq", residuals.shape, init_codebook.shape, metric, iters, nbits))
+        out = np.empty_like(init_codebook)
+        for j in range(m):
+            out[j], _ = oracle.kmeans_train(residuals, init_codebook[j], "dot" if metric == "dot" else "l2", iters,
+                                            cols=(j * dsub, (j + 1) * dsub))
+        return out
+
+    monkeypatch.setattr(build_mod, "pq_train", pq_train)
     monkeypatch.setattr(build_mod, "kmeans_train", kmeans_train)
     monkeypatch.setattr(build_mod, "ivf_residuals", ivf_residuals)
     monkeypatch.setattr(build_mod, "ivfpq_encode", ivfpq_encode)
@@ -48,14 +59,12 @@ def test_train_calls_and_shapes(oracle_backend, metric):
     cent, cb = b.train(x)
     assert cent.shape == (16, 32) and cb.shape == (8, 256, 4) and cent.dtype == cb.dtype == np.float32
     kinds = [c[0] for c in oracle_backend]
-    assert kinds == ["kmeans", "residuals"] + ["kmeans"] * 8
-    # IVF: sample_rate * num_partitions rows; PQ: sample_rate * 256 rows, one sub-vector range per call
+    assert kinds == ["kmeans", "residuals", "pq"]
+    # IVF: sample_rate * num_partitions rows; PQ: sample_rate * 256 rows, all 8 sub-quantisers in one call
     assert oracle_backend[0][1] == (8 * 16, 32) and oracle_backend[0][2] == (16, 32) and oracle_backend[0][4] == 3
     assert oracle_backend[1][1] == (8 * 256, 32)
-    assert [c[5] for c in oracle_backend[2:]] == [(4 * j, 4 * j + 4) for j in range(8)]
-    assert all(c[2] == (256, 4) for c in oracle_backend[2:])
-    # the sub-quantisers of l2 / cosine indexes are plain l2 k-means on residuals
-    assert {c[3] for c in oracle_backend[2:]} == {"dot" if metric == "dot" else "l2"}
+    assert oracle_backend[2][1] == (8 * 256, 32) and oracle_backend[2][2] == (8, 256, 4)
+    assert oracle_backend[2][3:] == (metric, 3, 8)  # the index metric: dot -> dot, else plain l2 on residuals
     if metric == "cosine":  # seeded with unit rows
         assert np.isfinite(cent).all()
     # same seed -> same index; another seed -> another sample
@@ -123,4 +132,4 @@ def test_four_bit_builder_shapes(oracle_backend):
     cent, cb = b.train(x)
     assert cb.shape == (8, 16, 4)
     assert oracle_backend[1][1] == (16 * 16, 32)  # PQ sample: sample_rate * 2^num_bits rows
-    assert all(c[2] == (16, 4) for c in oracle_backend[2:])
+    assert oracle_backend[2][2] == (8, 16, 4) and oracle_backend[2][5] == 4

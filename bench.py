@@ -441,26 +441,31 @@ def flat_c2(a, metric, cpu_queries):
 
 
 def recall_at_10(a, np, dim, m):
-    """recall@10 of the engine's IVF-PQ search against exact flat search (the
-    engine's own flat path, bit-identical to the oracle's exact sweep) on a REAL
-    index: Gaussian-mixture vectors; IVF centroids and residual PQ codebooks
-    trained and all rows encoded by the engine's own build entry points (index
-    parameters follow the reference's builder, 8-bit PQ with m sub-vectors,
-    rust/lancedb/src/index/vector.rs:61-119, :266-319).  The 100 M throughput index has
-    random codes, so recall is only meaningful here."""
+    """recall@10 of IVF-PQ search against exact flat search on a REAL index:
+    `--recall-rows` Gaussian-mixture vectors; IVF centroids (sample_rate 256 rows per partition) and
+    residual PQ codebooks (256 x 256 rows) trained for `--recall-iters` Lloyd iterations and all rows
+    encoded by the engine's own build entry points (mi355_kmeans_train / mi355_ivf_residuals /
+    mi355_pq_train / mi355_ivfpq_encode; parameters as the reference's builder,
+    rust/lancedb/src/index/vector.rs:61-119, :266-319); `--recall-queries` held-out queries.
+    Reported for the ENGINE and for the CPU ORACLE (same index, same queries): with bit-exact row ids
+    the two must be equal.  The 100 M throughput index has random codes, so recall is only
+    meaningful here; `nprobe64_refine10` is the operating point of `secondary.c3_refine10`."""
     import torch
     import lancedb_amd
+    from lancedb_amd import _abi
     t0 = time.perf_counter()
-    n, nlist, nq, dsub = a.recall_rows, 1024, 1000, dim // m
+    n, nlist, nq, dsub = a.recall_rows, 1024, a.recall_queries, dim // m
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(SEED)
-    comps = torch.randn((2048, dim), generator=g, device=dev) * 1.5
-    x = comps[torch.randint(0, 2048, (n,), generator=g, device=dev)] + torch.randn((n, dim), generator=g, device=dev)
-    q = comps[torch.randint(0, 2048, (nq,), generator=g, device=dev)] + torch.randn((nq, dim), generator=g, device=dev)
-    # the engine's own build path (mi355_kmeans_train / mi355_ivf_residuals / mi355_ivfpq_encode),
-    # device-resident; sample sizes as the reference's sample_rate = 256 (index/vector.rs:76-91)
-    iters = 6
+    n_comp = 4096
+    comps = torch.randn((n_comp, dim), generator=g, device=dev) * 1.5
+    x = torch.empty((n, dim), device=dev)
+    for r0 in range(0, n, 500_000):
+        c = min(500_000, n - r0)
+        x[r0:r0 + c] = comps[torch.randint(0, n_comp, (c,), generator=g, device=dev)] + torch.randn((c, dim), generator=g, device=dev)
+    q = comps[torch.randint(0, n_comp, (nq,), generator=g, device=dev)] + torch.randn((nq, dim), generator=g, device=dev)
+    iters = a.recall_iters
     torch.cuda.synchronize()
     pick = torch.randperm(n, generator=g, device=dev)
     ivf_rows = x[pick[:min(n, 256 * nlist)].sort().values].contiguous()
@@ -472,16 +477,15 @@ def recall_at_10(a, np, dim, m):
     torch.cuda.synchronize()
     resid, _ = lancedb_amd.ivf_residuals(pq_rows, cen)
     seeds = resid[torch.randperm(resid.shape[0], generator=g, device=dev)[:256].sort().values]
-    codebook = torch.empty((m, 256, dsub), device=dev)
-    for j in range(m):
-        cb0 = seeds[:, j * dsub:(j + 1) * dsub].contiguous()
-        torch.cuda.synchronize()
-        cb, _ = lancedb_amd.kmeans_train(resid, cb0, iters=iters, cols=(j * dsub, (j + 1) * dsub))
-        codebook[j] = cb
+    cb0 = seeds.reshape(256, m, dsub).permute(1, 0, 2).contiguous()
+    torch.cuda.synchronize()
+    codebook = lancedb_amd.pq_train(resid, cb0, iters=iters)
     torch.cuda.synchronize()
     t_train = time.perf_counter() - t_train
+    del ivf_rows, pq_rows, resid
     t_enc = time.perf_counter()
     part_offsets, codes, order = lancedb_amd.ivfpq_encode(x, cen, codebook)
+    torch.cuda.synchronize()
     t_enc = time.perf_counter() - t_enc
     xs = x[order].contiguous()
     torch.cuda.synchronize()
@@ -490,14 +494,29 @@ def recall_at_10(a, np, dim, m):
     torch.cuda.synchronize()
     hq = q.cpu().numpy()
     truth = fl.search(hq, k=10).rowids
+    del fl
     out = {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "queries": nq, "truth": "exact flat search (engine flat path)",
-           "data": "2048-component Gaussian mixture; IVF + residual PQ trained by 6 Lloyd iterations "
-                   "(mi355_kmeans_train), rows encoded by mi355_ivfpq_encode",
+           "data": f"{n_comp}-component Gaussian mixture; IVF (sample_rate 256) + residual PQ trained by {iters} Lloyd "
+                   "iterations on the GPU (mi355_kmeans_train / mi355_pq_train), rows encoded by mi355_ivfpq_encode",
            "train_seconds": round(t_train, 2), "encode_rows_per_s": round(n / t_enc)}
+
+    def rec(ids):
+        return round(float(np.mean([len(set(truth[i].tolist()) & set(ids[i].tolist())) / 10.0 for i in range(nq)])), 4)
+
+    ox = None
+    if a.cpu_seconds > 0:
+        from oracle import oracle as orc
+        orc.build()
+        ox = orc.OracleIndex(cen.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
+                             order.cpu().numpy().astype(np.uint64), raw_vectors=xs.cpu().numpy())
     for nprobe, rf in ((64, 0), (64, 10), (16, 0)):
+        key = f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")
         got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf).rowids
-        rec = float(np.mean([len(set(truth[i].tolist()) & set(got[i].tolist())) / 10.0 for i in range(nq)]))
-        out[f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")] = round(rec, 4)
+        out[key] = rec(got)
+        if ox is not None:
+            o_ids, _, _, _ = ox.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+            out[key + "_cpu_oracle"] = rec(o_ids)
+            out[key + "_rowids_bit_exact"] = bool((o_ids == got).all())
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 

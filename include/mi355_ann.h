@@ -353,7 +353,10 @@ enum {
   MI355_FLAT_GEMM_8PHASE = 4,    /* 256 x 256, persistent 8-phase schedule (counted vmcnt,
                                     staggered wave groups), fast epilogue */
   MI355_FLAT_GEMM_8PHASE_REF = 5,/* the same schedule with variant 2's epilogue arithmetic */
-  MI355_FLAT_GEMM_8PHASE_M = 6   /* variant 4 with the LDS-DMA pieces issued among the MFMAs */
+  MI355_FLAT_GEMM_8PHASE_M = 6,  /* variant 4 with the LDS-DMA pieces issued among the MFMAs */
+  MI355_FLAT_GEMM_4SLOT = 7,     /* 256 x 256, persistent, two 32-MFMA phases per k-tile (4 slots), pieces
+                                    among the MFMAs, epilogue inputs through LDS, fast epilogue */
+  MI355_FLAT_GEMM_4SLOT_REF = 8  /* the same schedule with variant 2's epilogue arithmetic */
 };
 enum {
   MI355_FLAT_CHECKSUM = 1u,

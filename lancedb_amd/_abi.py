@@ -58,6 +58,8 @@ FLAT_GEMM_256x128_3 = 3
 FLAT_GEMM_8PHASE = 4
 FLAT_GEMM_8PHASE_REF = 5
 FLAT_GEMM_8PHASE_M = 6
+FLAT_GEMM_4SLOT = 7
+FLAT_GEMM_4SLOT_REF = 8
 FLAT_CHECKSUM = 1
 FLAT_PROFILE = 2
 

@@ -6,6 +6,7 @@
 #include "kernels_flat.h"
 #include "kernels_flat_mfma.h"
 #include "kernels_flat_mfma8.h"
+#include "kernels_flat_mfma4.h"
 
 // what MI355_FLAT_GEMM_AUTO means for batches > 128 queries: the variant validated and measured
 // fastest on hardware (profiles/r02_*); flipped only together with a committed A/B
@@ -40,7 +41,8 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
     return bail(fail(MI355_ERR_RUNTIME, "hipStreamCreate failed"));
   f->stream = f->own_stream;
   size_t vb = dtype_size(d->dtype) * (size_t)d->dim * d->n_rows;
-  int32_t s = f->vectors.ensure(std::max<size_t>(vb, 16));
+  // + 256 rows: the GEMM's last row tile stages whole tiles (rows past the column are masked, never used)
+  int32_t s = f->vectors.ensure(std::max<size_t>(vb + dtype_size(d->dtype) * (size_t)d->dim * 256, 16));
   if (s) return bail(s);
   if (copy_in(f->vectors.p, d->vectors, vb, d->mem, f->stream) != hipSuccess)
     return bail(fail(MI355_ERR_RUNTIME, "upload of the vector column failed"));
@@ -58,7 +60,7 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
       f->dimp = (d->dim + 63u) & ~63u;
       f->shadowed = d->dtype != MI355_DTYPE_BF16 || f->dimp != d->dim;
       if (f->shadowed) {
-        s = f->shadow.ensure((size_t)d->n_rows * f->dimp * 2);
+        s = f->shadow.ensure(((size_t)d->n_rows + 256) * f->dimp * 2);
         if (s) return bail(s);
       }
       // padded to whole 256-row tiles (tail = 0): the GEMM epilogue loads its tile's terms unconditionally
@@ -112,6 +114,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
   if (variant >= MI355_FLAT_GEMM_8PHASE && KT < 2)
     variant = MI355_FLAT_GEMM_256;  // the 8-phase walk stages two k-tiles ahead
   const bool oct = variant >= MI355_FLAT_GEMM_8PHASE;
+  const bool quad = variant == MI355_FLAT_GEMM_4SLOT || variant == MI355_FLAT_GEMM_4SLOT_REF;
   const bool big = variant == MI355_FLAT_GEMM_256 || oct, tri = variant == MI355_FLAT_GEMM_256x128_3;
   const uint32_t BM = (big || tri) ? 256 : 128, BN = big ? 256 : 128;
   const uint32_t n_rtiles = (uint32_t)((f->n_rows + BM - 1) / BM);
@@ -196,11 +199,16 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
       }
       gemm_blocks = std::min(gemm_blocks, slots);
     }
-    const size_t gemm_lds = (size_t)(tri ? 3 : 2) * (BM + BN) * FG_BK * 2;
+    const size_t gemm_lds = (size_t)(tri ? 3 : 2) * (BM + BN) * FG_BK * 2 + (quad ? 6144 : 0);
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \
     if (tri) {                                                                                      \
       auto kern = k_flat_gemm<MET, 4, 2, 4, 4, 3>;                                                  \
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)gemm_lds));                                                  \
+      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
+    } else if (quad) {                                                                              \
+      auto kern = variant == MI355_FLAT_GEMM_4SLOT ? k_flat_gemm4<MET, 1> : k_flat_gemm4<MET, 0>;   \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
@@ -439,7 +447,7 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
 extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, uint32_t grid_workgroups,
                                         uint32_t flags) {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
-  if (gemm_variant > MI355_FLAT_GEMM_8PHASE_M) return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
+  if (gemm_variant > MI355_FLAT_GEMM_4SLOT_REF) return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
   if (flags & ~(uint32_t)(MI355_FLAT_CHECKSUM | MI355_FLAT_PROFILE)) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
   std::lock_guard<std::mutex> lk(f->mu);
   f->gemm_variant = gemm_variant;

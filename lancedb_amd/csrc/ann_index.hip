@@ -22,7 +22,9 @@ struct HostMap {
   void* dev;
 };
 std::mutex g_hostmap_mu;
-std::map<void*, HostMap> g_hostmap;
+// never destroyed: handles may be closed by the host's finalisers after this library's static
+// destructors have run (e.g. a Python interpreter shutting down)
+std::map<void*, HostMap>& g_hostmap = *new std::map<void*, HostMap>();
 }  // namespace
 
 static int32_t hostmap_acquire(void* host, size_t bytes, const void** out_dev) {

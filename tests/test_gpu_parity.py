@@ -487,10 +487,10 @@ def test_c5_config_shape_1536d_cosine_refine10(oracle, raw_dtype):
 
 GEMM_VARIANTS = {"128": _abi.FLAT_GEMM_128, "256": _abi.FLAT_GEMM_256, "3": _abi.FLAT_GEMM_256x128_3,
                  "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF,
-                 "8phase_m": _abi.FLAT_GEMM_8PHASE_M}
+                 "8phase_m": _abi.FLAT_GEMM_8PHASE_M, "4slot": _abi.FLAT_GEMM_4SLOT, "4slot_ref": _abi.FLAT_GEMM_4SLOT_REF}
 
 
-@pytest.mark.parametrize("tile", ["128", "256", "3", "8phase", "8phase_ref", "8phase_m"])
+@pytest.mark.parametrize("tile", ["128", "256", "3", "8phase", "8phase_ref", "8phase_m", "4slot", "4slot_ref"])
 def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     """A grid of 8 workgroups (one per XCD) walks every tile of the column: the cross-tile
     path of the flat GEMM (next tile's first stages issued under the last k-steps, ragged last
@@ -514,7 +514,7 @@ def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     assert f1.info()[0] == 1
 
 
-@pytest.mark.parametrize("variant", ["8phase", "8phase_ref", "8phase_m"])
+@pytest.mark.parametrize("variant", ["8phase", "8phase_ref", "8phase_m", "4slot", "4slot_ref"])
 @pytest.mark.parametrize("grid", [0, 1, 16])
 def test_flat_mfma_eight_phase_schedule(oracle, variant, grid):
     """The persistent 8-phase schedule against the exact sweep: ragged last row tile, 2 / 3 / 12
@@ -544,13 +544,15 @@ def test_flat_mfma_eight_phase_reference_epilogue_matches_two_barrier_kernel_bit
     f = lancedb_amd.FlatIndex(v)
     sums = {}
     for name, var, grid in (("256", _abi.FLAT_GEMM_256, 0), ("8ref", _abi.FLAT_GEMM_8PHASE_REF, 0),
-                            ("8ref_g1", _abi.FLAT_GEMM_8PHASE_REF, 1), ("8ref_g24", _abi.FLAT_GEMM_8PHASE_REF, 24)):
+                            ("8ref_g1", _abi.FLAT_GEMM_8PHASE_REF, 1), ("8ref_g24", _abi.FLAT_GEMM_8PHASE_REF, 24),
+                            ("4ref", _abi.FLAT_GEMM_4SLOT_REF, 0), ("4ref_g1", _abi.FLAT_GEMM_4SLOT_REF, 1),
+                            ("4ref_g24", _abi.FLAT_GEMM_4SLOT_REF, 24)):
         for metric in ("l2", "cosine", "dot"):
             f.configure(gemm_variant=var, grid_workgroups=grid, checksum=True)
             f.search(q, k=10, metric=_abi.METRIC_NAMES[metric])
             sums[(name, metric)] = f.checksum()
     for metric in ("l2", "cosine", "dot"):
-        assert len({sums[(n, metric)] for n in ("256", "8ref", "8ref_g1", "8ref_g24")}) == 1, sums
+        assert len({sums[(n, metric)] for n in ("256", "8ref", "8ref_g1", "8ref_g24", "4ref", "4ref_g1", "4ref_g24")}) == 1, sums
 
 
 def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):
@@ -567,7 +569,7 @@ def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):
     q = np.concatenate([v[[100, 5000, 6000, 6002]], np.zeros((1, dim), np.float32),
                         rng.normal(size=(251, dim)).astype(np.float32)])
     f = lancedb_amd.FlatIndex(v)
-    for variant in (_abi.FLAT_GEMM_8PHASE, _abi.FLAT_GEMM_8PHASE_M):
+    for variant in (_abi.FLAT_GEMM_8PHASE, _abi.FLAT_GEMM_8PHASE_M, _abi.FLAT_GEMM_4SLOT):
         f.configure(gemm_variant=variant)
         for metric in ("l2", "cosine", "dot"):
             mt = _abi.METRIC_NAMES[metric]

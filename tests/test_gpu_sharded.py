@@ -69,6 +69,32 @@ def test_world_of_one_runs_the_whole_exchange(oracle, m, dim):
         ShardedSearcher(part, comm).search(q, _abi.make_params(k=5, nprobe_min=4, nprobe_max=4))
 
 
+def test_shard_handles_from_local_arrays_equal_those_from_global_arrays(oracle):
+    """MI355_INDEX_LOCAL_ARRAYS: a rank hands over only the partitions it owns (bench.py generates
+    exactly those); the handle must behave as the one cut out of the global arrays."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sharded_model import shard_local
+    rng = np.random.default_rng(3)
+    for m, dim in ((8, 32), (32, 128)):
+        s = train.synthetic_index(30000, dim, 40, m, seed=5, skew=0.9, empty_parts=3)
+        s["raw"] = rng.normal(size=(30000, dim)).astype(np.float32)
+        owner = lancedb_amd.shard_plan(s["part_offsets"], 3)
+        q = rng.normal(size=(17, dim)).astype(np.float32)
+        for r in range(3):
+            loc = shard_local(s, owner, r)
+            tr = train.to_part_transposed(loc["codes"], loc["part_offsets"])
+            for codes, layout in ((loc["codes"], _abi.CODES_ROW_MAJOR), (tr, _abi.CODES_PART_TRANSPOSED)):
+                a = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], codes, loc["row_ids"],
+                                           raw_vectors=loc["raw"], codes_layout=layout, shard_count=3, shard_rank=r, local_arrays=True)
+                b = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                                           raw_vectors=s["raw"], shard_count=3, shard_rank=r)
+                assert a.info() == b.info()
+                for kw in (dict(k=10, nprobe_min=12, nprobe_max=12), dict(k=5, nprobe_min=9, nprobe_max=9, refine_factor=4)):
+                    ra, rb = a.search(q, **kw), b.search(q, **kw)
+                    assert (ra.rowids == rb.rowids).all() and (ra.distances == rb.distances).all() and (ra.counts == rb.counts).all()
+
+
 def test_flat_rows_sharded_world_of_one(oracle):
     rng = np.random.default_rng(9)
     v = rng.normal(size=(20000, 64)).astype(np.float32)

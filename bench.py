@@ -267,7 +267,8 @@ def main():
     if rank == 0 and world == 1 and a.recall_rows > 0:
         result["recall_at_10"] = recall_at_10(a, np, dim, m)
     if rank == 0 and world == 1 and a.secondary:
-        result["secondary"] = {"c3_refine10": refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev)}
+        result["secondary"] = {"latency_c3": latency_and_concurrency(a, np, ix, qpool),
+                               "c3_refine10": refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev)}
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(a, np, h_centroids, h_codebook, part_offsets, h_codes, h_rowids,
                                               qpool[(a.steps - 1) % P], last, params)
@@ -306,6 +307,48 @@ def scan_roofline(achieved, bytes_per_launch, us_per_launch, launches, traffic, 
         "launches": launches, "stage_us_per_step": stage_us,
     }
     return r
+
+
+def latency_and_concurrency(a, np, ix, qpool):
+    """Host-I/O callers on the 100 M index (SURVEY.md §8b threading: callers are tokio workers,
+    python/src/runtime.rs:31-37): single-query latency from one thread (the launch sequence is a
+    replayed hipGraph, MI355_CFG_GRAPH) and 64 threads issuing single queries at once (calls that
+    arrive while the device is busy are served from one device batch, MI355_CFG_COALESCE)."""
+    import threading
+    from lancedb_amd import _abi
+    hq = qpool[0].cpu().numpy()
+    kw = dict(k=a.k, nprobe_min=a.nprobe, nprobe_max=a.nprobe)
+    out = {}
+    for mode, graph in (("graph", True), ("eager", False)):
+        ix.configure(profile=0, graph=graph, coalesce=False)
+        for i in range(8):
+            ix.search(hq[i:i + 1], **kw)
+        lat = []
+        for i in range(200):
+            t0 = time.perf_counter()
+            ix.search(hq[i % 512:i % 512 + 1], **kw)
+            lat.append(time.perf_counter() - t0)
+        lat = np.sort(np.array(lat)) * 1e6
+        out[f"single_query_us_{mode}"] = {"p50": float(lat[100]), "p99": float(lat[197]), "mean": float(lat.mean())}
+    out["graph_replays"] = ix.stats()["graph_replays"]
+    for mode, coalesce in (("coalesced", True), ("serialised", False)):
+        ix.configure(profile=0, graph=True, coalesce=coalesce)
+        n_threads, per = 64, 24
+        barrier = threading.Barrier(n_threads + 1)
+
+        def worker(t):
+            barrier.wait()
+            for i in range(per):
+                ix.search(hq[(t * per + i) % 2048:(t * per + i) % 2048 + 1], **kw)
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        [t.start() for t in th]
+        barrier.wait()
+        t0 = time.perf_counter()
+        [t.join() for t in th]
+        out[f"qps_64_threads_{mode}"] = n_threads * per / (time.perf_counter() - t0)
+    ix.configure(profile=0)
+    return out
 
 
 def refine_operating_point(a, torch, ix, qpool, n_rows, dim, dev):

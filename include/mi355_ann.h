@@ -367,12 +367,17 @@ enum {
 int32_t mi355_flat_configure(mi355_flat *flat, uint32_t gemm_variant,
                              uint32_t grid_workgroups, uint32_t flags);
 int32_t mi355_flat_checksum(mi355_flat *flat, uint64_t *out_checksum);
+/* census of the same matrix (MI355_FLAT_CHECKSUM searches): entries marked "never filter" (-inf),
+   entries that are NaN / +inf (must be 0) and the sum of the finite ones */
+int32_t mi355_flat_census(mi355_flat *flat, uint64_t *out_never_filter, uint64_t *out_not_finite, double *out_sum);
 
 typedef struct mi355_flat_stats {
   uint32_t struct_size;
   uint32_t gemm_variant;   /* MI355_FLAT_GEMM_* the last search ran */
   uint32_t gemm_launches;  /* GEMM launches folded into us_gemm */
-  uint32_t reserved;
+  uint32_t fallback_queries; /* queries of the LAST search whose candidate list overflowed and were swept
+                                exactly (adversarial columns; 0 on ordinary data — a non-zero value on
+                                random data means the filter GEMM produced garbage) */
   float us_gemm;           /* summed device time of those launches */
   float us_rest;           /* query prep + thresholds + compaction + exact re-rank of the same searches */
   uint64_t gemm_flops;     /* algorithmic flops of those launches: 2 * queries (padded) * rows * dim (padded) */

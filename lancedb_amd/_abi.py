@@ -203,7 +203,7 @@ class FlatStats(C.Structure):
         ("struct_size", C.c_uint32),
         ("gemm_variant", C.c_uint32),
         ("gemm_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("fallback_queries", C.c_uint32),
         ("us_gemm", C.c_float),
         ("us_rest", C.c_float),
         ("gemm_flops", C.c_uint64),
@@ -248,6 +248,7 @@ EXPORTED_SYMBOLS = (
     "mi355_flat_info",
     "mi355_flat_configure",
     "mi355_flat_checksum",
+    "mi355_flat_census",
     "mi355_flat_last_stats",
     "mi355_comm_unique_id",
     "mi355_comm_create",

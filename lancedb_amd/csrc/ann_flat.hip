@@ -134,7 +134,13 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     if (e != hipSuccess) return fail(MI355_ERR_RUNTIME, "flat stage %s failed: %s", what, hipGetErrorString(e));
     return MI355_OK;
   };
-  if (want_sum) f->checksum = 0;
+  if (want_sum) {
+    f->checksum = 0;
+    f->census[0] = f->census[1] = 0;
+    f->census_sum = 0.0;
+  }
+  ST_TRY(f->w_fallback.ensure(16));
+  HIP_TRY(hipMemsetAsync(f->w_fallback.p, 0, 4, st));
   ST_TRY(f->g_qb.ensure((size_t)chunk * f->dimp * 2));
   ST_TRY(f->g_qa.ensure(sizeof(float) * chunk));
   ST_TRY(f->g_qg.ensure(sizeof(float) * chunk));
@@ -244,15 +250,20 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ST_TRY(stage_ok("gemm"));
     if (want_sum) {
       // only whole tiles' groups of real rows are defined; padding queries are computed too
-      ST_TRY(f->w_sum.ensure(8));
-      unsigned long long h_sum = 0;
-      HIP_TRY(hipMemsetAsync(f->w_sum.p, 0, 8, st));
+      ST_TRY(f->w_sum.ensure(32));
+      unsigned long long h_sum[4] = {0, 0, 0, 0};
+      HIP_TRY(hipMemsetAsync(f->w_sum.p, 0, 32, st));
       const size_t real_groups = (size_t)((f->n_rows + FG_GROUP - 1) / FG_GROUP);
       hipLaunchKernelGGL(k_flat_checksum, dim3(1024), dim3(256), 0, st, ga.gm, real_groups * n_pad,
                          f->w_sum.as<unsigned long long>());
-      HIP_TRY(hipMemcpyAsync(&h_sum, f->w_sum.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_sum, f->w_sum.p, 32, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      f->checksum += h_sum;
+      f->checksum += h_sum[0];
+      f->census[0] += h_sum[1];
+      f->census[1] += h_sum[2];
+      double fs;
+      memcpy(&fs, &h_sum[3], 8);
+      f->census_sum += fs;
     }
     hipLaunchKernelGGL(k_flat_segmin, dim3((n_pad + 255) / 256, n_seg), dim3(256), 0, st, ga.gm, n_groups, n_pad,
                        groups_per_seg, f->g_seg.as<float>());
@@ -290,6 +301,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ra.out_ids = d_ids + (size_t)q0 * k;
     ra.out_dist = d_dist + (size_t)q0 * k;
     ra.out_cnt = d_cnt + q0;
+    ra.fallback = f->w_fallback.as<uint32_t>();
     const size_t rl = (((size_t)f->dim * 4 + 15) & ~(size_t)15) + sizeof(Cand) * 4 * std::min<uint32_t>(k, 64u * kpl);
     launch_by_kpl(kpl, k_flat_rerank<1>, k_flat_rerank<2>, k_flat_rerank<4>, dim3(n), dim3(256), rl, st, ra);
     HIP_TRY(hipGetLastError());
@@ -307,7 +319,7 @@ extern "C" int32_t mi355_flat_close(mi355_flat* f) {
   (void)hipSetDevice(f->device);
   DevBuf* bufs[] = {&f->vectors, &f->row_ids, &f->w_q,  &f->w_cand, &f->w_ids,  &f->w_dist, &f->w_cnt,
                     &f->shadow,  &f->vv,      &f->vmax, &f->g_qb,   &f->g_qa,   &f->g_qg,   &f->g_slack,
-                    &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand, &f->w_filter, &f->w_sum};
+                    &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand, &f->w_filter, &f->w_sum, &f->w_fallback};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&f->ev_free, &f->ev_pending})
     for (auto& fe : *v)
@@ -476,6 +488,8 @@ extern "C" int32_t mi355_flat_last_stats(mi355_flat* f, mi355_flat_stats* out) {
     f->ev_free.push_back(fe);
   }
   f->ev_pending.clear();
+  f->fstats.fallback_queries = 0;
+  if (f->w_fallback.p) HIP_TRY(hipMemcpy(&f->fstats.fallback_queries, f->w_fallback.p, 4, hipMemcpyDeviceToHost));
   *out = f->fstats;
   out->struct_size = sizeof(mi355_flat_stats);
   return MI355_OK;
@@ -485,6 +499,15 @@ extern "C" int32_t mi355_flat_checksum(mi355_flat* f, uint64_t* out) {
   if (!f || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
   std::lock_guard<std::mutex> lk(f->mu);
   *out = f->checksum;
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_flat_census(mi355_flat* f, uint64_t* out_never_filter, uint64_t* out_not_finite, double* out_sum) {
+  if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
+  std::lock_guard<std::mutex> lk(f->mu);
+  if (out_never_filter) *out_never_filter = f->census[0];
+  if (out_not_finite) *out_not_finite = f->census[1];
+  if (out_sum) *out_sum = f->census_sum;
   return MI355_OK;
 }
 

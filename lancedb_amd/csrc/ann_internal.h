@@ -221,10 +221,11 @@ struct mi355_flat {
   bool shadowed = false;  // GEMM reads a bf16 shadow (column is f32/f16 or dim % 64 != 0)
   uint32_t dimp = 0;
   float c_err = 0.f, vv_max = 0.f;
-  DevBuf shadow, vv, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand, w_filter, w_sum;
+  DevBuf shadow, vv, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand, w_filter, w_sum, w_fallback;
   uint32_t last_path = 0;  // 1 = MFMA filter, 2 = exact sweep (reported by mi355_flat_info)
   uint32_t gemm_variant = MI355_FLAT_GEMM_AUTO, grid_workgroups = 0, cfg_flags = 0;
-  uint64_t checksum = 0;
+  uint64_t checksum = 0, census[2] = {0, 0};
+  double census_sum = 0.0;
   // MI355_FLAT_PROFILE: events {before prep, before GEMM, after GEMM, after re-rank} per launch sequence
   struct FlatEv {
     hipEvent_t ev[4];

@@ -401,14 +401,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
   }
 }
 
-// dev (MI355_FLAT_SYNC=1): order-independent checksum of the group-minimum matrix, to compare
-// GEMM schedules bit for bit on identical inputs
-static __global__ void k_flat_checksum(const float* __restrict__ gm, size_t n, unsigned long long* __restrict__ out) {
-  unsigned long long acc = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    acc += (unsigned long long)__float_as_uint(gm[i]) * (i % 1000003ull + 1ull);
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+// MI355_FLAT_CHECKSUM: order-independent checksum of the group-minimum matrix (to compare GEMM
+// schedules bit for bit on identical inputs) plus a census: out[1] = entries that are -inf ("never
+// filter"), out[2] = NaN or +inf entries (must be 0), out[3] = sum of the finite entries as f64 bits
+__global__ void k_flat_checksum(const float* __restrict__ gm, size_t n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0, n_neg = 0, n_bad = 0;
+  double fsum = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = gm[i];
+    acc += (unsigned long long)__float_as_uint(v) * (i % 1000003ull + 1ull);
+    if (v == -__builtin_huge_valf())
+      ++n_neg;
+    else if (!(v - v == 0.f))
+      ++n_bad;
+    else
+      fsum += (double)v;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    acc += __shfl_xor(acc, off);
+    n_neg += __shfl_xor(n_neg, off);
+    n_bad += __shfl_xor(n_bad, off);
+    fsum += __shfl_xor(fsum, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, acc);
+    atomicAdd(out + 1, n_neg);
+    atomicAdd(out + 2, n_bad);
+    atomicAdd((double*)(out + 3), fsum);
+  }
 }
 
 // ---------------------------------------------------- threshold + candidates ---
@@ -478,6 +498,7 @@ struct FlatRerankArgs {
   uint64_t* out_ids;        // [nq, k]
   float* out_dist;
   uint32_t* out_cnt;
+  uint32_t* fallback;       // [1] queries that overflowed the candidate list (exact sweep)
 };
 
 template <int KPL>
@@ -501,6 +522,7 @@ __global__ __launch_bounds__(256) void k_flat_rerank(FlatRerankArgs a) {
   const float qq = s_qq;
   const uint32_t cnt = a.cand_cnt[b];
   const bool all = cnt > FG_CAND_CAP;
+  if (all && tid == 0 && a.fallback) atomicAdd(a.fallback, 1u);
   const uint64_t total = all ? f.n_rows : (uint64_t)cnt * FG_GROUP;
   uint64_t* oi = a.out_ids + (size_t)b * f.kk;
   float* od = a.out_dist + (size_t)b * f.kk;

@@ -270,12 +270,18 @@ class FlatIndex(_Handle):
         s = _abi.FlatStats()
         s.struct_size = C.sizeof(_abi.FlatStats)
         check(lib().mi355_flat_last_stats(self._h, C.byref(s)))
-        return {name: getattr(s, name) for name, _ in _abi.FlatStats._fields_ if name not in ("struct_size", "reserved")}
+        return {name: getattr(s, name) for name, _ in _abi.FlatStats._fields_ if name != "struct_size"}
 
     def checksum(self):
         v = C.c_uint64(0)
         check(lib().mi355_flat_checksum(self._h, C.byref(v)))
         return v.value
+
+    def census(self):
+        """-> (never_filter, not_finite, finite_sum) of the last checksummed search's group-minimum matrix."""
+        a, b, s = C.c_uint64(0), C.c_uint64(0), C.c_double(0.0)
+        check(lib().mi355_flat_census(self._h, C.byref(a), C.byref(b), C.byref(s)))
+        return a.value, b.value, s.value
 
     def info(self):
         """-> (last_path, has_filter): 1 = MFMA filter + exact re-rank, 2 = exact sweep."""

@@ -32,13 +32,16 @@ def test_struct_sizes_match_c_layout(tmp_path):
     """Compile a tiny C program against the header and compare sizeof()s."""
     import subprocess
     c = tmp_path / "sz.c"
-    c.write_text('#include "mi355_ann.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n",'
-                 'sizeof(mi355_index_desc),sizeof(mi355_search_params),sizeof(mi355_flat_desc),sizeof(mi355_stats));return 0;}')
+    pairs = [("mi355_index_desc", _abi.IndexDesc), ("mi355_search_params", _abi.SearchParams),
+             ("mi355_flat_desc", _abi.FlatDesc), ("mi355_stats", _abi.Stats), ("mi355_flat_stats", _abi.FlatStats),
+             ("mi355_comm_stats", _abi.CommStats), ("mi355_encode_desc", _abi.EncodeDesc),
+             ("mi355_kmeans_desc", _abi.KmeansDesc), ("mi355_pq_train_desc", _abi.PqTrainDesc)]
+    c.write_text('#include "mi355_ann.h"\n#include <stdio.h>\nint main(){printf("' + " ".join(["%zu"] * len(pairs)) + '\\n",'
+                 + ",".join(f"sizeof({n})" for n, _ in pairs) + ');return 0;}')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.dirname(HEADER), str(c), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert [int(x) for x in out] == [C.sizeof(_abi.IndexDesc), C.sizeof(_abi.SearchParams),
-                                     C.sizeof(_abi.FlatDesc), C.sizeof(_abi.Stats)]
+    assert [int(x) for x in out] == [C.sizeof(t) for _, t in pairs]
 
 
 def _desc(**over):

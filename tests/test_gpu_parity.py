@@ -505,6 +505,7 @@ def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
         mt = _abi.METRIC_NAMES[metric]
         _assert_same(f.search(q, k=10, metric=mt), oracle.flat_search(v, q, k=10, metric=mt))
         assert f.info()[0] == 1
+        assert f.stats()["fallback_queries"] == 0  # random data: the filter itself must have done the work
     # a single k-tile per row tile (dim <= 64): the first stage of the next tile is the only stage
     # (the 8-phase walk needs two k-tiles and hands such columns to the two-barrier kernel)
     v1, q1 = np.ascontiguousarray(v[:, :40]), np.ascontiguousarray(q[:, :40])
@@ -531,6 +532,7 @@ def test_flat_mfma_eight_phase_schedule(oracle, variant, grid):
             exp = oracle.flat_search(v, q, k=10, metric=mt)
             for _ in range(3):
                 _assert_same(f.search(q, k=10, metric=mt), exp)
+                assert f.stats()["fallback_queries"] == 0  # a garbage filter would hide behind the exact re-scan
             assert f.info()[0] == 1
 
 
@@ -553,6 +555,28 @@ def test_flat_mfma_eight_phase_reference_epilogue_matches_two_barrier_kernel_bit
             sums[(name, metric)] = f.checksum()
     for metric in ("l2", "cosine", "dot"):
         assert len({sums[(n, metric)] for n in ("256", "8ref", "8ref_g1", "8ref_g24", "4ref", "4ref_g1", "4ref_g24")}) == 1, sums
+
+
+@pytest.mark.parametrize("variant", sorted(GEMM_VARIANTS))
+def test_flat_gemm_variants_on_a_chip_filling_grid(variant):
+    """Every schedule on a column large enough for every CU to walk many tiles (and, with grid 1,
+    for thousands of one-tile workgroups): identical results across variants and no candidate-list
+    overflow (the exact re-scan would mask a wrong filter; checked against the exact sweep on a
+    sample of queries)."""
+    rng = np.random.default_rng(5)
+    n, dim = 400_000, 256
+    v = rng.normal(size=(n, dim)).astype(np.float32)
+    q = rng.normal(size=(512, dim)).astype(np.float32)
+    f = lancedb_amd.FlatIndex(v)
+    f.configure(gemm_variant=_abi.FLAT_GEMM_256)
+    ref = f.search(q, k=10)
+    assert f.stats()["fallback_queries"] == 0
+    for grid in (0, 1):
+        f.configure(gemm_variant=GEMM_VARIANTS[variant], grid_workgroups=grid)
+        for _ in range(2):
+            got = f.search(q, k=10)
+            assert f.stats()["fallback_queries"] == 0, (variant, grid)
+            assert (got.rowids == ref.rowids).all() and (got.distances == ref.distances).all()
 
 
 def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):

@@ -340,23 +340,20 @@ int32_t mi355_flat_search(mi355_flat *flat, const float *queries,
                           uint32_t *out_counts);
 
 /* Tuning of the flat GEMM filter.  gemm_variant: MI355_FLAT_GEMM_* (AUTO = the library's
-   choice per batch size).  grid_workgroups: 0 = one persistent workgroup per CU slot,
-   1 = one workgroup per tile, N >= 8 = a persistent grid of N / 8 * 8 workgroups.
-   flags: MI355_FLAT_CHECKSUM = after every GEMM launch synchronise and keep an
-   order-independent checksum of the group-minimum matrix (mi355_flat_checksum; used to
-   compare schedules bit for bit). */
+   choice per batch size).  grid_workgroups: 1 = one workgroup per tile, N >= 8 = a persistent
+   grid of N / 8 * 8 workgroups (each walks its XCD's tiles), 0 = the library's choice for the
+   schedule.  flags: MI355_FLAT_CHECKSUM = after every GEMM launch synchronise and keep an
+   order-independent checksum + census of the group-minimum matrix (mi355_flat_checksum /
+   mi355_flat_census; used to compare schedules bit for bit). */
 enum {
   MI355_FLAT_GEMM_AUTO = 0,
   MI355_FLAT_GEMM_128 = 1,       /* 128 x 128 tile, 4 waves, two barriers per k-step */
   MI355_FLAT_GEMM_256 = 2,       /* 256 x 256 tile, 8 waves, two barriers per k-step */
-  MI355_FLAT_GEMM_256x128_3 = 3, /* 256 x 128, three LDS stages, one barrier per k-step */
-  MI355_FLAT_GEMM_8PHASE = 4,    /* 256 x 256, persistent 8-phase schedule (counted vmcnt,
-                                    staggered wave groups), fast epilogue */
-  MI355_FLAT_GEMM_8PHASE_REF = 5,/* the same schedule with variant 2's epilogue arithmetic */
-  MI355_FLAT_GEMM_8PHASE_M = 6,  /* variant 4 with the LDS-DMA pieces issued among the MFMAs */
-  MI355_FLAT_GEMM_4SLOT = 7,     /* 256 x 256, persistent, two 32-MFMA phases per k-tile (4 slots), pieces
-                                    among the MFMAs, epilogue inputs through LDS, fast epilogue */
-  MI355_FLAT_GEMM_4SLOT_REF = 8  /* the same schedule with variant 2's epilogue arithmetic */
+  /* 3, 6, 7, 8: schedules measured as no gain in rounds 1-2 and removed (profiles/r02_*) */
+  MI355_FLAT_GEMM_8PHASE = 4,    /* 256 x 256, 8-phase schedule (counted vmcnt, staggered wave
+                                    groups), fast epilogue: AUTO's choice above 128 queries */
+  MI355_FLAT_GEMM_8PHASE_REF = 5 /* the same schedule with variant 2's epilogue arithmetic
+                                    (bit-identical filter matrix: the schedule's own check) */
 };
 enum {
   MI355_FLAT_CHECKSUM = 1u,

@@ -54,12 +54,8 @@ CFG_COALESCE = 0x200
 FLAT_GEMM_AUTO = 0
 FLAT_GEMM_128 = 1
 FLAT_GEMM_256 = 2
-FLAT_GEMM_256x128_3 = 3
 FLAT_GEMM_8PHASE = 4
 FLAT_GEMM_8PHASE_REF = 5
-FLAT_GEMM_8PHASE_M = 6
-FLAT_GEMM_4SLOT = 7
-FLAT_GEMM_4SLOT_REF = 8
 FLAT_CHECKSUM = 1
 FLAT_PROFILE = 2
 

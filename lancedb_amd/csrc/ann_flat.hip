@@ -6,11 +6,12 @@
 #include "kernels_flat.h"
 #include "kernels_flat_mfma.h"
 #include "kernels_flat_mfma8.h"
-#include "kernels_flat_mfma4.h"
 
 // what MI355_FLAT_GEMM_AUTO means for batches > 128 queries: the variant validated and measured
-// fastest on hardware (profiles/r02_*); flipped only together with a committed A/B
-#define MI355_FLAT_GEMM_AUTO_BIG MI355_FLAT_GEMM_256
+// fastest on hardware (profiles/r02_e_flat_gemm_schedules.json: 8-phase, one workgroup per tile,
+// 14.45 ms against 15.46 ms for the two-barrier kernel at 10 M x 768); flipped only together with
+// a committed A/B
+#define MI355_FLAT_GEMM_AUTO_BIG MI355_FLAT_GEMM_8PHASE
 
 // -------------------------------------------------------------------- flat --
 extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
@@ -41,8 +42,7 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
     return bail(fail(MI355_ERR_RUNTIME, "hipStreamCreate failed"));
   f->stream = f->own_stream;
   size_t vb = dtype_size(d->dtype) * (size_t)d->dim * d->n_rows;
-  // + 256 rows: the GEMM's last row tile stages whole tiles (rows past the column are masked, never used)
-  int32_t s = f->vectors.ensure(std::max<size_t>(vb + dtype_size(d->dtype) * (size_t)d->dim * 256, 16));
+  int32_t s = f->vectors.ensure(std::max<size_t>(vb, 16));
   if (s) return bail(s);
   if (copy_in(f->vectors.p, d->vectors, vb, d->mem, f->stream) != hipSuccess)
     return bail(fail(MI355_ERR_RUNTIME, "upload of the vector column failed"));
@@ -60,7 +60,7 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
       f->dimp = (d->dim + 63u) & ~63u;
       f->shadowed = d->dtype != MI355_DTYPE_BF16 || f->dimp != d->dim;
       if (f->shadowed) {
-        s = f->shadow.ensure(((size_t)d->n_rows + 256) * f->dimp * 2);
+        s = f->shadow.ensure((size_t)d->n_rows * f->dimp * 2);
         if (s) return bail(s);
       }
       // padded to whole 256-row tiles (tail = 0): the GEMM epilogue loads its tile's terms unconditionally
@@ -107,16 +107,15 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
                              const RangeFilter& range, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt) {
   hipStream_t st = f->stream;
   // GEMM schedule (mi355_flat_configure): 128 x 128 (4 waves, 2 workgroups per CU) for small batches,
-  // otherwise a 256 x 256 tile: the persistent 8-phase schedule when the k loop has >= 2 tiles
+  // otherwise a 256 x 256 tile: the 8-phase schedule when the k loop has >= 2 tiles
   uint32_t variant = f->gemm_variant;
   const uint32_t KT = f->dimp / FG_BK;
   if (variant == MI355_FLAT_GEMM_AUTO) variant = nq <= 128 ? MI355_FLAT_GEMM_128 : MI355_FLAT_GEMM_AUTO_BIG;
   if (variant >= MI355_FLAT_GEMM_8PHASE && KT < 2)
     variant = MI355_FLAT_GEMM_256;  // the 8-phase walk stages two k-tiles ahead
   const bool oct = variant >= MI355_FLAT_GEMM_8PHASE;
-  const bool quad = variant == MI355_FLAT_GEMM_4SLOT || variant == MI355_FLAT_GEMM_4SLOT_REF;
-  const bool big = variant == MI355_FLAT_GEMM_256 || oct, tri = variant == MI355_FLAT_GEMM_256x128_3;
-  const uint32_t BM = (big || tri) ? 256 : 128, BN = big ? 256 : 128;
+  const bool big = variant == MI355_FLAT_GEMM_256 || oct;
+  const uint32_t BM = big ? 256 : 128, BN = BM;
   const uint32_t n_rtiles = (uint32_t)((f->n_rows + BM - 1) / BM);
   const uint32_t n_groups = n_rtiles * (BM / FG_GROUP);
   uint32_t groups_per_seg = (n_groups + FG_MAX_SEG - 1) / FG_MAX_SEG;
@@ -195,42 +194,33 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;  // one per (row tile, query tile)
     // persistent grid: one workgroup per CU slot walks its XCD's tiles and overlaps the next tile's
     // first stage with the current tile's last k-step and epilogue (grid_workgroups of
-    // mi355_flat_configure: 0 = that, 1 = one workgroup per tile, N >= 8 = a grid of N / 8 * 8)
-    if (f->grid_workgroups != 1) {
+    // mi355_flat_configure: 1 = one workgroup per tile, N >= 8 = a persistent grid of N / 8 * 8,
+    // 0 = what measured fastest for the schedule: persistent for the two-barrier kernels, one
+    // workgroup per tile for the 8-phase one, whose staggered wave groups already hide the prologue)
+    if (f->grid_workgroups != 1 && !(oct && f->grid_workgroups == 0)) {
       uint32_t slots = f->grid_workgroups / 8 * 8;
       if (f->grid_workgroups < 8) {
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, f->device));
-        slots = (uint32_t)std::max(cus, 8) / 8 * 8 * ((big || tri) ? 1u : 2u);
+        slots = (uint32_t)std::max(cus, 8) / 8 * 8 * (big ? 1u : 2u);
       }
       gemm_blocks = std::min(gemm_blocks, slots);
     }
-    const size_t gemm_lds = (size_t)(tri ? 3 : 2) * (BM + BN) * FG_BK * 2 + (quad ? 6144 : 0);
+    const size_t gemm_lds = (size_t)2 * (BM + BN) * FG_BK * 2;
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \
-    if (tri) {                                                                                      \
-      auto kern = k_flat_gemm<MET, 4, 2, 4, 4, 3>;                                                  \
-      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                  (int)gemm_lds));                                                  \
-      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
-    } else if (quad) {                                                                              \
-      auto kern = variant == MI355_FLAT_GEMM_4SLOT ? k_flat_gemm4<MET, 1> : k_flat_gemm4<MET, 0>;   \
-      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                  (int)gemm_lds));                                                  \
-      hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
-    } else if (oct) {                                                                               \
-      auto kern = variant == MI355_FLAT_GEMM_8PHASE_M ? k_flat_gemm8<MET, 1, 1>                      \
-                  : variant == MI355_FLAT_GEMM_8PHASE ? k_flat_gemm8<MET, 1, 0> : k_flat_gemm8<MET, 0, 0>; \
+    if (oct) {                                                                                      \
+      auto kern = variant == MI355_FLAT_GEMM_8PHASE ? k_flat_gemm8<MET, 1> : k_flat_gemm8<MET, 0>;  \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
     } else if (big) {                                                                               \
-      auto kern = k_flat_gemm<MET, 2, 4, 8, 4, 2>;                                                  \
+      auto kern = k_flat_gemm<MET, 2, 4, 8, 4>;                                                     \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
     } else {                                                                                        \
-      auto kern = k_flat_gemm<MET, 2, 2, 4, 4, 2>;                                                     \
+      auto kern = k_flat_gemm<MET, 2, 2, 4, 4>;                                                     \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(256), gemm_lds, st, ga);                     \
@@ -459,7 +449,8 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
 extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, uint32_t grid_workgroups,
                                         uint32_t flags) {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
-  if (gemm_variant > MI355_FLAT_GEMM_4SLOT_REF) return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
+  if (gemm_variant > MI355_FLAT_GEMM_8PHASE_REF || gemm_variant == 3)
+    return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
   if (flags & ~(uint32_t)(MI355_FLAT_CHECKSUM | MI355_FLAT_PROFILE)) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
   std::lock_guard<std::mutex> lk(f->mu);
   f->gemm_variant = gemm_variant;

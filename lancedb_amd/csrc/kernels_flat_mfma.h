@@ -153,7 +153,7 @@ __device__ __forceinline__ void fg_glds16(const void* g, void* lds_wave_base) {
 //     reads (MI + NI) x 1 KiB of fragments for MI x NI MFMAs: 24 KiB per 64 MFMAs instead
 //     of 16 KiB per 32 - with the small tile the LDS read bandwidth (256 B/clk) is as
 //     loaded as the matrix pipe.
-template <int METRIC, int WM, int WN, int MI, int NI, int STAGES>
+template <int METRIC, int WM, int WN, int MI, int NI>
 __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = WM * WN * 64;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
   };
   uint32_t p0 = 0;  // LDS buffer of the current tile's k-tile 0 (two-stage schedule)
-  if constexpr (STAGES == 2) stage(0, 0);
+  stage(0, 0);
   while (true) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -284,54 +284,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
     const uint32_t e_q0 = q0, e_rt = rt;
     const uint32_t nvb = next_valid(vb + gridDim.x);  // sets rt / qt of the next tile
     const bool has_next = nvb < total_vb;
-    if constexpr (STAGES == 2) {
-      // two stages, two barriers per k-step
-      for (uint32_t kt = 0; kt + 1 < KT; ++kt) {
-        const uint32_t buf = (p0 + kt) & 1u;
-        stage(kt + 1, buf ^ 1u);
-        // this stage's DMAs have landed, the next stage's SA + SB fly on
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
-        __builtin_amdgcn_s_barrier();
-        compute(buf);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
-      }
-      {
-        const uint32_t buf = (p0 + KT - 1) & 1u;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (has_next) {
-          // the other buffer was last read in step KT-2, behind that step's closing barrier:
-          // the next tile's first stage flies under this step's MFMAs and the epilogue
-          set_tile();
-          stage(0, buf ^ 1u);
-        }
-        compute(buf);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      p0 = (p0 + KT) & 1u;
-    } else {
-      // three stages, ONE barrier per k-step: stage kt+2 is issued after the barrier of step kt,
-      // i.e. when every wave has finished reading the buffer it overwrites (that of step kt-1)
-      stage(0, 0);
-      if (KT > 1) stage(1, 1);
-      uint32_t buf = 0;
-      for (uint32_t kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT)
-          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");  // stage kt landed, stage kt+1 may fly
-        else
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < KT) stage(kt + 2, buf == 0 ? 2 : buf - 1);
-        compute(buf);
-        buf = buf == 2 ? 0 : buf + 1;
-      }
+    // two stages, two barriers per k-step
+    for (uint32_t kt = 0; kt + 1 < KT; ++kt) {
+      const uint32_t buf = (p0 + kt) & 1u;
+      stage(kt + 1, buf ^ 1u);
+      // this stage's DMAs have landed, the next stage's SA + SB fly on
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(SA + SB) : "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(buf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // the next tile's stage(0) overwrites buffer 0
-      if (has_next) set_tile();
+      __builtin_amdgcn_s_barrier();  // every wave is done reading `buf` before it is refilled
     }
+    {
+      const uint32_t buf = (p0 + KT - 1) & 1u;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (has_next) {
+        // the other buffer was last read in step KT-2, behind that step's closing barrier:
+        // the next tile's first stage flies under this step's MFMAs and the epilogue
+        set_tile();
+        stage(0, buf ^ 1u);
+      }
+      compute(buf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    p0 = (p0 + KT) & 1u;
 
     // ---- epilogue: lo = approx - eps, minimum per 32-row group ------------------
     // D layout (16x16): col = lane & 15 -> query, row = (lane >> 4) * 4 + reg -> row of V
@@ -395,9 +373,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void k_flat_gemm(FlatGemmArgs a) {
     }
     if (!has_next) break;
     vb = nvb;
-    if constexpr (STAGES != 2) {
-      // nothing in flight: the loop head stages the next tile from scratch
-    }
   }
 }
 

@@ -85,16 +85,7 @@
     if (!FG_ABL(16)) __builtin_amdgcn_s_barrier();       \
   } while (0)
 
-// DMA_IN_M = 1 (variant MI355_FLAT_GEMM_8PHASE_M): the LDS-DMA pieces are issued INSIDE the MFMA
-// block of the phase instead of its L section.  A piece costs the issuing wave 60-185 cycles
-// (MI355X_MICROARCH.md, per-instruction constants): two per L section make L (300-400 cycles with
-// the fragment reads) longer than the other group's 16 MFMAs (272), so the slots are loader-bound
-// — the 62 % MfmaUtil of the template.  Among bare MFMAs the issue rides in the matrix pipe's
-// shadow (the wave would otherwise sit on the next MFMA's issue).  Every piece moves one slot
-// later, which only relaxes the WAR conditions above; the RAW wait becomes vmcnt(2): at the q4
-// wait the pieces newer than k-tile g+1's are A-h0(g+2) alone (issued in M_q3; B-h0(g+2) follows
-// in M_q4, after the wait).  The piece addresses are computed in the L section.
-template <int METRIC, int EPI, int DMA_IN_M>
+template <int METRIC, int EPI>
 __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256, BN = 256, MI = 8, NI = 4, WN = 4;
@@ -181,48 +172,8 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   };
 
   fg_f32x4 acc[MI][NI];
-  // DMA_IN_M: a half-tile's two pieces, addresses prepared in the L section, issued among the MFMAs
-  // The issue is UNCONDITIONAL (the MFMA block stays one basic block): past the end of the walk the
-  // pieces re-read k-tile 0 of the last tile into regions nobody reads again (nxt == the last tile
-  // when there is no next one; B-h1 / A-h1 of the other buffer and A-h0 / B-h0 of this one are dead
-  // by the WAR analysis above) and are drained before the kernel ends.
-  struct Pieces {
-    const unsigned char* g[2];  // per-lane global source
-    uint32_t lds[2];            // wave-uniform LDS byte offset
-  };
-  auto prep_pieces = [&](bool is_a, int h, uint32_t u, uint32_t ahead, uint32_t buf) -> Pieces {
-    Pieces pc;
-    const uint32_t kt0 = u + ahead;
-    const TileRef& t = kt0 < KT ? cur : nxt;
-    const uint32_t koff = (kt0 < KT ? kt0 : has_next ? kt0 - KT : 0u) * (FG_BK * 2);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (is_a) {
-        const uint32_t ra0 = i * 128 + h * 64 + wid * 8;
-        uint32_t rs = ra0 + l8;
-        rs = rs < t.lim ? rs : t.lim;
-        pc.g[i] = t.baseA + koff + (size_t)(rs * pitch + swz);
-        pc.lds[i] = buf * BUF + ra0 * 128;
-      } else {
-        const uint32_t g2 = 2 * wid + i;
-        const uint32_t rb0 = (g2 >> 2) * 64 + h * 32 + (g2 & 3u) * 8;
-        pc.g[i] = t.baseB + (koff + rb0 * pitch) + (size_t)voffB;
-        pc.lds[i] = buf * BUF + A_BYTES + rb0 * 128;
-      }
-    }
-    return pc;
-  };
-  auto issue_piece = [&](const Pieces& pc, int i) {
-    if (FG_ABL(1)) {
-      asm volatile("" ::"v"(pc.g[i]), "s"(pc.lds[i]));
-      return;
-    }
-    fg_glds16(pc.g[i], smem + pc.lds[i]);
-  };
-  // one phase's 16 MFMAs (rows mi0..mi0+3, queries ni0..ni0+1, both k-halves), the two pieces after
-  // the 4th and the 10th
-  auto mfma_block = [&](const fg_bf16x8 (&fa)[2][MI], const fg_bf16x8 (&fb)[2][NI], int mi0, int ni0, const Pieces& pc) {
-    int n = 0;
+  // one phase's 16 MFMAs (rows mi0..mi0+3, queries ni0..ni0+1, both k-halves)
+  auto mfma_block = [&](const fg_bf16x8 (&fa)[2][MI], const fg_bf16x8 (&fb)[2][NI], int mi0, int ni0) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -233,12 +184,6 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
             asm volatile("" ::"v"(fa[kk][mi0 + mi]), "v"(fb[kk][ni0 + ni]));
           else
             acc[mi0 + mi][ni0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][mi0 + mi], fb[kk][ni0 + ni], acc[mi0 + mi][ni0 + ni], 0, 0, 0);
-          ++n;
-          if (DMA_IN_M && (n == 4 || n == 10)) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_piece(pc, n == 4 ? 0 : 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
         }
     // pin the block: hipcc otherwise sinks MFMAs (register-only, no memory semantics) below the
     // closing barrier into the next phase's fragment reads, i.e. into the OTHER group's MFMA slot
@@ -381,7 +326,6 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   uint32_t u = 0, par = 0;         // k-tile inside the current tile; parity of the global k-tile index
   bool pending = false;            // the previous tile's epilogue is still to run (its TileRef is `done`)
   TileRef done = cur;
-  Pieces pc = prep_pieces(true, 0, 0, 0, 0);
   bool first = true;  // (ablation 2 reads the fragments once)
   while (true) {
     const unsigned char* sb = smem + par * BUF;
@@ -408,14 +352,11 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (DMA_IN_M)
-      pc = prep_pieces(false, 1, u, 1, par ^ 1u);
-    else
-      (void)stage_ahead(false, 1, u, 1, par ^ 1u);
+    (void)stage_ahead(false, 1, u, 1, par ^ 1u);
     asm volatile("" ::: "memory");
     FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-    mfma_block(fa, fb, 0, 0, pc);
+    mfma_block(fa, fb, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     FG_BARRIER();
@@ -428,14 +369,11 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (DMA_IN_M)
-      pc = prep_pieces(true, 1, u, 1, par ^ 1u);
-    else
-      (void)stage_ahead(true, 1, u, 1, par ^ 1u);
+    (void)stage_ahead(true, 1, u, 1, par ^ 1u);
     asm volatile("" ::: "memory");
     FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-    mfma_block(fa, fb, 0, 2, pc);
+    mfma_block(fa, fb, 0, 2);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     FG_BARRIER();
@@ -448,30 +386,22 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (DMA_IN_M)
-      pc = prep_pieces(true, 0, u, 2, par);
-    else
-      (void)stage_ahead(true, 0, u, 2, par);
+    (void)stage_ahead(true, 0, u, 2, par);
     asm volatile("" ::: "memory");
     FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-    mfma_block(fa, fb, 4, 2, pc);
+    mfma_block(fa, fb, 4, 2);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     FG_BARRIER();
     // ---------------- q4: (A1, B0); stage B-h0(g+2); retire k-tile g+1
-    if (DMA_IN_M) {
-      pc = prep_pieces(false, 0, u, 2, par);
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // A-h0(g+2) flies on; B-h0(g+2) follows among the MFMAs
-    } else {
-      if (stage_ahead(false, 0, u, 2, par))
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A-h0(g+2), B-h0(g+2) fly on
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (stage_ahead(false, 0, u, 2, par))
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A-h0(g+2), B-h0(g+2) fly on
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-    mfma_block(fa, fb, 4, 0, pc);
+    mfma_block(fa, fb, 4, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     FG_BARRIER();
@@ -489,7 +419,5 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     }
   }
   if (wr == 0) FG_BARRIER();  // group 0's extra barrier: every wave executed the same count
-  if (DMA_IN_M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the walk's last (unused) pieces
   if (!FG_ABL(8)) epilogue(done);
-  if (DMA_IN_M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

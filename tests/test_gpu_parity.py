@@ -485,12 +485,11 @@ def test_c5_config_shape_1536d_cosine_refine10(oracle, raw_dtype):
         _assert_same(g.search(q, **kw), o.search(q, **kw))
 
 
-GEMM_VARIANTS = {"128": _abi.FLAT_GEMM_128, "256": _abi.FLAT_GEMM_256, "3": _abi.FLAT_GEMM_256x128_3,
-                 "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF,
-                 "8phase_m": _abi.FLAT_GEMM_8PHASE_M, "4slot": _abi.FLAT_GEMM_4SLOT, "4slot_ref": _abi.FLAT_GEMM_4SLOT_REF}
+GEMM_VARIANTS = {"128": _abi.FLAT_GEMM_128, "256": _abi.FLAT_GEMM_256,
+                 "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF}
 
 
-@pytest.mark.parametrize("tile", ["128", "256", "3", "8phase", "8phase_ref", "8phase_m", "4slot", "4slot_ref"])
+@pytest.mark.parametrize("tile", sorted(GEMM_VARIANTS))
 def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     """A grid of 8 workgroups (one per XCD) walks every tile of the column: the cross-tile
     path of the flat GEMM (next tile's first stages issued under the last k-steps, ragged last
@@ -515,7 +514,7 @@ def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     assert f1.info()[0] == 1
 
 
-@pytest.mark.parametrize("variant", ["8phase", "8phase_ref", "8phase_m", "4slot", "4slot_ref"])
+@pytest.mark.parametrize("variant", ["8phase", "8phase_ref"])
 @pytest.mark.parametrize("grid", [0, 1, 16])
 def test_flat_mfma_eight_phase_schedule(oracle, variant, grid):
     """The persistent 8-phase schedule against the exact sweep: ragged last row tile, 2 / 3 / 12
@@ -547,14 +546,13 @@ def test_flat_mfma_eight_phase_reference_epilogue_matches_two_barrier_kernel_bit
     sums = {}
     for name, var, grid in (("256", _abi.FLAT_GEMM_256, 0), ("8ref", _abi.FLAT_GEMM_8PHASE_REF, 0),
                             ("8ref_g1", _abi.FLAT_GEMM_8PHASE_REF, 1), ("8ref_g24", _abi.FLAT_GEMM_8PHASE_REF, 24),
-                            ("4ref", _abi.FLAT_GEMM_4SLOT_REF, 0), ("4ref_g1", _abi.FLAT_GEMM_4SLOT_REF, 1),
-                            ("4ref_g24", _abi.FLAT_GEMM_4SLOT_REF, 24)):
+                            ("8ref_g256", _abi.FLAT_GEMM_8PHASE_REF, 256)):
         for metric in ("l2", "cosine", "dot"):
             f.configure(gemm_variant=var, grid_workgroups=grid, checksum=True)
             f.search(q, k=10, metric=_abi.METRIC_NAMES[metric])
             sums[(name, metric)] = f.checksum()
     for metric in ("l2", "cosine", "dot"):
-        assert len({sums[(n, metric)] for n in ("256", "8ref", "8ref_g1", "8ref_g24", "4ref", "4ref_g1", "4ref_g24")}) == 1, sums
+        assert len({sums[(n, metric)] for n in ("256", "8ref", "8ref_g1", "8ref_g24", "8ref_g256")}) == 1, sums
 
 
 @pytest.mark.parametrize("variant", sorted(GEMM_VARIANTS))
@@ -571,7 +569,7 @@ def test_flat_gemm_variants_on_a_chip_filling_grid(variant):
     f.configure(gemm_variant=_abi.FLAT_GEMM_256)
     ref = f.search(q, k=10)
     assert f.stats()["fallback_queries"] == 0
-    for grid in (0, 1):
+    for grid in (0, 1, 256):
         f.configure(gemm_variant=GEMM_VARIANTS[variant], grid_workgroups=grid)
         for _ in range(2):
             got = f.search(q, k=10)
@@ -593,8 +591,8 @@ def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):
     q = np.concatenate([v[[100, 5000, 6000, 6002]], np.zeros((1, dim), np.float32),
                         rng.normal(size=(251, dim)).astype(np.float32)])
     f = lancedb_amd.FlatIndex(v)
-    for variant in (_abi.FLAT_GEMM_8PHASE, _abi.FLAT_GEMM_8PHASE_M, _abi.FLAT_GEMM_4SLOT):
-        f.configure(gemm_variant=variant)
+    for variant, grid in ((_abi.FLAT_GEMM_8PHASE, 0), (_abi.FLAT_GEMM_8PHASE, 8)):
+        f.configure(gemm_variant=variant, grid_workgroups=grid)
         for metric in ("l2", "cosine", "dot"):
             mt = _abi.METRIC_NAMES[metric]
             for k in (1, 10, 200):

@@ -282,7 +282,11 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        # tear down in dependency order: the communicator before the index whose stream it used
+        torch.cuda.synchronize()
         dist.barrier()
+        comm.close()
+        ix.close()
         dist.destroy_process_group()
 
 

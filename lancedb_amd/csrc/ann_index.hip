@@ -134,10 +134,11 @@ static int32_t validate_index_desc(const mi355_index_desc* d) {
   if (d->shard_count > 1 && d->shard_rank >= d->shard_count)
     return fail(MI355_ERR_INVALID_INPUT, "shard_rank %u >= shard_count %u", d->shard_rank,
                 d->shard_count);
-  if (scan_pair_lds(d->m, d->nbits, d->dim, 5, 256) > 160u * 1024)
-    return fail(MI355_ERR_NOT_SUPPORTED,
-                "distance table of %u sub-vectors x %u entries (%u KiB) does not fit the 160 KiB LDS", d->m,
-                1u << d->nbits, (d->m << d->nbits) * 4 / 1024);
+  // an 8-bit distance table larger than the LDS keeps its tail in global memory (k_scan_pair SPILL);
+  // what cannot work is a residual + candidate lists that leave no room for any table
+  if (scan_pair_m_lds(d->m, d->nbits, d->dim) == 0)
+    return fail(MI355_ERR_NOT_SUPPORTED, "dim %u / %u sub-vectors x %u entries do not fit the 160 KiB LDS", d->dim,
+                d->m, 1u << d->nbits);
   return MI355_OK;
 }
 
@@ -152,7 +153,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->cbT,       &ix->order,  &ix->xcd_first, &ix->p_cnt,  &ix->p_off,
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
-                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann};
+                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -183,7 +184,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   const uint32_t nlist = d->nlist, m = d->m, mb = ix->mb, cb_entries = 1u << d->nbits;
   for (DevBuf* b : {&ix->w_q, &ix->w_qp, &ix->w_qq, &ix->w_coarse, &ix->w_probes, &ix->w_cand, &ix->w_ids, &ix->w_dist,
                     &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr,
-                    &ix->w_filter, &ix->w_probes64})
+                    &ix->w_filter, &ix->w_probes64, &ix->w_spill})
     b->gen = &ix->ws_gen;  // a re-allocation of any of these invalidates the cached hipGraphs
 
   // -- ownership + local layout
@@ -656,6 +657,9 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   // tuning (dev knobs; defaults chosen from the index shape)
   uint32_t nt = dev_knob("MI355_SCAN_THREADS", 0), vpt = dev_knob("MI355_SCAN_VPT", 0);
   if (!nt) nt = pl.kk > 64 ? 256 : ix->max_len >= 8192 ? 1024 : ix->max_len >= 2048 ? 512 : 256;
+  // an 8-bit distance table larger than the LDS keeps its tail in global memory (long lists, 256 threads)
+  const uint32_t m_lds = skew ? ix->m : scan_pair_m_lds(ix->m, ix->nbits, ix->dim);
+  if (m_lds < ix->m) nt = 256;
   if (!vpt) vpt = ix->max_len >= 4 * nt * 4 ? 16 : 4;
   // Generic kernel: one work item per (query, partition) whenever the batch
   // alone fills the chip: the distance table is then built once per pair and
@@ -672,7 +676,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   const uint32_t n_slices = skew ? 1u : std::max(1u, (ix->max_len + slice - 1) / slice);
 
   // chunk the batch so the workspace stays bounded
-  const size_t per_q = (size_t)ix->nlist * 4 + (size_t)nprobe * n_slices * pl.kk * sizeof(Cand);
+  const size_t spill_per_item = (size_t)(ix->m - m_lds) * 1024;  // table tail of one work item (k_scan_pair SPILL)
+  const size_t per_q = (size_t)ix->nlist * 4 + (size_t)nprobe * n_slices * (pl.kk * sizeof(Cand) + spill_per_item);
   const size_t budget = (size_t)dev_knob("MI355_WORKSPACE_MB", 2048) << 20;
   uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / std::max<size_t>(per_q, 1)));
   chunk = std::min(chunk, 65535u);  // grid.z limit
@@ -685,6 +690,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   ST_TRY(ix->w_coarse.ensure(sizeof(float) * (size_t)chunk * ix->nlist));
   ST_TRY(ix->w_probes.ensure(sizeof(uint32_t) * (size_t)chunk * nprobe));
   ST_TRY(ix->w_cand.ensure(sizeof(Cand) * (size_t)chunk * nprobe * n_slices * pl.kk));
+  if (spill_per_item) ST_TRY(ix->w_spill.ensure(spill_per_item * (size_t)chunk * nprobe * n_slices));
   if (pl.refine && !pl.out_cand) ST_TRY(ix->w_cand2.ensure(sizeof(Cand) * (size_t)chunk * pl.kk * 2));
   DevCtl* d_ctl = ix->w_ctl.as<DevCtl>();
   unsigned long long* d_stat = &d_ctl->rows_scanned;
@@ -789,6 +795,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       sa.cand = ix->w_cand.as<Cand>();
       sa.dbg = dev_knob("MI355_DBG_SKIP", 0);
       sa.ctl = d_ctl;
+      sa.m_lds = m_lds;
+      sa.lut_spill = ix->w_spill.as<float>();
       ST_TRY(launch_scan_pair(sa, dim3(n_slices, nprobe, n), st, vpt, nt));
     }
     if (prof) HIP_TRY(hipEventRecord(es.ev[3], st));

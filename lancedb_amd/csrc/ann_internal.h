@@ -190,7 +190,7 @@ struct mi355_index {
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2, w_dist2, w_cnt2, w_ctl,
-      w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann;
+      w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann, w_spill;
   uint32_t ws_gen = 0;  // bumped by every workspace re-allocation
   // config
   uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
@@ -257,6 +257,7 @@ struct ScanArgs;
 struct SkewArgs;
 int32_t launch_scan_pair(const ScanArgs& sa, dim3 grid, hipStream_t st, uint32_t vpt, uint32_t nt);
 size_t scan_pair_lds(uint32_t m, uint32_t nbits, uint32_t dim, uint32_t lr, uint32_t nt);
+uint32_t scan_pair_m_lds(uint32_t m, uint32_t nbits, uint32_t dim);
 int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint32_t dim, uint32_t kk, hipStream_t st);
 
 struct IndexView;

@@ -10,10 +10,19 @@ size_t scan_pair_lds(uint32_t m, uint32_t nbits, uint32_t dim, uint32_t lr, uint
          (size_t)(nt / 64) * 4 + 48;
 }
 
-template <int VPT, int LR, int NT, int NBITS, bool MULTI>
+// sub-quantisers whose 8-bit tables fit the LDS next to everything else (m itself when all do);
+// the spill launch always uses the long lists / 256 threads
+uint32_t scan_pair_m_lds(uint32_t m, uint32_t nbits, uint32_t dim) {
+  if (scan_pair_lds(m, nbits, dim, 5, 256) <= 160u * 1024) return m;
+  if (nbits != 8) return 0;  // 4-bit tables are 64 B per sub-quantiser: not the problem then
+  const size_t rest = scan_pair_lds(0, 8, dim, 5, 256);
+  return rest + 1024 <= 160u * 1024 ? (uint32_t)((160u * 1024 - rest) / 1024) : 0u;
+}
+
+template <int VPT, int LR, int NT, int NBITS, bool MULTI, bool SPILL = false>
 static int32_t launch_one(const ScanArgs& sa, dim3 grid, hipStream_t st) {
-  auto kern = k_scan_pair<VPT, LR, NT, NBITS, MULTI>;
-  const size_t lds = scan_pair_lds(sa.ix.m, NBITS, sa.ix.dim, LR, NT);
+  auto kern = k_scan_pair<VPT, LR, NT, NBITS, MULTI, SPILL>;
+  const size_t lds = scan_pair_lds(SPILL ? sa.m_lds : sa.ix.m, NBITS, sa.ix.dim, LR, NT);
   if (lds > 160u * 1024)
     return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds);
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -34,6 +43,14 @@ static int32_t launch_vpt(const ScanArgs& sa, dim3 grid, hipStream_t st, uint32_
 }
 
 int32_t launch_scan_pair(const ScanArgs& sa, dim3 grid, hipStream_t st, uint32_t vpt, uint32_t nt) {
+  if (sa.ix.nbits == 8 && sa.m_lds < sa.ix.m) {  // table tail in global memory
+    if (!sa.lut_spill || !sa.m_lds) return fail(MI355_ERR_RUNTIME, "spilled distance table without scratch");
+    if (vpt == 4)
+      return sa.kk > SCAN_PASS_ROWS ? launch_one<4, 5, 256, 8, true, true>(sa, grid, st)
+                                    : launch_one<4, 5, 256, 8, false, true>(sa, grid, st);
+    return sa.kk > SCAN_PASS_ROWS ? launch_one<16, 5, 256, 8, true, true>(sa, grid, st)
+                                  : launch_one<16, 5, 256, 8, false, true>(sa, grid, st);
+  }
   if (sa.ix.nbits == 8) {
     if (vpt == 4) return launch_vpt<4, 8>(sa, grid, st, nt);
     if (vpt == 16) return launch_vpt<16, 8>(sa, grid, st, nt);

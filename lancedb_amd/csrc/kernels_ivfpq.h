@@ -437,6 +437,11 @@ struct ScanArgs {
   Cand* cand;               // [nq, nprobe, n_slices, kk]
   uint32_t dbg;             // dev ablation mask (MI355_DBG_SKIP): 1 LUT build, 2 ADC loop, 4 top-k
   DevCtl* ctl;              // deadline / counters of the call
+  // SPILL (8-bit tables that exceed the LDS, e.g. dim 3072 with the default dim / 16 = 192 sub-vectors):
+  // sub-quantisers [0, m_lds) keep their tables in LDS, the rest live in a per-work-item slice of
+  // `lut_spill` ([grid blocks][m - m_lds][256] f32, served by L2) and are gathered from there
+  uint32_t m_lds;
+  float* lut_spill;
 };
 
 // rows per selection pass of a scan work item when kk exceeds the per-wave list capacity
@@ -461,7 +466,8 @@ __device__ __forceinline__ float finalize_dist(float acc, uint32_t metric, uint3
 // MULTI: kk > 256 — the work item's rows are selected in passes of SCAN_PASS_ROWS: pass p keeps
 // the best rows strictly above the last row of pass p-1 in the (distance, rowid) order and
 // writes ranks p*256 .. of the item's kk output slots; the distance table is built once.
-template <int VPT, int LR, int NTHREADS, int NBITS, bool MULTI>
+// SPILL: see ScanArgs::m_lds (the sum stays j-ascending: LDS part first, then the spilled part).
+template <int VPT, int LR, int NTHREADS, int NBITS, bool MULTI, bool SPILL = false>
 __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NTHREADS / MI355_WAVE;
@@ -485,8 +491,12 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
     return;
   }
   const uint32_t v1 = min(len, v0 + a.slice_rows);
-  const size_t lut_bytes = (size_t)ix.m * CB * 4;
-  float* lut = (float*)smem;                  // [m][CB]
+  const uint32_t m_lds = SPILL ? a.m_lds : ix.m;
+  const size_t lut_bytes = (size_t)m_lds * CB * 4;
+  float* lut = (float*)smem;                  // [m_lds][CB]
+  float* spill = nullptr;                     // [m - m_lds][CB] of this work item
+  if (SPILL)
+    spill = a.lut_spill + ((((size_t)b * gridDim.y + r) * gridDim.x + s) * (ix.m - m_lds)) * CB;
   float* res = (float*)(smem + lut_bytes);    // [dim]
   const float* q = a.qp + (size_t)b * ix.dim;
 
@@ -514,10 +524,13 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
           acc = __fmaf_rn(df, df, acc);
         }
       }
-      lut[e] = acc;
+      if (!SPILL || j < m_lds)
+        lut[e] = acc;
+      else
+        spill[e - m_lds * CB] = acc;
     }
   }
-  __syncthreads();
+  __syncthreads();  // (orders the block's global writes to `spill` before its reads, too)
 
   // ---- K3: ADC scan + K4 shuffle-free selection ----------------------------
   ListEnt* lists = (ListEnt*)(smem + lut_bytes + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
       for (int e = 0; e < VPT; ++e) acc[e] = 0.f;
       const uint8_t* col = codes + i0;
 #pragma unroll 8
-      for (uint32_t jb = 0; jb < ix.mb; ++jb) {
+      for (uint32_t jb = 0; jb < (SPILL ? m_lds : ix.mb); ++jb) {
         cvec cv = *(const cvec*)(col + (size_t)jb * stride);
         if (NBITS == 8) {
           const float* t = lut + jb * 256;
@@ -572,6 +585,15 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
             acc[e] = acc[e] + t0[by & 15u];
             acc[e] = acc[e] + t1[by >> 4];
           }
+        }
+      }
+      if (SPILL) {  // the table's tail: 4-byte gathers from L2
+#pragma unroll 4
+        for (uint32_t jb = m_lds; jb < ix.mb; ++jb) {
+          cvec cv = *(const cvec*)(col + (size_t)jb * stride);
+          const float* t = spill + (size_t)(jb - m_lds) * 256;
+#pragma unroll
+          for (int e = 0; e < VPT; ++e) acc[e] = acc[e] + t[code_byte<VPT>(cv, e)];
         }
       }
       if (a.dbg & 4u) {  // ablation: keep the distances live, skip the selection

@@ -71,7 +71,7 @@ def _desc(**over):
     (dict(metric=9), _abi.ERR_INVALID_INPUT, "metric"),
     (dict(n_rows=5), _abi.ERR_INVALID_INPUT, "part_offsets"),
     (dict(shard_count=2, shard_rank=2), _abi.ERR_INVALID_INPUT, "shard_rank"),
-    (dict(m=200, dim=1600), _abi.ERR_NOT_SUPPORTED, "LDS"),
+    (dict(m=2, dim=40000), _abi.ERR_NOT_SUPPORTED, "LDS"),  # (m = 200 x 256 entries spill to global memory: fine)
 ])
 def test_index_open_rejects_bad_descriptors(L, over, status, needle):
     d, keep = _desc(**over)

@@ -30,8 +30,8 @@ One JSON line on rank 0, with `roofline` (dominant kernel = the ADC scan, HIP
 events recorded on the search stream inside the timed region) and, at N = 1,
 `cpu_baseline` (the C oracle on a bounded sample of the same queries, also used
 as a full-size parity check), `recall_at_10` (a trained 2 M-row index, engine and
-oracle), and `secondary`: the same 100 M index with refine_factor 10 over resident
-bf16 raw vectors (the operating point whose recall@10 is >= 0.9) and flat C2
+oracle), and `secondary`: single-query latency and 64-thread throughput of host callers,
+the same 100 M index with refine_factor 10 / 25 over resident bf16 raw vectors, and flat C2
 (BASELINE.json configs[1]: 10 M x 768 bf16, 1024 queries, L2 and cosine) with the
 GEMM kernel's own roofline and a full-size parity check each.
 """
@@ -267,8 +267,8 @@ def main():
     if rank == 0 and world == 1 and a.recall_rows > 0:
         result["recall_at_10"] = recall_at_10(a, np, dim, m)
     if rank == 0 and world == 1 and a.secondary:
-        result["secondary"] = {"latency_c3": latency_and_concurrency(a, np, ix, qpool),
-                               "c3_refine10": refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev)}
+        result["secondary"] = {"latency_c3": latency_and_concurrency(a, np, ix, qpool)}
+        result["secondary"].update(refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev))
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(a, np, h_centroids, h_codebook, part_offsets, h_codes, h_rowids,
                                               qpool[(a.steps - 1) % P], last, params)
@@ -334,7 +334,13 @@ def latency_and_concurrency(a, np, ix, qpool):
             lat.append(time.perf_counter() - t0)
         lat = np.sort(np.array(lat)) * 1e6
         out[f"single_query_us_{mode}"] = {"p50": float(lat[100]), "p99": float(lat[197]), "mean": float(lat.mean())}
-    out["graph_replays"] = ix.stats()["graph_replays"]
+        if graph:
+            out["graph_replays"] = ix.stats()["graph_replays"]  # (configure() resets the counters)
+    # where a single query's time goes on the device (per-stage HIP events of one eager search)
+    ix.configure(profile=1, graph=False, coalesce=False)
+    ix.search(hq[7:8], **kw)
+    st = ix.stats()
+    out["single_query_stage_us"] = {s2: st["us_" + s2] for s2 in ("coarse", "select", "scan", "merge")}
     for mode, coalesce in (("coalesced", True), ("serialised", False)):
         ix.configure(profile=0, graph=True, coalesce=coalesce)
         n_threads, per = 64, 24
@@ -356,16 +362,17 @@ def latency_and_concurrency(a, np, ix, qpool):
 
 
 def refine_operating_point(a, torch, ix, qpool, n_rows, dim, dev):
-    """The SAME 100 M index with refine_factor 10 (query.rs:1302-1332): k * 10 ANN candidates per query,
-    exact re-rank on raw bf16 vectors resident in HBM (100 M x 768 x 2 B = 154 GB).  This is the
-    operating point whose recall@10 is >= 0.9 on the trained index of the recall leg; the raw
-    vectors are random finite bf16 values (the gather / exact-distance work does not depend on them)."""
+    """The SAME 100 M index with refine_factor 10 and 25 (query.rs:1302-1332): k * rf ANN candidates per query,
+    exact re-rank on raw bf16 vectors resident in HBM (100 M x 768 x 2 B = 154 GB, borrowed from the
+    caller: mi355_index_attach_raw).  The recall of each point on a trained index is in the recall
+    leg (recall_at_10.nprobe64_refine10 / _refine25); the raw vectors here are random finite bf16
+    values (the gather / exact-distance work does not depend on them)."""
     import lancedb_amd
     from lancedb_amd import _abi
     free, _ = torch.cuda.mem_get_info(dev)
     need = n_rows * dim * 2
     if free < need + (24 << 30):
-        return {"skipped": f"{need / 1e9:.0f} GB of raw vectors do not fit ({free / 1e9:.0f} GB free)"}
+        return {"c3_refine10": {"skipped": f"{need / 1e9:.0f} GB of raw vectors do not fit ({free / 1e9:.0f} GB free)"}}
     raw = torch.empty((n_rows, dim), dtype=torch.int16, device=dev)
     g = torch.Generator(device=dev)
     g.manual_seed(SEED + 7)
@@ -376,33 +383,38 @@ def refine_operating_point(a, torch, ix, qpool, n_rows, dim, dev):
     t0 = time.perf_counter()
     ix.attach_raw_vectors(raw, _abi.DTYPE_BF16)
     t_attach = time.perf_counter() - t0
-    B, k, rf = a.batch, a.k, 10
-    params = _abi.make_params(k=k, nprobe_min=a.nprobe, nprobe_max=a.nprobe, refine_factor=rf)
+    B, k = a.batch, a.k
     out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
            torch.empty((B,), dtype=torch.int32, device=dev))
-    ix.configure(profile=0)
-    for i in range(2):
-        ix.search(qpool[i % len(qpool)], params, out=out)
-    torch.cuda.synchronize()
-    ix.configure(profile=2)
-    steps = max(3, a.steps // 2)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ix.search(qpool[i % len(qpool)], params, out=out)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = ix.stats()
-    ix.detach_raw_vectors()
-    del raw
-    torch.cuda.empty_cache()
-    refine_bytes = B * k * rf * dim * 2  # algorithmic: k * rf raw rows per query
-    return {"value": B * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+    res = {}
+    for rf in (10, 25):  # k * rf = 100 / 250 candidates per query (recall of both: recall_at_10.nprobe64_refine*)
+        params = _abi.make_params(k=k, nprobe_min=a.nprobe, nprobe_max=a.nprobe, refine_factor=rf)
+        ix.configure(profile=0)
+        for i in range(2):
+            ix.search(qpool[i % len(qpool)], params, out=out)
+        torch.cuda.synchronize()
+        ix.configure(profile=2)
+        steps = max(3, a.steps // 2)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ix.search(qpool[i % len(qpool)], params, out=out)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = ix.stats()
+        refine_bytes = B * k * rf * dim * 2  # algorithmic: k * rf raw rows per query
+        res[f"c3_refine{rf}"] = {
+            "value": B * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
             "config": {"workload": f"ivfpq C3 + refine_factor {rf}, raw bf16 vectors resident", "k": k, "refine_factor": rf,
                        "nprobe": a.nprobe, "batch_queries": B, "raw_vectors_gb": need / 1e9, "attach_s": round(t_attach, 2)},
             "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge", "refine")},
             "refine_gather": {"algorithmic_bytes_per_step": refine_bytes,
                               "gb_per_s": refine_bytes / max(st["us_refine"] / steps, 1e-9) / 1e3},
-            "recall_at_10": "see recall_at_10.nprobe64_refine10 (trained index)"}
+            "recall_at_10": f"see recall_at_10.nprobe64_refine{rf} (trained index)"}
+    ix.configure(profile=0)
+    ix.detach_raw_vectors()
+    del raw
+    torch.cuda.empty_cache()
+    return res
 
 
 def flat_c2(a, metric, cpu_queries):
@@ -556,7 +568,7 @@ def recall_at_10(a, np, dim, m):
         orc.build()
         ox = orc.OracleIndex(cen.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
                              order.cpu().numpy().astype(np.uint64), raw_vectors=xs.cpu().numpy())
-    for nprobe, rf in ((64, 0), (64, 10), (16, 0)):
+    for nprobe, rf in ((64, 0), (64, 10), (64, 25), (64, 50), (16, 0)):
         key = f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")
         got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf).rowids
         out[key] = rec(got)

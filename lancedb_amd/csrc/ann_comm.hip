@@ -85,7 +85,14 @@ extern "C" int32_t mi355_comm_destroy(mi355_comm* c) {
                     &c->tmp_dist, &c->tmp_cnt, &c->w_q, &c->w_ids, &c->w_dist, &c->w_cnt, &c->sq, &c->sids, &c->sdist,
                     &c->scnt, &c->short_rows})
     b->release();
-  if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->comm) {
+    // nothing of this communicator may still be in flight when its resources go away (a caller
+    // that exits right after the destroy would otherwise race RCCL's own teardown): drain the
+    // device, finalize (flushes outstanding operations and stops the proxy), then destroy
+    (void)hipDeviceSynchronize();
+    (void)ncclCommFinalize(c->comm);
+    (void)ncclCommDestroy(c->comm);
+  }
   delete c;
   return MI355_OK;
 }

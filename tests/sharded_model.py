@@ -20,8 +20,6 @@ The shard plan and the centroid slices come from the product's own host code
 import ctypes as C
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 import lancedb_amd
 from lancedb_amd import _abi
@@ -116,6 +114,8 @@ def _slab(cands, counts):
 
 
 def _gather(slab, world, group=None):
+    import torch  # (only the gloo model needs it: a GPU test process that has initialised RCCL through
+    import torch.distributed as dist  # the C ABI must not import torch afterwards)
     mine = torch.from_numpy(slab.copy())
     out = torch.empty(world * mine.numel(), dtype=torch.uint8)
     dist.all_gather_into_tensor(out, mine, group=group)  # ONE collective per exchange

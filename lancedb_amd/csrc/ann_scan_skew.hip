@@ -10,11 +10,11 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_
                                   hipStream_t st) {
   auto lds_of = [&](int nw, int lr) {
     return (size_t)SK_TABLE_BYTES + (((size_t)dim * 4 + 15) & ~(size_t)15) +
-           (size_t)nw * lr * 64 * 8 + (size_t)(nw + 10) * 4 + 128;
+           (size_t)nw * lr * 64 * 8 + (size_t)(2 * nw + 11) * 4 + 128;
   };
-#define LAUNCH_SK(LR, NT, MULTI)                                                                \
+#define LAUNCH_SK(LR, NT, MULTI, OPT)                                                           \
   {                                                                                             \
-    auto kern = k_scan_skew<M, LR, NT, MULTI>;                                                       \
+    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT>;                                             \
     const size_t lds = lds_of(NT / 64, LR);                                                     \
     if (lds > 160u * 1024)                                                                      \
       return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
@@ -22,10 +22,14 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_
                                 (int)lds));                                                     \
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(NT), lds, st, sa);                            \
   }
-  if (kk <= 64) LAUNCH_SK(2, 1024, false)
-  else if (kk <= 128) LAUNCH_SK(3, 1024, false)
-  else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false)
-  else LAUNCH_SK(5, 512, true)  // passes of SCAN_PASS_ROWS rows per work item
+  // kk <= 128: sixteen waves with lists of 128 / 192 rows; 128 < kk <= 256: sixteen waves with
+  // 192-row lists, optimistic single pass (k_scan_skew OPT) when that fits the LDS, else eight waves
+  // with 320-row lists; beyond: eight waves, passes of SCAN_PASS_ROWS rows per work item
+  if (kk <= 64) LAUNCH_SK(2, 1024, false, false)
+  else if (kk <= 128) LAUNCH_SK(3, 1024, false, false)
+  else if (kk <= SCAN_PASS_ROWS && lds_of(16, 3) <= 160u * 1024) LAUNCH_SK(3, 1024, true, true)
+  else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
+  else LAUNCH_SK(5, 512, true, false)
 #undef LAUNCH_SK
   HIP_TRY(hipGetLastError());
   return MI355_OK;

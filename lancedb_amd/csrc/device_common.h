@@ -412,18 +412,27 @@ struct ListEnt {
   uint32_t pos;
 };
 
-template <int R>  // capacity = 64 * R entries
+// QTRACK: every compaction also records the distance of the wave's q-th best row (t_q), the wave's
+// share of a WORKGROUP-wide bound: if each of the NW waves holds q rows at or below its own t_q and
+// NW * q >= kk, then kk rows lie at or below max_w t_q (k_scan_skew publishes it as the shared
+// admission threshold: far tighter than any single wave's kk-th best when the winners are spread
+// over the waves).
+template <int R, bool QTRACK = false>  // capacity = 64 * R entries
 struct WaveList {
   ListEnt* list;  // LDS
   uint32_t cnt;   // wave-uniform
   uint32_t kk;
   float t_run;    // distance of the kk-th best row seen so far (+inf until then)
+  uint32_t q;     // (QTRACK) rank tracked by t_q
+  float t_q;      // (QTRACK) distance of the q-th best row seen so far (+inf until q rows were compacted)
 
-  __device__ __forceinline__ void init(ListEnt* lds, uint32_t kk_) {
+  __device__ __forceinline__ void init(ListEnt* lds, uint32_t kk_, uint32_t q_ = 0) {
     list = lds;
     cnt = 0;
     kk = kk_;
     t_run = __builtin_huge_valf();
+    q = q_;
+    t_q = __builtin_huge_valf();
   }
 
   // keep the kk best entries, sorted by (distance, id); idof(pos) -> row id
@@ -452,8 +461,8 @@ struct WaveList {
       }
     }
     __threadfence_block();
-    float kth = __builtin_huge_valf();
-    bool has_kth = false;
+    float kth = __builtin_huge_valf(), qth = __builtin_huge_valf();
+    bool has_kth = false, has_qth = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (val[r] && rank[r] < kk) list[rank[r]] = mine[r];
@@ -461,11 +470,32 @@ struct WaveList {
         has_kth = true;
         kth = mine[r].d;
       }
+      if (QTRACK && val[r] && rank[r] == q - 1) {
+        has_qth = true;
+        qth = mine[r].d;
+      }
     }
     uint64_t mk = __ballot(has_kth);
     if (mk) t_run = fminf(t_run, readlane_f(kth, __ffsll((unsigned long long)mk) - 1));
+    if (QTRACK) {
+      uint64_t mq = __ballot(has_qth);
+      if (mq) t_q = fminf(t_q, readlane_f(qth, __ffsll((unsigned long long)mq) - 1));
+    }
     cnt = min(cnt, kk);
     __threadfence_block();
+  }
+
+  // After compact() (the list is sorted by (distance, id)): drop every entry above `thr`.  The
+  // kept entries are a prefix of the sorted list, so only the count changes.
+  __device__ __forceinline__ void prune(float thr, int lane) {
+    uint32_t keep = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t slot = (uint32_t)(r * MI355_WAVE + lane);
+      const bool k = slot < cnt && list[slot].d <= thr;
+      keep += (uint32_t)__popcll((unsigned long long)__ballot(k));
+    }
+    cnt = keep;
   }
 
   // Every lane offers at most one row.  `thr` is the caller's current

@@ -363,8 +363,17 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
 // re-scanned per pass against the table built once; pass p keeps the best rows strictly above the
 // last row of pass p-1 in the (distance, rowid) order).  MULTI = false compiles to the single-pass
 // kernel unchanged.
-template <int M, int LR, int NT, bool MULTI>
+// OPT (with MULTI; 128 < kk <= 256): sixteen waves whose lists hold 192 rows — fewer than kk.  The
+// winners of a work item are spread over its 16 units, so with the workgroup-shared threshold
+// (QSHARE below) a wave needs room for about kk / 16 rows plus what arrives between two
+// compactions.  The first pass is OPTIMISTIC: kk_pass = kk, a full list is sorted, cut at the
+// shared threshold (WaveList::prune) and refilled; a wave that still cannot make room (the item's
+// best rows crowd into one unit: adversarial row order) raises `s_ovf`, the pass is discarded and
+// the item is redone in passes of SK_SAFE_PASS rows, which fit any list.
+#define SK_SAFE_PASS 128u
+template <int M, int LR, int NT, bool MULTI, bool OPT = false>
 __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
+  static_assert(!OPT || (MULTI && LR * 64 >= (int)SK_SAFE_PASS), "OPT rides on the pass machinery");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / MI355_WAVE;
   constexpr int P = 128;       // LUT pitch in dwords (sk_pitch_dwords)
@@ -380,7 +389,12 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   float* res = (float*)(smem + SK_TABLE_BYTES);               // [dim]
   ListEnt* lists = (ListEnt*)(smem + SK_TABLE_BYTES + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
   uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);  // [NW]
-  uint32_t* s_thr = s_cnt + NW;                               // [1] block threshold (sort key)
+  uint32_t* s_part = s_cnt + NW;                              // [NW] every wave's q-th best (sort key), QSHARE
+  uint32_t* s_ovf = s_part + NW;                              // [1] OPT: a list overflowed in the optimistic pass
+  uint32_t* s_thr = s_ovf + 1;                                // [1] block threshold (sort key)
+  // long candidate lists (kk > 64): the shared threshold is built from every wave's q-th best,
+  // q = ceil(kk / NW) (WaveList QTRACK); the kk <= 64 kernel keeps the per-wave bound alone
+  constexpr bool QSHARE = LR >= 3;
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
   SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
   PassFloor* s_floor = (PassFloor*)(s_rec + 2);                          // [1] (MULTI)
@@ -459,6 +473,8 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       if (d < ix.dim) res[d] = pre_q[u] - pre_c[u];  // dot: pre_c == 0, q - 0 == q exactly
     }
     if (tid == 0) *s_thr = __hip_atomic_load(a.qthr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
+    if (OPT && tid == 0) *s_ovf = 0u;
     __syncthreads();
     if (!(a.dbg & 1u)) {
       const uint32_t dsub = ix.dsub;
@@ -553,8 +569,10 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
     const uint8_t* pcodes = ix.codes + code_off;
     const uint32_t thr0_key = *s_thr;  // the query's bound when this item started (valid for every pass)
-    for (uint32_t pass_base = 0;; pass_base += SCAN_PASS_ROWS) {
-    const uint32_t kk_pass = MULTI ? min(a.kk - pass_base, SCAN_PASS_ROWS) : a.kk;
+    uint32_t pass_rows = SCAN_PASS_ROWS;  // OPT: kk <= SCAN_PASS_ROWS, one optimistic pass of kk rows
+    bool optimistic = OPT;
+    for (uint32_t pass_base = 0;; pass_base += pass_rows) {
+    const uint32_t kk_pass = MULTI ? min(a.kk - pass_base, pass_rows) : a.kk;
     const bool last_known = !MULTI;  // single pass: the item's tail work overlaps the merge below
     bool fl_on = false;
     float fl_d = 0.f;
@@ -564,8 +582,11 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       fl_d = s_floor->d;
       fl_id = s_floor->id;
     }
-    WaveList<LR> wl;
-    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass);
+    WaveList<LR, QSHARE> wl;
+    const uint32_t q_share = (kk_pass + NW - 1) / NW;
+    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass, q_share);
+    float pub_q = __builtin_huge_valf();
+    bool q_sorted = false;  // the one early sort of the list happened
     float thr = f32_from_sort_key(thr0_key);
     if (thr0_key == 0xFFFFFFFFu) thr = __builtin_huge_valf();
 
@@ -586,10 +607,45 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       ok = ok && d <= thr;
       if (__any(ok)) {
         if (a.filter.mode != MI355_FILTER_NONE && ok) ok = row_permitted(idof(lrow0 + row), a.filter);
+        if constexpr (OPT) {
+          // a list shorter than kk_pass cannot shrink by rank: sort it, cut it at the shared threshold
+          if (optimistic && wl.cnt + (uint32_t)__popcll((unsigned long long)__ballot(ok)) > (uint32_t)(LR * MI355_WAVE)) {
+            wl.compact(lane, idof);
+            thr = fminf(thr, wl.t_run);
+            const uint32_t bk2 = __hip_atomic_load(s_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (bk2 != 0xFFFFFFFFu) thr = fminf(thr, f32_from_sort_key(bk2));
+            wl.prune(thr, lane);
+            ok = ok && d <= thr;
+            if (wl.cnt + (uint32_t)__popcll((unsigned long long)__ballot(ok)) > (uint32_t)(LR * MI355_WAVE)) {
+              if (lane == 0) __hip_atomic_store(s_ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              ok = false;  // the pass is void: the item is redone in safe passes
+            }
+          }
+        }
         wl.append(ok, d, lrow0 + row, thr, lane, idof);
         if (wl.t_run < published) {  // a compaction tightened this wave's kk-th best: share it
           published = wl.t_run;
           if (lane == 0) atomicMin(s_thr, f32_sort_key(published));
+        }
+        if constexpr (QSHARE) {
+          // the first time the wave holds a tile's worth of rows (and at least q), sort them once to
+          // learn its q-th best; later compactions (list overflow) keep tightening it
+          if (!q_sorted && wl.cnt >= q_share && wl.cnt >= MI355_WAVE) {
+            q_sorted = true;
+            wl.compact(lane, idof);
+            thr = fminf(thr, wl.t_run);
+          }
+          if (wl.t_q < pub_q) {
+            // every wave's entry is a bound it holds q rows under, at any time: the maximum over a
+            // (possibly stale) snapshot of all NW entries bounds the workgroup's NW * q >= kk best rows
+            pub_q = wl.t_q;
+            if (lane == 0) __hip_atomic_store(s_part + wid, f32_sort_key(pub_q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t v = lane < NW ? __hip_atomic_load(s_part + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+#pragma unroll
+            for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            if (v != 0xFFFFFFFFu && lane == 0) atomicMin(s_thr, v);
+          }
         }
       }
     };
@@ -717,6 +773,23 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     };
     if (last_known && tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) next_item_fallback();
     __syncthreads();
+    if constexpr (OPT) {
+      if (optimistic) {
+        optimistic = false;
+        if (*s_ovf) {  // (workgroup-uniform after the barrier) redo the item in passes that fit any list
+          __syncthreads();  // every thread has read the flag
+          if (tid == 0) {
+            *s_ovf = 0u;
+            *s_thr = thr0_key;
+          }
+          if (tid < NW) s_part[tid] = 0xFFFFFFFFu;
+          __syncthreads();
+          pass_rows = SK_SAFE_PASS;
+          pass_base = 0u - pass_rows;  // the loop increment brings it back to 0
+          continue;
+        }
+      }
+    }
     // the next item's residual operands travel while this item's lists are merged
     if (last_known && s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     uint32_t total = 0;
@@ -766,6 +839,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     }
     __syncthreads();  // the floor is published; the lists and the block threshold are rebuilt
     if (tid == 0) *s_thr = thr0_key;
+    if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
     __syncthreads();
     }  // passes
     if (MULTI) {  // the tail work of the item, once (it overlaps the merge in the single-pass kernel)

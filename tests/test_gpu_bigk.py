@@ -109,3 +109,48 @@ def test_merge_topk_beyond_one_selection_pass(oracle):
     e_ids, e_dist, e_cnt = oracle.merge_topk(ids, dist, cnt, k)
     assert (g_cnt.numpy().view(np.uint32) == e_cnt).all()
     assert (g_ids.numpy().view(np.uint64) == e_ids).all() and (g_dist.numpy() == e_dist).all()
+
+
+@pytest.mark.parametrize("m,dim", [(32, 128), (96, 192)])
+def test_long_lists_on_sixteen_waves(oracle, m, dim):
+    """128 < k * refine_factor <= 256 on the production scan: sixteen waves whose candidate lists
+    (192 rows) are SHORTER than kk, kept short by the workgroup-shared threshold (k_scan_skew OPT /
+    QSHARE).  Random row order (the optimistic pass succeeds) and the adversarial one: the best rows
+    of a partition all sit in the tiles ONE wave scans, so its list overflows and the work item is
+    redone in passes of 128 rows — same results either way, bit-exact against the oracle."""
+    rng = np.random.default_rng(m)
+    s = train.synthetic_index(50000, dim, 6, m, seed=m + 1, skew=0.3)
+    po = s["part_offsets"].astype(np.int64)
+    q = rng.normal(size=(5, dim)).astype(np.float32)
+    raw = rng.normal(size=(50000, dim)).astype(np.float32)
+
+    def check(codes):
+        g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], codes, s["row_ids"], raw_vectors=raw)
+        o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], codes, s["row_ids"], raw_vectors=raw)
+        for kw in (dict(k=129, nprobe_min=3, nprobe_max=3), dict(k=200, nprobe_min=6, nprobe_max=6),
+                   dict(k=250, nprobe_min=2, nprobe_max=2), dict(k=256, nprobe_min=6, nprobe_max=6),
+                   dict(k=10, nprobe_min=4, nprobe_max=4, refine_factor=25), dict(k=192, nprobe_min=1, nprobe_max=1),
+                   dict(k=240, nprobe_min=2, nprobe_max=6, upper_bound=float(o.search(q, k=300, nprobe_min=6, nprobe_max=6)[1][0, 150]))):
+            _same(g.search(q, **kw), o.search(q, **kw))
+        assert g.stats()["scan_variant"] == _abi.SCAN_SKEW
+
+    check(s["codes"])
+    # adversarial: in every partition, the rows of the tiles that unit 0 scans (tile % 32 in {0, 1}: two
+    # chains per wave) get the codes of the partition's first row with a few bytes varied — hundreds of
+    # near-equal best rows for a query near that row's reconstruction, all in one wave's list
+    codes = s["codes"].copy()
+    for p in range(len(po) - 1):
+        n_p = po[p + 1] - po[p]
+        rows = np.arange(n_p)
+        crowd = rows[((rows // 64) % 32) < 2]
+        base = codes[po[p]].copy()
+        codes[po[p] + crowd] = base
+        codes[po[p] + crowd, rng.integers(0, m, size=len(crowd))] = rng.integers(0, 256, size=len(crowd)).astype(np.uint8)
+    # queries = reconstructions of each partition's first row (so the crowd is the near set)
+    cb = s["codebook"]
+    recon = []
+    for p in range(min(5, len(po) - 1)):
+        c0 = codes[po[p]]
+        recon.append(s["centroids"][p] + np.concatenate([cb[j, c0[j]] for j in range(m)]))
+    q[:len(recon)] = np.asarray(recon, dtype=np.float32)
+    check(codes)

@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--flat-metric", default="l2", choices=["l2", "cosine", "dot"])
     ap.add_argument("--flat-gemm", type=int, default=0, help="mi355_flat_configure gemm_variant (0 = the library's choice)")
     ap.add_argument("--flat-grid", type=int, default=0, help="mi355_flat_configure grid_workgroups")
+    ap.add_argument("--force-sharded-path", action="store_true",
+                    help="dev: run the N > 1 code path (process group, RCCL communicator behind the C ABI, "
+                         "mi355_search_sharded, teardown) in a world of one rank: what a 1-GPU box can verify")
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--slice-rows", type=int, default=0)
     return ap.parse_args()
@@ -109,9 +112,11 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or a.force_sharded_path
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n, dim, nlist, m = a.n_rows, a.dim, a.nlist, a.m
     dsub = dim // m
@@ -158,7 +163,7 @@ def main():
     rows_local, parts_local = ix.info()
     assert rows_local == rows_mine
 
-    want_cpu = rank == 0 and world == 1 and a.cpu_seconds > 0
+    want_cpu = rank == 0 and not sharded and a.cpu_seconds > 0
     h_codes = h_rowids = None
     if want_cpu:
         h_codes = codes.cpu().numpy()
@@ -182,7 +187,7 @@ def main():
     ix.set_stream(stream)  # engine kernels, RCCL and torch share one ordered stream
     ix.configure(scan_variant=a.scan_variant, slice_rows=a.slice_rows, profile=0)
     comm = searcher = None
-    if world > 1:
+    if sharded:
         # the exchange is RCCL behind the C ABI (mi355_comm_* / mi355_search_sharded: one packed
         # all-gather of the per-shard candidate records on the search stream + a k-way merge on every
         # rank); torch.distributed only carries the 128-byte communicator id to the other ranks
@@ -198,7 +203,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -212,7 +217,7 @@ def main():
         last = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -223,12 +228,12 @@ def main():
     bytes_per_launch = st["code_bytes_scanned"] / launches
     us_per_launch = st["us_scan"] / launches
     stat = torch.tensor([st["code_bytes_scanned"], st["us_scan"], float(launches)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(stat, op=dist.ReduceOp.SUM)  # whole-job bytes / summed kernel time
     achieved = (float(stat[0]) / float(stat[2])) / (float(stat[1]) / float(stat[2]) * 1e-6) / 1e9 if float(stat[1]) > 0 else 0.0
     qps = a.batch * a.steps / elapsed
     workload = f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{a.nprobe}_k{a.k}_l2"
-    traffic = traffic_from_profiles(workload, a.batch) if world == 1 else None
+    traffic = traffic_from_profiles(workload, a.batch) if not sharded else None
 
     result = {
         "metric": "queries/sec @ recall@10, 100M×768 IVF-PQ nprobe=64 k=10",
@@ -251,28 +256,33 @@ def main():
             "index_open_s": round(t_open, 2),
         },
         "roofline": scan_roofline(achieved, bytes_per_launch, us_per_launch, int(float(stat[2])), traffic,
-                                  traffic_source_from_profiles(workload, a.batch) if world == 1 else None,
+                                  traffic_source_from_profiles(workload, a.batch) if not sharded else None,
                                   torch.cuda.get_device_properties(dev).multi_processor_count,
                                   {s: st["us_" + s] / a.steps for s in ("coarse", "select", "scan", "merge")}),
     }
-    if world > 1:
+    if sharded:
         cs = comm.stats()  # identical on every rank: the per-rank scanned rows travel in the gathered slabs
         result["multi_gpu"] = {
             "exchange": "RCCL behind the C ABI (mi355_search_sharded): one packed all-gather per step + k-way merge",
             "rccl_ranks": cs["world"], "gathers_per_step": cs["n_gathers"], "bytes_gathered_per_step": cs["bytes_gathered"],
-            "rows_scanned_per_rank_last_step": cs["rows_scanned"], "load_imbalance_max_over_mean": cs["imbalance"],
+            "rows_scanned_per_rank_timed_steps": cs["rows_scanned"], "load_imbalance_max_over_mean": cs["imbalance"],
             "rows_on_rank": [int(lens[owner == r].sum()) for r in range(world)],
         }
+        if world == 1:  # --force-sharded-path: the exchange of a world of one must reproduce the plain search
+            plain = ix.search(qpool[(a.steps - 1) % P], params)
+            torch.cuda.synchronize()
+            result["multi_gpu"]["sharded_equals_unsharded"] = bool(
+                (plain.rowids == last[0]).all().item() and (plain.distances == last[1]).all().item())
 
-    if rank == 0 and world == 1 and a.recall_rows > 0:
+    if rank == 0 and not sharded and a.recall_rows > 0:
         result["recall_at_10"] = recall_at_10(a, np, dim, m)
-    if rank == 0 and world == 1 and a.secondary:
+    if rank == 0 and not sharded and a.secondary:
         result["secondary"] = {"latency_c3": latency_and_concurrency(a, np, ix, qpool)}
         result["secondary"].update(refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev))
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(a, np, h_centroids, h_codebook, part_offsets, h_codes, h_rowids,
                                               qpool[(a.steps - 1) % P], last, params)
-    if rank == 0 and world == 1 and a.secondary:
+    if rank == 0 and not sharded and a.secondary:
         # flat C2 needs 15 GB for its column: drop the 100 M index first
         ix.close()
         del ix
@@ -281,7 +291,7 @@ def main():
             result["secondary"]["flat_c2_" + metric] = flat_c2(a, metric, cpu_queries=32 if metric == "l2" else 16)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if sharded:
         # tear down in dependency order: the communicator before the index whose stream it used
         torch.cuda.synchronize()
         dist.barrier()

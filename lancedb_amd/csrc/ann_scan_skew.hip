@@ -22,12 +22,13 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_
                                 (int)lds));                                                     \
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(NT), lds, st, sa);                            \
   }
-  // kk <= 128: sixteen waves with lists of 128 / 192 rows; 128 < kk <= 256: sixteen waves with
-  // 192-row lists, optimistic single pass (k_scan_skew OPT) when that fits the LDS, else eight waves
-  // with 320-row lists; beyond: eight waves, passes of SCAN_PASS_ROWS rows per work item
+  // kk <= 128: sixteen waves with lists of 128 / 192 rows; beyond: sixteen waves with 192-row
+  // lists and optimistic passes of SCAN_PASS_ROWS rows (k_scan_skew OPT) when that fits the LDS,
+  // else eight waves with 320-row lists
+  const bool opt_fits = lds_of(16, 3) <= 160u * 1024;
   if (kk <= 64) LAUNCH_SK(2, 1024, false, false)
   else if (kk <= 128) LAUNCH_SK(3, 1024, false, false)
-  else if (kk <= SCAN_PASS_ROWS && lds_of(16, 3) <= 160u * 1024) LAUNCH_SK(3, 1024, true, true)
+  else if (opt_fits) LAUNCH_SK(3, 1024, true, true)
   else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
   else LAUNCH_SK(5, 512, true, false)
 #undef LAUNCH_SK

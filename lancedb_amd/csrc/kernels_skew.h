@@ -363,13 +363,14 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
 // re-scanned per pass against the table built once; pass p keeps the best rows strictly above the
 // last row of pass p-1 in the (distance, rowid) order).  MULTI = false compiles to the single-pass
 // kernel unchanged.
-// OPT (with MULTI; 128 < kk <= 256): sixteen waves whose lists hold 192 rows — fewer than kk.  The
-// winners of a work item are spread over its 16 units, so with the workgroup-shared threshold
-// (QSHARE below) a wave needs room for about kk / 16 rows plus what arrives between two
-// compactions.  The first pass is OPTIMISTIC: kk_pass = kk, a full list is sorted, cut at the
-// shared threshold (WaveList::prune) and refilled; a wave that still cannot make room (the item's
-// best rows crowd into one unit: adversarial row order) raises `s_ovf`, the pass is discarded and
-// the item is redone in passes of SK_SAFE_PASS rows, which fit any list.
+// OPT (with MULTI; kk > 128): sixteen waves whose lists hold 192 rows — fewer than the
+// SCAN_PASS_ROWS a pass selects.  The winners of a work item are spread over its 16 units, so with
+// the workgroup-shared threshold (QSHARE below) a wave needs room for about kk_pass / 16 rows plus
+// what arrives between two compactions.  Passes are OPTIMISTIC: kk_pass = min(rows left,
+// SCAN_PASS_ROWS), a full list is sorted, cut at the shared threshold (WaveList::prune) and
+// refilled; a wave that still cannot make room (the item's best rows crowd into one unit:
+// adversarial row order, or hundreds of equal distances) raises `s_ovf`, that pass is discarded
+// and it and all later passes of the item select SK_SAFE_PASS rows each, which fit any list.
 #define SK_SAFE_PASS 128u
 template <int M, int LR, int NT, bool MULTI, bool OPT = false>
 __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
     const uint8_t* pcodes = ix.codes + code_off;
     const uint32_t thr0_key = *s_thr;  // the query's bound when this item started (valid for every pass)
-    uint32_t pass_rows = SCAN_PASS_ROWS;  // OPT: kk <= SCAN_PASS_ROWS, one optimistic pass of kk rows
+    uint32_t pass_rows = SCAN_PASS_ROWS;  // (OPT: optimistic passes of SCAN_PASS_ROWS rows, SK_SAFE_PASS after an overflow)
     bool optimistic = OPT;
     for (uint32_t pass_base = 0;; pass_base += pass_rows) {
     const uint32_t kk_pass = MULTI ? min(a.kk - pass_base, pass_rows) : a.kk;
@@ -774,20 +775,20 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     if (last_known && tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) next_item_fallback();
     __syncthreads();
     if constexpr (OPT) {
-      if (optimistic) {
+      if (optimistic && *s_ovf) {  // (workgroup-uniform after the barrier)
+        // this pass is void: redo it, and run whatever follows, in passes that fit any list; the floor
+        // it started from is untouched (s_floor is only written by a pass's merge)
         optimistic = false;
-        if (*s_ovf) {  // (workgroup-uniform after the barrier) redo the item in passes that fit any list
-          __syncthreads();  // every thread has read the flag
-          if (tid == 0) {
-            *s_ovf = 0u;
-            *s_thr = thr0_key;
-          }
-          if (tid < NW) s_part[tid] = 0xFFFFFFFFu;
-          __syncthreads();
-          pass_rows = SK_SAFE_PASS;
-          pass_base = 0u - pass_rows;  // the loop increment brings it back to 0
-          continue;
+        __syncthreads();  // every thread has read the flag
+        if (tid == 0) {
+          *s_ovf = 0u;
+          *s_thr = thr0_key;
         }
+        if (tid < NW) s_part[tid] = 0xFFFFFFFFu;
+        __syncthreads();
+        pass_rows = SK_SAFE_PASS;
+        pass_base -= pass_rows;  // the loop increment brings it back to this pass's base
+        continue;
       }
     }
     // the next item's residual operands travel while this item's lists are merged

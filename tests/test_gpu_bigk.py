@@ -113,9 +113,9 @@ def test_merge_topk_beyond_one_selection_pass(oracle):
 
 @pytest.mark.parametrize("m,dim", [(32, 128), (96, 192)])
 def test_long_lists_on_sixteen_waves(oracle, m, dim):
-    """128 < k * refine_factor <= 256 on the production scan: sixteen waves whose candidate lists
-    (192 rows) are SHORTER than kk, kept short by the workgroup-shared threshold (k_scan_skew OPT /
-    QSHARE).  Random row order (the optimistic pass succeeds) and the adversarial one: the best rows
+    """k * refine_factor > 128 on the production scan: sixteen waves whose candidate lists (192 rows)
+    are SHORTER than the 256 rows a pass selects, kept short by the workgroup-shared threshold
+    (k_scan_skew OPT / QSHARE).  Random row order (the optimistic pass succeeds) and the adversarial one: the best rows
     of a partition all sit in the tiles ONE wave scans, so its list overflows and the work item is
     redone in passes of 128 rows — same results either way, bit-exact against the oracle."""
     rng = np.random.default_rng(m)
@@ -130,6 +130,7 @@ def test_long_lists_on_sixteen_waves(oracle, m, dim):
         for kw in (dict(k=129, nprobe_min=3, nprobe_max=3), dict(k=200, nprobe_min=6, nprobe_max=6),
                    dict(k=250, nprobe_min=2, nprobe_max=2), dict(k=256, nprobe_min=6, nprobe_max=6),
                    dict(k=10, nprobe_min=4, nprobe_max=4, refine_factor=25), dict(k=192, nprobe_min=1, nprobe_max=1),
+                   dict(k=600, nprobe_min=1, nprobe_max=1), dict(k=10, nprobe_min=3, nprobe_max=3, refine_factor=50),
                    dict(k=240, nprobe_min=2, nprobe_max=6, upper_bound=float(o.search(q, k=300, nprobe_min=6, nprobe_max=6)[1][0, 150]))):
             _same(g.search(q, **kw), o.search(q, **kw))
         assert g.stats()["scan_variant"] == _abi.SCAN_SKEW

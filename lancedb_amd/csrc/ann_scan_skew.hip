@@ -27,7 +27,8 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_
   // else eight waves with 320-row lists
   const bool opt_fits = lds_of(16, 3) <= 160u * 1024;
   if (kk <= 64) LAUNCH_SK(2, 1024, false, false)
-  else if (kk <= 128) LAUNCH_SK(3, 1024, false, false)
+  else if (kk <= 128 && opt_fits) LAUNCH_SK(3, 1024, false, false)
+  else if (kk <= 128) LAUNCH_SK(3, 512, false, false)  // dim close to 2048: the lists of 16 waves do not fit
   else if (opt_fits) LAUNCH_SK(3, 1024, true, true)
   else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
   else LAUNCH_SK(5, 512, true, false)

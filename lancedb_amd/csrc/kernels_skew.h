@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / MI355_WAVE;
   constexpr int P = 128;       // LUT pitch in dwords (sk_pitch_dwords)
-  constexpr int PB = P * 4;
+  [[maybe_unused]] constexpr int PB = P * 4;  // (SK_ADDR_BFE address form)
   constexpr int CPT = M / 16;  // 1-KiB chunks per tile
   static_assert(M + 32 <= P, "table columns exceed the pitch");
   const IndexView& ix = a.ix;

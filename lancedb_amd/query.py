@@ -87,6 +87,10 @@ class VectorQuery:
 
     # ---- QueryBase -----------------------------------------------------
     def limit(self, limit):
+        """A vector query needs a positive limit (python/python/lancedb/query.py:1176-1178; the Rust
+        setter takes a usize, rust/lancedb/src/query.rs:818-907)."""
+        if limit is None or int(limit) <= 0:
+            raise InvalidInput(1, "Limit is required for ANN/KNN queries")
         q = self._clone()
         q.request.limit = int(limit)
         return q
@@ -263,8 +267,12 @@ class VectorTable:
         q = VectorQuery(self)
         a = np.asarray(vector)
         vecs = [a] if a.ndim == 1 else list(a)  # a list of vectors = multi-vector query
+        if len(vecs) == 0:  # ensure_vector_query, python/python/lancedb/query.py:332-350
+            raise InvalidInput(1, "Vector query must be a non-empty list")
         for v in vecs:
             v = _to_query_vector(v)
+            if v.shape[0] == 0:
+                raise InvalidInput(1, "Vector query must be a non-empty list")
             if v.shape[0] != self.dim:
                 raise InvalidInput(1, f"query vector has dimension {v.shape[0]} but the column has {self.dim}")
             q.request.query_vector.append(v)

@@ -169,3 +169,30 @@ def test_default_vector_column_and_supported_types():
     assert supported_vector_data_type(vec(4)) and supported_vector_data_type(vec(4, pa.float16()))
     assert supported_vector_data_type(vec(4, pa.uint8())) and supported_vector_data_type(pa.list_(vec(4)))
     assert not supported_vector_data_type(vec(4, pa.int32())) and not supported_vector_data_type(pa.utf8())
+
+
+def test_reference_python_query_tests_on_the_mirror():
+    """python/python/tests/test_query.py: test_offset (:251-256), test_vector_query_with_no_limit
+    (:853-862), test_invalid_nprobes_sync / test_nprobes_works_sync / test_nprobes_min_max_works_sync
+    (:917-940), test_search_empty_table (:1990-2004), test_ensure_vector_query_*empty_list (:2007-2016)."""
+    t = VectorTable(index=_ArrayIndex(2))  # the reference fixture has two rows
+    assert len(t.vector_search([0, 0, 0, 0]).execute()["_rowid"]) == 2
+    assert len(t.vector_search([0, 0, 0, 0]).offset(1).execute()["_rowid"]) == 1
+    for bad in (0, None, -3):
+        with pytest.raises(ValueError, match="Limit is required for ANN/KNN queries"):
+            t.vector_search([0, 0, 0, 0]).limit(bad)
+    with pytest.raises(ValueError, match="minimum_nprobes must be greater than 0"):
+        t.vector_search([0, 0, 0, 0]).minimum_nprobes(0)
+    with pytest.raises(ValueError, match="maximum_nprobes must be greater than or equal to minimum_nprobes"):
+        t.vector_search([0, 0, 0, 0]).maximum_nprobes(5)
+    with pytest.raises(ValueError, match="minimum_nprobes must be less than or equal to maximum_nprobes"):
+        t.vector_search([0, 0, 0, 0]).minimum_nprobes(100)
+    t.vector_search([0, 0, 0, 0]).nprobes(30).execute()
+    t.vector_search([0, 0, 0, 0]).minimum_nprobes(2).maximum_nprobes(4).execute()
+    # an empty table answers with no rows
+    empty = VectorTable(index=_ArrayIndex(0))
+    r = empty.vector_search([1.0, 2.0, 0, 0]).limit(5).execute()
+    assert len(r["_rowid"]) == 0 and len(r["_distance"]) == 0
+    for bad in ([], [[]]):
+        with pytest.raises(ValueError, match="non-empty"):
+            t.vector_search(bad)

@@ -360,7 +360,7 @@ def create_plan(table, req: VectorQueryRequest, options: QueryExecutionOptions) 
     metric = _abi.METRIC_DEFAULT if req.distance_type is None else _abi.METRIC_NAMES[req.distance_type]
     filtered = req.allow_rowids is not None or req.block_rowids is not None
     pre = filtered and req.prefilter
-    timeout_ms = 0 if options.timeout is None else max(1, int(round(options.timeout * 1000)))
+    timeout_ms = 0 if options.timeout is None else max(1, int(round(_seconds(options.timeout) * 1000)))
     params = _abi.make_params(
         k=k, nprobe_min=req.minimum_nprobes, nprobe_max=req.maximum_nprobes,
         refine_factor=req.refine_factor or 0, metric=metric,
@@ -424,6 +424,12 @@ def execute_generic_query(table, req: VectorQueryRequest, options: QueryExecutio
     return _batches(out, options, t0)
 
 
+def _seconds(timeout):
+    """QueryExecutionOptions.timeout: seconds, or a datetime.timedelta as the reference's Python API
+    passes it (python/python/tests/test_query.py:1846-1873; a zero timeout fails every query)."""
+    return timeout.total_seconds() if hasattr(timeout, "total_seconds") else float(timeout)
+
+
 def _batches(cols, options: QueryExecutionOptions, t0):
     """MaxBatchLengthStream + TimeoutStream (utils/mod.rs:328-471): slices of at most
     max_batch_length rows (0 = one batch); the deadline is checked as each batch is handed out."""
@@ -431,8 +437,8 @@ def _batches(cols, options: QueryExecutionOptions, t0):
     step = options.max_batch_length or max(n, 1)
     off = 0
     while True:
-        if options.timeout is not None and time.monotonic() - t0 > options.timeout:
-            raise QueryTimeout(3, f"Query timeout: {options.timeout} s")
+        if options.timeout is not None and time.monotonic() - t0 > _seconds(options.timeout):
+            raise QueryTimeout(3, f"Query timeout: {_seconds(options.timeout)} s")
         yield {c: v[off:off + step] for c, v in cols.items()}
         off += step
         if off >= n:

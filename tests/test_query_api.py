@@ -196,3 +196,13 @@ def test_reference_python_query_tests_on_the_mirror():
     for bad in ([], [[]]):
         with pytest.raises(ValueError, match="non-empty"):
             t.vector_search(bad)
+    # test_query_timeout (:1846-1873): a zero timeout fails the query with "Query timeout"
+    from datetime import timedelta
+    from lancedb_amd.query import QueryExecutionOptions
+    with pytest.raises(Exception, match="Query timeout"):
+        t.vector_search([0.0, 0.0, 0, 0]).execute(QueryExecutionOptions(timeout=timedelta(0)))
+    assert len(t.vector_search([0.0, 0.0, 0, 0]).execute(QueryExecutionOptions(timeout=timedelta(seconds=30)))["_rowid"]) == 2
+    # test_query_builder_batches (:865-897): to_batches(1) -> two batches of one row, to_batches(2) -> one of two
+    q2 = t.vector_search([0, 0, 0, 0]).limit(2)
+    assert [len(b["_rowid"]) for b in q2.execute_with_options(QueryExecutionOptions(max_batch_length=1))] == [1, 1]
+    assert [len(b["_rowid"]) for b in q2.execute_with_options(QueryExecutionOptions(max_batch_length=2))] == [2]

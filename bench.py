@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--flat-metric", default="l2", choices=["l2", "cosine", "dot"])
     ap.add_argument("--flat-gemm", type=int, default=0, help="mi355_flat_configure gemm_variant (0 = the library's choice)")
     ap.add_argument("--flat-grid", type=int, default=0, help="mi355_flat_configure grid_workgroups")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: keep the exchange on the search stream (MI355_SHARD_NO_OVERLAP) instead of running it "
+                         "on the communicator's stream under the next step's scan")
     ap.add_argument("--force-sharded-path", action="store_true",
                     help="dev: run the N > 1 code path (process group, RCCL communicator behind the C ABI, "
                          "mi355_search_sharded, teardown) in a world of one rank: what a 1-GPU box can verify")
@@ -195,7 +198,7 @@ def main():
         uid = [unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = Comm(uid[0], rank, world, device=local_rank)
-        searcher = ShardedSearcher(ix, comm)
+        searcher = ShardedSearcher(ix, comm, overlap=not a.no_overlap)
 
     def step(i):
         r = searcher.search(qpool[i % P], params, out=out) if searcher else ix.search(qpool[i % P], params, out=out)
@@ -262,11 +265,20 @@ def main():
     }
     if sharded:
         cs = comm.stats()  # identical on every rank: the per-rank scanned rows travel in the gathered slabs
+        # every rank's own stage times (HIP events on its search stream) and exchange time, so that a
+        # scaling run explains itself: step = max over ranks of (coarse + select + scan + merge) [+ exchange
+        # when it is not overlapped with the next step's scan]
+        mine_us = {s2: st["us_" + s2] / a.steps for s2 in ("coarse", "select", "scan", "merge")}
+        mine_us["exchange_last_step"] = cs["us_exchange"]
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_us)
         result["multi_gpu"] = {
             "exchange": "RCCL behind the C ABI (mi355_search_sharded): one packed all-gather per step + k-way merge",
+            "exchange_overlapped_with_next_scan": cs["overlapped"],
             "rccl_ranks": cs["world"], "gathers_per_step": cs["n_gathers"], "bytes_gathered_per_step": cs["bytes_gathered"],
             "rows_scanned_per_rank_timed_steps": cs["rows_scanned"], "load_imbalance_max_over_mean": cs["imbalance"],
             "rows_on_rank": [int(lens[owner == r].sum()) for r in range(world)],
+            "stage_us_per_step_by_rank": per_rank,
         }
         if world == 1:  # --force-sharded-path: the exchange of a world of one must reproduce the plain search
             plain = ix.search(qpool[(a.steps - 1) % P], params)
@@ -352,7 +364,7 @@ def latency_and_concurrency(a, np, ix, qpool):
     st = ix.stats()
     out["single_query_stage_us"] = {s2: st["us_" + s2] for s2 in ("coarse", "select", "scan", "merge")}
     for mode, coalesce in (("coalesced", True), ("serialised", False)):
-        ix.configure(profile=0, graph=True, coalesce=coalesce)
+        ix.configure(profile=0, graph=False, coalesce=coalesce)
         n_threads, per = 64, 24
         barrier = threading.Barrier(n_threads + 1)
 
@@ -367,7 +379,7 @@ def latency_and_concurrency(a, np, ix, qpool):
         t0 = time.perf_counter()
         [t.join() for t in th]
         out[f"qps_64_threads_{mode}"] = n_threads * per / (time.perf_counter() - t0)
-    ix.configure(profile=0)
+    ix.configure(profile=0, graph=False, coalesce=True)  # the defaults of a freshly opened handle
     return out
 
 

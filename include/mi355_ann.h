@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MI355_ANN_ABI_VERSION 3u
+#define MI355_ANN_ABI_VERSION 4u
 
 /* ---- status codes (rust/lancedb/src/error.rs:55-145) -------------------- */
 enum {
@@ -274,8 +274,9 @@ int32_t mi355_index_sync(mi355_index *index);
    until the next configure().  Times come from hipEvents recorded on the search
    stream with no host synchronisation; they are read back by mi355_last_stats.
    Higher bits: MI355_CFG_GRAPH / MI355_CFG_COALESCE (latency / concurrency modes,
-   host-I/O calls only; both are ON after mi355_index_open, a configure() call sets
-   them as given). */
+   host-I/O calls only; after mi355_index_open coalescing is ON and graph replay is OFF —
+   replay measured slower than eager launches; a configure() call sets
+   both as given).  A configure() call also drops the handle's captured graphs. */
 int32_t mi355_index_configure(mi355_index *index, uint32_t scan_variant,
                               uint32_t slice_rows, uint32_t profile);
 /* Attach (or replace) the raw vector column of an open handle WITHOUT copying it: a DEVICE array
@@ -496,15 +497,32 @@ typedef struct mi355_comm mi355_comm;
 #define MI355_COMM_ID_BYTES 128
 /* rank 0: a fresh id (ncclGetUniqueId) */
 int32_t mi355_comm_unique_id(void *out_id /*[MI355_COMM_ID_BYTES]*/);
-/* every rank, collectively (ncclCommInitRank on `device`); world = 1 needs no peers */
+/* every rank, collectively (ncclCommInitRank on `device`); world = 1 needs no peers.
+   librccl is loaded (dlopen) by the first mi355_comm_unique_id / mi355_comm_create call: a host
+   that never shards needs no RCCL installed. */
 int32_t mi355_comm_create(const void *id, uint32_t rank, uint32_t world, int32_t device,
                           mi355_comm **out);
+/* Loopback transport: `world` communicators (out[0 .. world)) whose ranks all live in THIS
+   process on ONE device.  Rank r's collective calls must come from its own thread with shard
+   handle r of `world` — the gather is a host rendezvous plus device copies between the ranks'
+   slabs, stream-ordered by events; everything above the gather (slab layout, merge with owners,
+   owner-side refine, the collective second pass, the sharded coarse stage) is the code the RCCL
+   transport runs.  Purpose: execute and time the world > 1 path on a single GPU.  A rank that
+   fails inside a collective aborts the group (its peers return MI355_ERR_RUNTIME instead of
+   waiting); each communicator is released with mi355_comm_destroy. */
+int32_t mi355_comm_create_loopback(uint32_t world, int32_t device, mi355_comm **out /*[world]*/);
 int32_t mi355_comm_destroy(mi355_comm *comm);
 
 enum {
   /* score only this rank's slice of the centroids and select the probe list after an
      all-gather of per-rank (partition, distance) pairs (C4: nlist = 65536) */
-  MI355_SHARD_COARSE = 1u
+  MI355_SHARD_COARSE = 1u,
+  /* keep the exchange on the handle's stream.  By default a device-I/O call without a timeout
+     and without maximum_nprobes expansion queues its exchange (gather, merge, owner-side refine,
+     second gather, final merge) on the communicator's own stream, so the NEXT call's scan
+     overlaps it; its outputs are complete after mi355_index_sync, and
+     every other entry point of the handle joins the exchange first. */
+  MI355_SHARD_NO_OVERLAP = 2u
 };
 
 /* per-rank load of the last mi355_search_sharded call, identical on every rank */
@@ -518,6 +536,8 @@ typedef struct mi355_comm_stats {
   uint64_t rows_scanned[MI355_MAX_RANKS]; /* ADC rows per rank (sum over its work items) */
   float imbalance;                      /* max / mean of rows_scanned */
   uint32_t reserved;
+  float us_exchange;                    /* device time of the last call's exchange: first gather .. final merge */
+  uint32_t overlapped;                  /* 1: that exchange ran on the communicator's stream (MI355_SHARD_NO_OVERLAP unset) */
 } mi355_comm_stats;
 int32_t mi355_comm_last_stats(mi355_comm *comm, mi355_comm_stats *out);
 
@@ -529,9 +549,13 @@ int32_t mi355_comm_last_stats(mi355_comm *comm, mi355_comm_stats *out);
  * candidates whose raw vectors it owns and a second all-gather + merge keeps k:
  * rank-sharded raw vectors, C5) and maximum_nprobes (the expansion decision is taken
  * on the merged counts, so all ranks take it together).
- * One packed all-gather per exchange ([B, kk] x 16-B candidate records + [B] counts)
- * on the handle's stream, then k_merge on every rank.  Device-I/O calls return
- * without waiting; queries / outputs live where params->io_mem says.
+ * One packed all-gather per exchange ([B, kk] x 16-B candidate records + [B] counts),
+ * then k_merge on every rank.  Device-I/O calls return without waiting and never
+ * synchronise with the host — the short queries of maximum_nprobes are picked on the
+ * device; queries / outputs live where params->io_mem says and must stay untouched until
+ * mi355_index_sync (see MI355_SHARD_NO_OVERLAP for the stream the exchange runs on).
+ * With a timeout the status is the OR of every rank's device-side deadline flag (it
+ * travels in the slab trailer), so every rank returns the same status.
  */
 int32_t mi355_search_sharded(mi355_index *index, mi355_comm *comm, const float *queries,
                              uint32_t n_queries, const mi355_search_params *params,

@@ -6,7 +6,7 @@ exactly; `struct_size` guards against drift at run time.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 ERR_INVALID_INPUT = 1
@@ -60,6 +60,7 @@ FLAT_CHECKSUM = 1
 FLAT_PROFILE = 2
 
 SHARD_COARSE = 1
+SHARD_NO_OVERLAP = 2
 COMM_ID_BYTES = 128
 MAX_RANKS = 64
 
@@ -216,6 +217,8 @@ class CommStats(C.Structure):
         ("rows_scanned", C.c_uint64 * MAX_RANKS),
         ("imbalance", C.c_float),
         ("reserved", C.c_uint32),
+        ("us_exchange", C.c_float),
+        ("overlapped", C.c_uint32),
     ]
 
 
@@ -248,6 +251,7 @@ EXPORTED_SYMBOLS = (
     "mi355_flat_last_stats",
     "mi355_comm_unique_id",
     "mi355_comm_create",
+    "mi355_comm_create_loopback",
     "mi355_comm_destroy",
     "mi355_comm_last_stats",
     "mi355_search_sharded",

@@ -24,8 +24,25 @@ _HEADER = os.path.join(ROOT, "include", "mi355_ann.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
-# the multi-GPU exchange (mi355_comm_*, mi355_search_sharded) is RCCL behind the C ABI
-LINK_FLAGS = ["-shared", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def _hipcc():
+    hipcc = os.environ.get("HIPCC") or os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    return hipcc if os.path.exists(hipcc) else "hipcc"
+
+
+def _link_flags():
+    """The library links the HIP runtime only (hipcc adds it); RCCL — the multi-GPU exchange behind
+    mi355_comm_* — is dlopen'ed by the first communicator call.  The rpath is the lib directory of the
+    ROCm installation the compiler belongs to, not a hard-coded one."""
+    import shutil
+    exe = shutil.which(_hipcc()) or _hipcc()
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(exe))), "lib")
+    flags = ["-shared", "-ldl"]
+    if os.path.isdir(rocm_lib):
+        flags.append("-Wl,-rpath," + rocm_lib)
+    return flags
+
 
 _lib = None
 
@@ -49,11 +66,6 @@ class NotSupported(EngineError):
 
 class QueryTimeout(EngineError, TimeoutError):
     pass
-
-
-def _hipcc():
-    hipcc = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
-    return hipcc if os.path.exists(hipcc) else "hipcc"
 
 
 def _newer(path, deps):
@@ -96,7 +108,7 @@ def build(force=False, verbose=False, extra_flags=(), lib_path=None, obj_dir=Non
         raise RuntimeError("hipcc failed building libmi355_ann.so:\n" +
                            "\n".join(f"--- {u}\n{out[-4000:]}" for u, out in failed))
     objs = [os.path.join(obj_dir, u[:-4] + ".o") for u in _UNITS]
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC"] + objs + LINK_FLAGS + ["-o", lib_path]
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC"] + objs + _link_flags() + ["-o", lib_path]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout)

@@ -153,7 +153,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->cbT,       &ix->order,  &ix->xcd_first, &ix->p_cnt,  &ix->p_off,
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
-                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill};
+                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -161,6 +161,7 @@ static int32_t index_free(mi355_index* ix) {
   for (auto& kv : ix->graphs)
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   if (ix->raw_mapped_host) hostmap_release(ix->raw_mapped_host);
+  if (ix->xdone) (void)hipEventDestroy(ix->xdone);
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
   delete ix;
   return MI355_OK;
@@ -460,6 +461,7 @@ extern "C" int32_t mi355_index_close(mi355_index* index) { return index_free(ind
 extern "C" int32_t mi355_index_set_stream(mi355_index* ix, void* hip_stream) {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   std::lock_guard<std::mutex> lk(ix->mu);
+  ST_TRY(join_exchange(ix));
   ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
   return MI355_OK;
 }
@@ -468,6 +470,7 @@ extern "C" int32_t mi355_index_sync(mi355_index* ix) {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
+  if (ix->xdone) HIP_TRY(hipEventSynchronize(ix->xdone));  // an overlapped sharded search finishes on the communicator's stream
   // device-I/O calls cannot return their timeout: it is reported here (and in mi355_last_stats)
   uint32_t timed_out = 0;
   HIP_TRY(hipMemcpy(&timed_out, &ix->w_ctl.as<DevCtl>()->timed_out, 4, hipMemcpyDeviceToHost));
@@ -491,7 +494,9 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   ix->profile = profile & MI355_PROFILE_MASK;
   ix->use_graph = (profile & MI355_CFG_GRAPH) != 0;
   ix->coalesce = (profile & MI355_CFG_COALESCE) != 0;
+  ++ix->ws_gen;  // captured graphs bake in the slicing
   HIP_TRY(hipSetDevice(ix->device));
+  ST_TRY(join_exchange(ix));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ST_TRY(drain_events(ix, true));
   reset_stats(ix);
@@ -504,6 +509,7 @@ extern "C" int32_t mi355_index_attach_raw(mi355_index* ix, const void* raw_vecto
   if (raw_dtype > MI355_DTYPE_F16) return fail(MI355_ERR_INVALID_INPUT, "bad raw_dtype enum");
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
+  ST_TRY(join_exchange(ix));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->raw_attached = raw_vectors;
   ix->raw_attached_dtype = raw_dtype;
@@ -515,6 +521,7 @@ extern "C" int32_t mi355_index_detach_raw(mi355_index* ix) {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
+  ST_TRY(join_exchange(ix));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->raw_attached = nullptr;
   ++ix->ws_gen;
@@ -565,6 +572,7 @@ extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) {
     return fail(MI355_ERR_INVALID_INPUT, "mi355_stats.struct_size mismatch");
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
+  ST_TRY(join_exchange(ix));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ST_TRY(drain_events(ix, false));
   DevCtl h_ctl;
@@ -574,6 +582,9 @@ extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) {
   ix->stats.timed_out = h_ctl.timed_out;
   ix->stats.bad_probes = h_ctl.bad_probes;
   *out = ix->stats;
+  // queries re-searched over maximum_nprobes partitions were counted on the device
+  out->n_queries += h_ctl.short_queries;
+  out->partitions_probed += (uint64_t)h_ctl.short_queries * ix->second_np;
   out->struct_size = sizeof(mi355_stats);
   return MI355_OK;
 }
@@ -615,7 +626,7 @@ int32_t make_row_filter(const mi355_search_params* p, DevBuf& stage, hipStream_t
 // given) into `out` [nq, kk]; the top-k over them is a k_merge_cands launch by the caller
 int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,
                       const uint32_t* in_cnt, const uint32_t* owner, uint32_t my_rank, uint32_t kk,
-                      const RangeFilter& range, Cand* out, hipStream_t st) {
+                      const RangeFilter& range, Cand* out, hipStream_t st, ActiveMask act) {
   RefineArgs ra;
   ra.ix = view;
   ra.q = q;
@@ -627,6 +638,8 @@ int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, ui
   ra.range = range;
   ra.out = out;
   ra.ctl = ix->w_ctl.as<DevCtl>();
+  ra.n_rows = (uint32_t)ix->n_local;
+  ra.act = act;
   const size_t rl = ((size_t)ix->dim * 4 + 15) & ~(size_t)15;
   for (uint32_t q0 = 0; q0 < nq; q0 += 65535u) {  // grid.y limit
     const uint32_t n = std::min(65535u, nq - q0);
@@ -636,6 +649,7 @@ int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, ui
     rb.in_cnt = in_cnt + q0;
     rb.in_owner = owner ? owner + (size_t)q0 * kk : nullptr;
     rb.out = out + (size_t)q0 * kk;
+    rb.act.base = act.base + q0;
     hipLaunchKernelGGL(k_refine_dist, dim3((kk + 255) / 256, n), dim3(256), rl, st, rb);
   }
   HIP_TRY(hipGetLastError());
@@ -678,7 +692,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   // chunk the batch so the workspace stays bounded
   const size_t spill_per_item = (size_t)(ix->m - m_lds) * 1024;  // table tail of one work item (k_scan_pair SPILL)
   const size_t per_q = (size_t)ix->nlist * 4 + (size_t)nprobe * n_slices * (pl.kk * sizeof(Cand) + spill_per_item);
-  const size_t budget = (size_t)dev_knob("MI355_WORKSPACE_MB", 2048) << 20;
+  const size_t budget = (size_t)(pl.ws_mb ? pl.ws_mb : dev_knob("MI355_WORKSPACE_MB", 2048)) << 20;
   uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / std::max<size_t>(per_q, 1)));
   chunk = std::min(chunk, 65535u);  // grid.z limit
   if (skew) {
@@ -699,6 +713,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t n = std::min(chunk, nq - q0);
     const float* q = d_q + (size_t)q0 * ix->dim;
+    ActiveMask act = pl.act;  // device-side batch size (second pass): this chunk's slots start at q0
+    act.base += q0;
     EventSet es{};
     if (prof) {
       if (!ix->ev_free.empty()) {
@@ -716,7 +732,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       HIP_TRY(hipMemsetAsync(&d_ctl->bad_probes, 0, 4, st));
       const uint32_t np = n * nprobe;
       hipLaunchKernelGGL(k_take_probes, dim3((np + 255) / 256), dim3(256), 0, st, pl.ext_probes + (size_t)q0 * nprobe, np,
-                         ix->nlist, view.plen, ix->w_probes.as<uint32_t>(), d_stat, &d_ctl->bad_probes);
+                         ix->nlist, view.plen, ix->w_probes.as<uint32_t>(), d_stat, &d_ctl->bad_probes, nprobe, act);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
     } else {
@@ -729,11 +745,11 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       hipLaunchKernelGGL(k_coarse_mfma, dim3((ix->nlist + CM_T - 1) / CM_T, (n + CM_T - 1) / CM_T),
                          dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
                          view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
-                         ix->w_coarse.as<float>());
+                         ix->w_coarse.as<float>(), act);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
     hipLaunchKernelGGL(k_select_probes, dim3(n), dim3(256), 0, st, ix->w_coarse.as<float>(),
-                       ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat);
+                       ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat, act);
     HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(es.ev[2], st));
@@ -757,6 +773,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       pa.code_off = view.code_off;
       pa.cand = ix->w_cand.as<Cand>();
       pa.kk = pl.kk;
+      pa.nprobe = nprobe;
+      pa.act = act;
       const uint32_t pb = (pa.n_pairs + 255) / 256;
       HIP_TRY(hipMemsetAsync(ix->qthr.p, 0xFF, sizeof(uint32_t) * n, st));
       hipLaunchKernelGGL(k_plan_count, dim3(pb), dim3(256), 0, st, pa);
@@ -797,12 +815,14 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       sa.ctl = d_ctl;
       sa.m_lds = m_lds;
       sa.lut_spill = ix->w_spill.as<float>();
+      sa.act = act;
       ST_TRY(launch_scan_pair(sa, dim3(n_slices, nprobe, n), st, vpt, nt));
     }
     if (prof) HIP_TRY(hipEventRecord(es.ev[3], st));
 
     MergeArgs ma = merge_args_dense(ix->w_cand.as<Cand>(), nprobe * n_slices, pl.kk, n, pl.k);
     ma.ctl = d_ctl;
+    ma.act = act;
     if (pl.out_cand) {
       // sharded search: the kk best ANN records of this shard; refine runs after the cross-rank merge
       ma.k_out = pl.kk;
@@ -828,9 +848,10 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       launch_by_kpl(kpl_kk, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
-      ST_TRY(launch_refine(ix, view, q, n, ann, d_cnt_ann + q0, nullptr, 0, pl.kk, pl.range, exact, st));
+      ST_TRY(launch_refine(ix, view, q, n, ann, d_cnt_ann + q0, nullptr, 0, pl.kk, pl.range, exact, st, act));
       MergeArgs mr = merge_args_dense(exact, 1, pl.kk, n, pl.k);
       mr.ctl = d_ctl;
+      mr.act = act;
       mr.out_ids = d_ids + (size_t)q0 * pl.k;
       mr.out_dist = d_dist + (size_t)q0 * pl.k;
       mr.out_cnt = d_cnt + q0;
@@ -853,7 +874,7 @@ static int32_t launch_sequence(mi355_index* ix, const float* d_q, uint32_t nq, c
   hipStream_t st = ix->stream;
   DevCtl* ctl = ix->w_ctl.as<DevCtl>();
   if ((ix->profile & MI355_PROFILE_MASK) != 2)  // 2 = cumulative: the row counter runs until the next configure()
-    HIP_TRY(hipMemsetAsync(&ctl->rows_scanned, 0, sizeof(ctl->rows_scanned), st));
+    HIP_TRY(hipMemsetAsync(ctl, 0, DEVCTL_COUNTER_BYTES, st));
   hipLaunchKernelGGL(k_arm_deadline, dim3(1), dim3(1), 0, st, ctl, (unsigned long long)timeout_ms * ix->wall_khz);
   HIP_TRY(hipGetLastError());
   return run_ivfpq(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann);
@@ -973,39 +994,55 @@ int32_t check_search(mi355_index* ix, const float* queries, uint32_t n_queries, 
   return MI355_OK;
 }
 
-// queries whose ANN stage found fewer than kk rows are searched again over np_max partitions
-// (maximum_nprobes, query.rs:1246-1262; the decision is taken before the refine re-rank)
+// maximum_nprobes (query.rs:1246-1262): queries whose ANN stage found fewer than kk rows are searched
+// again over np_max partitions; the decision is taken before the refine re-rank.  The short queries
+// are picked ON THE DEVICE (k_compact_short) and the second pass runs over all n_queries slots behind
+// an ActiveMask, so the host never reads the count: no synchronisation inside a device-I/O call, and
+// in a sharded search no rank stalls the others.  `rows` receives [n_queries] slot -> query index and,
+// behind them, the device-side count; `sq` the gathered query vectors.
+int32_t expand_short_device(mi355_index* ix, const uint32_t* d_cnt_ann, uint32_t n_queries, uint32_t kk, const float* d_q,
+                            DevBuf& rows, DevBuf& sq, hipStream_t st, ActiveMask* out_act) {
+  ST_TRY(rows.ensure(sizeof(uint32_t) * ((size_t)n_queries + 1)));
+  ST_TRY(sq.ensure(sizeof(float) * (size_t)n_queries * ix->dim));
+  uint32_t* d_rows = rows.as<uint32_t>();
+  uint32_t* d_n = d_rows + n_queries;
+  hipLaunchKernelGGL(k_compact_short, dim3(1), dim3(1024), 0, st, d_cnt_ann, n_queries, kk, d_rows, d_n, ix->w_ctl.as<DevCtl>());
+  ActiveMask act;
+  act.n = d_n;
+  act.base = 0;
+  hipLaunchKernelGGL(k_gather_rows_f32, dim3(n_queries), dim3(256), 0, st, d_q, d_rows, ix->dim, sq.as<float>(), act);
+  HIP_TRY(hipGetLastError());
+  *out_act = act;
+  return MI355_OK;
+}
+
 static int32_t expand_short_queries(mi355_index* ix, const float* d_q, uint32_t n_queries, const SearchPlan& pl,
                                     uint32_t np_max, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt,
                                     const uint32_t* d_cnt_ann) {
   hipStream_t st = ix->stream;
   const uint32_t k = pl.k;
-  std::vector<uint32_t> cnt(n_queries);
-  HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt_ann, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  std::vector<uint32_t> shortq;
-  for (uint32_t i = 0; i < n_queries; ++i)
-    if (cnt[i] < pl.kk) shortq.push_back(i);
-  if (shortq.empty()) return MI355_OK;
-  const uint32_t ns = (uint32_t)shortq.size();
-  ST_TRY(ix->w_sq.ensure(sizeof(float) * (size_t)ns * ix->dim + sizeof(uint32_t) * ns));
-  ST_TRY(ix->w_sids.ensure(sizeof(uint64_t) * (size_t)ns * k));
-  ST_TRY(ix->w_sdist.ensure(sizeof(float) * (size_t)ns * k));
-  ST_TRY(ix->w_scnt.ensure(sizeof(uint32_t) * ns));
-  ST_TRY(ix->w_scnt_ann.ensure(sizeof(uint32_t) * ns));
-  uint32_t* d_short = (uint32_t*)(ix->w_sq.as<float>() + (size_t)ns * ix->dim);
-  HIP_TRY(hipMemcpyAsync(d_short, shortq.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_gather_rows_f32, dim3(ns), dim3(256), 0, st, d_q, d_short, ix->dim, ix->w_sq.as<float>());
-  HIP_TRY(hipGetLastError());
+  ST_TRY(ix->w_sids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
+  ST_TRY(ix->w_sdist.ensure(sizeof(float) * (size_t)n_queries * k));
+  ST_TRY(ix->w_scnt.ensure(sizeof(uint32_t) * n_queries));
+  ST_TRY(ix->w_scnt_ann.ensure(sizeof(uint32_t) * n_queries));
   SearchPlan p2 = pl;
   p2.nprobe = np_max;
-  ST_TRY(run_ivfpq(ix, ix->w_sq.as<float>(), ns, p2, ix->w_sids.as<uint64_t>(), ix->w_sdist.as<float>(),
+  p2.ws_mb = 512;  // slots, not queries, size the workspace of this pass
+  ST_TRY(expand_short_device(ix, d_cnt_ann, n_queries, pl.kk, d_q, ix->w_srows, ix->w_sq, st, &p2.act));
+  ST_TRY(run_ivfpq(ix, ix->w_sq.as<float>(), n_queries, p2, ix->w_sids.as<uint64_t>(), ix->w_sdist.as<float>(),
                    ix->w_scnt.as<uint32_t>(), pl.refine ? ix->w_scnt_ann.as<uint32_t>() : ix->w_scnt.as<uint32_t>()));
-  hipLaunchKernelGGL(k_scatter_results, dim3(ns), dim3(64), 0, st, d_short, k, ix->w_sids.as<uint64_t>(),
-                     ix->w_sdist.as<float>(), ix->w_scnt.as<uint32_t>(), d_ids, d_dist, d_cnt);
+  hipLaunchKernelGGL(k_scatter_results, dim3(n_queries), dim3(64), 0, st, ix->w_srows.as<uint32_t>(), k, ix->w_sids.as<uint64_t>(),
+                     ix->w_sdist.as<float>(), ix->w_scnt.as<uint32_t>(), d_ids, d_dist, d_cnt, p2.act);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(st));  // shortq (pageable host memory) was read by the upload
-  account(ix, ns, np_max);
+  ix->second_np = np_max;
+  return MI355_OK;
+}
+
+int32_t join_exchange(mi355_index* ix) {
+  if (ix->xpending) {
+    HIP_TRY(hipStreamWaitEvent(ix->stream, ix->xdone, 0));
+    ix->xpending = false;
+  }
   return MI355_OK;
 }
 
@@ -1014,6 +1051,7 @@ static int32_t expand_short_queries(mi355_index* ix, const float* d_q, uint32_t 
 static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& calls, const mi355_search_params* p,
                              const SearchShape& sh, const uint64_t* ext_probes, uint32_t ext_nprobe) {
   HIP_TRY(hipSetDevice(ix->device));
+  ST_TRY(join_exchange(ix));
   hipStream_t st = ix->stream;
   auto t_start = std::chrono::steady_clock::now();
   const bool host_io = p->io_mem == MI355_MEM_HOST;
@@ -1255,6 +1293,7 @@ extern "C" int32_t mi355_coarse_topn(mi355_index* ix, const float* queries, uint
   if (!queries || !out_part_ids || !out_dist || !out_counts) return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
+  ST_TRY(join_exchange(ix));
   hipStream_t st = ix->stream;
   const bool host_io = io_mem == MI355_MEM_HOST;
   const uint32_t nq = n_queries;

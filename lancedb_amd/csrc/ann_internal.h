@@ -190,11 +190,16 @@ struct mi355_index {
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2, w_dist2, w_cnt2, w_ctl,
-      w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann, w_spill;
+      w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann, w_spill, w_srows;
   uint32_t ws_gen = 0;  // bumped by every workspace re-allocation
+  uint32_t second_np = 0;  // nprobe of the last maximum_nprobes second pass (stats: DevCtl.short_queries x this)
+  // overlapped sharded search (ann_comm.hip): the exchange of the last call may still run on the
+  // communicator's stream; `xdone` is recorded behind it and every other entry point joins it first
+  hipEvent_t xdone = nullptr;
+  bool xpending = false;
   // config
   uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
-  bool use_graph = true, coalesce = true;
+  bool use_graph = false, coalesce = true;  // graph replay measured slower than eager launches
   mi355_stats stats{};
   std::vector<EventSet> ev_free, ev_pending;
   std::map<GraphKey, GraphEntry> graphs;
@@ -245,6 +250,8 @@ struct SearchPlan {
   // sharded search: stop after the ANN merge and leave the kk best (distance, position, rowid)
   // records per query in out_cand [nq, kk] (refine runs after the cross-rank merge)
   Cand* out_cand = nullptr;
+  ActiveMask act;      // device-side batch size: the maximum_nprobes second pass (slots past *act.n are skipped)
+  uint32_t ws_mb = 0;  // workspace budget of this pass in MiB (0 = the default)
 };
 int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl, uint64_t* d_ids,
                   float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann);
@@ -263,7 +270,7 @@ int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint
 struct IndexView;
 int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,
                       const uint32_t* in_cnt, const uint32_t* owner, uint32_t my_rank, uint32_t kk,
-                      const RangeFilter& range, Cand* out, hipStream_t st);
+                      const RangeFilter& range, Cand* out, hipStream_t st, ActiveMask act = ActiveMask());
 IndexView make_view(const mi355_index* ix);
 
 // pieces of the search path shared with the sharded search (ann_comm.hip)
@@ -275,6 +282,9 @@ int32_t check_search(mi355_index* ix, const float* queries, uint32_t n_queries, 
                      uint32_t* out_counts, SearchShape* sh, bool sharded_call);
 void account(mi355_index* ix, uint32_t nq, uint32_t nprobe);
 int32_t drain_events(mi355_index* ix, bool discard);
+int32_t join_exchange(mi355_index* ix);  // make ix->stream wait for an exchange still running on a communicator's stream
+int32_t expand_short_device(mi355_index* ix, const uint32_t* d_cnt_ann, uint32_t n_queries, uint32_t kk, const float* d_q,
+                            DevBuf& rows, DevBuf& sq, hipStream_t st, ActiveMask* out_act);
 void reset_stats(mi355_index* ix);
 int32_t coarse_topn_device(mi355_index* ix, const float* d_q, uint32_t nq, uint32_t nprobe, uint32_t cent_lo,
                            uint32_t cent_hi, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt);

@@ -25,12 +25,16 @@ struct Cand {  // 16 B candidate record kept between scan -> merge -> refine
 // at entry; the first kernel that sees it pass latches `timed_out` and the rest of the
 // call's launch sequence exits at once.
 struct DevCtl {
+  // per-call counters, zeroed together (DEVCTL_COUNTER_BYTES) unless the profile mode is cumulative
   unsigned long long rows_scanned;  // stats: vectors scanned (sum over (query, partition) pairs)
+  uint32_t short_queries;           // queries re-searched over maximum_nprobes partitions (decided on the device)
+  uint32_t pad0;
   unsigned long long deadline;      // wall_clock64() value after which kernels stop; 0 = none
   uint32_t timed_out;
   uint32_t bad_probes;              // probe ids outside 0..nlist-1 (mi355_search_probes)
-  uint32_t pad[10];
+  uint32_t pad[8];
 };
+#define DEVCTL_COUNTER_BYTES 16u
 
 __device__ __forceinline__ bool ctl_expired(DevCtl* ctl) {
   if (!ctl) return false;
@@ -93,6 +97,16 @@ __device__ __forceinline__ bool in_range(float d, const RangeFilter& r) {
   if (r.has_upper && !(d < r.upper)) return false;
   return true;
 }
+
+// Device-decided batch size (maximum_nprobes second pass, query.rs:1246-1262): the queries that came
+// back short are compacted on the device (k_compact_short) and the second pass is launched over the
+// FULL slot count with this mask — slots at or past *n are inactive and cost an early exit, so the
+// host never reads the count (no synchronisation inside a device-I/O call).
+struct ActiveMask {
+  const uint32_t* n = nullptr;  // device: number of active slots, or nullptr (every slot is active)
+  uint32_t base = 0;            // slot index of this launch's query 0
+  __device__ __forceinline__ bool on(uint32_t b) const { return !n || base + b < *n; }
+};
 
 // prefilter (mi355_search_params.filter_*): sorted unique row ids, allow or block list.
 // Evaluated lazily, only for rows that already beat the running distance threshold.

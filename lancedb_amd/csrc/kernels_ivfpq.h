@@ -194,12 +194,13 @@ typedef __attribute__((ext_vector_type(16))) float cm_f32x16;
 static __global__ __launch_bounds__(256) void k_coarse_mfma(
     const float* __restrict__ qp, const float* __restrict__ qq, uint32_t nq,
     const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist, uint32_t dim,
-    uint32_t metric, float* __restrict__ out /*[nq, nlist]*/) {
+    uint32_t metric, float* __restrict__ out /*[nq, nlist]*/, ActiveMask act = ActiveMask()) {
   __shared__ float sa[CM_T][CM_K + 1];
   __shared__ float sb[CM_T][CM_K + 1];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const uint32_t q0 = blockIdx.y * CM_T, c0 = blockIdx.x * CM_T;
+  if (!act.on(q0)) return;  // a query tile past the device-side batch size
   cm_f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -285,7 +286,7 @@ static __global__ __launch_bounds__(256) void k_coarse_mfma(
 static __global__ __launch_bounds__(256) void k_select_probes(
     const float* __restrict__ coarse, uint32_t nlist, uint32_t nprobe,
     const uint32_t* __restrict__ plen, uint32_t* __restrict__ probes /*[nq, nprobe]*/,
-    unsigned long long* __restrict__ stat_rows) {
+    unsigned long long* __restrict__ stat_rows, ActiveMask act = ActiveMask()) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_prefix, s_need, s_less, s_wave_cnt[4], s_running;
   __shared__ unsigned long long s_rows;
@@ -293,6 +294,7 @@ static __global__ __launch_bounds__(256) void k_select_probes(
   const uint32_t b = blockIdx.x;
   const float* src = coarse + (size_t)b * nlist;
   uint32_t* out = probes + (size_t)b * nprobe;
+  if (!act.on(b)) return;  // inactive slot: the planner, the scan and the merge skip it too
   if (tid == 0) {
     s_prefix = 0;
     s_need = nprobe;
@@ -378,9 +380,11 @@ static __global__ void k_emit_coarse_pairs(const uint32_t* __restrict__ probes, 
 // external probe list (u64 ids) -> the u32 list the scan reads, plus the row counter
 static __global__ void k_take_probes(const uint64_t* __restrict__ in, uint32_t n, uint32_t nlist,
                               const uint32_t* __restrict__ plen, uint32_t* __restrict__ out,
-                              unsigned long long* __restrict__ stat_rows, uint32_t* __restrict__ bad) {
+                              unsigned long long* __restrict__ stat_rows, uint32_t* __restrict__ bad,
+                              uint32_t nprobe = 1, ActiveMask act = ActiveMask()) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (!act.on(i / nprobe)) return;
   const uint64_t p = in[i];
   if (p >= nlist) {  // not a partition of this index: counted (mi355_stats.bad_probes; host-I/O calls fail) and
     atomicAdd(bad, 1u);  // turned into an EMPTY work item (the planner and the scan treat ids >= nlist as length 0)
@@ -442,6 +446,7 @@ struct ScanArgs {
   // `lut_spill` ([grid blocks][m - m_lds][256] f32, served by L2) and are gathered from there
   uint32_t m_lds;
   float* lut_spill;
+  ActiveMask act;           // device-side batch size (second pass of maximum_nprobes)
 };
 
 // rows per selection pass of a scan work item when kk exceeds the per-wave list capacity
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(NTHREADS) void k_scan_pair(ScanArgs a) {
   const IndexView& ix = a.ix;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t s = blockIdx.x, r = blockIdx.y, b = blockIdx.z;
+  if (!a.act.on(b)) return;
   if (ctl_expired(a.ctl)) return;  // block-uniform enough: a late block only wastes its own time
   Cand* out = a.cand + (((size_t)b * a.nprobe + r) * a.n_slices + s) * a.kk;
   const uint32_t p = a.probes[(size_t)b * a.nprobe + r];
@@ -711,6 +717,7 @@ struct MergeArgs {
   Cand* out_cand;     // [nq, k_out] packed records (distance, pos, id), or nullptr
   uint32_t* out_cnt;  // [nq]
   const DevCtl* ctl;  // deadline flag (nullptr = none)
+  ActiveMask act;     // device-side batch size (inactive queries are not merged)
 };
 
 // the scan's own layout: cand [nq][n_src][kk_in], empty slots marked by pos
@@ -732,6 +739,7 @@ static inline MergeArgs merge_args_dense(const Cand* cand, uint32_t n_src, uint3
   m.out_cand = nullptr;
   m.out_cnt = nullptr;
   m.ctl = nullptr;
+  m.act = ActiveMask();
   return m;
 }
 
@@ -740,6 +748,7 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
   const int lane = threadIdx.x;
   const uint32_t b = blockIdx.x;
   if (a.ctl && a.ctl->timed_out) return;
+  if (!a.act.on(b)) return;
   const Cand* src = a.cand + (size_t)b * a.q_stride;
   const uint32_t n = a.n_src * a.kk_in;
   uint64_t* oi = a.out_ids ? a.out_ids + (size_t)b * a.k_out : nullptr;
@@ -925,6 +934,9 @@ struct RefineArgs {
   RangeFilter range;
   Cand* out;               // [nq, kk]
   const DevCtl* ctl;
+  uint32_t n_rows;         // rows on this handle: a position at or past it is not refined (a peer's slab
+                           // that a timed-out scan left unwritten must not become an address)
+  ActiveMask act;
 };
 
 static __global__ __launch_bounds__(256) void k_refine_dist(RefineArgs a) {
@@ -934,6 +946,7 @@ static __global__ __launch_bounds__(256) void k_refine_dist(RefineArgs a) {
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.y;
   if (a.ctl && a.ctl->timed_out) return;
+  if (!a.act.on(b)) return;
   const float* q = a.q + (size_t)b * a.ix.dim;
   for (uint32_t d = tid; d < a.ix.dim; d += 256) sq[d] = q[d];
   __syncthreads();
@@ -952,7 +965,7 @@ static __global__ __launch_bounds__(256) void k_refine_dist(RefineArgs a) {
   o.id = ~0ull;
   if (c < cnt && (!a.in_owner || a.in_owner[(size_t)b * a.kk + c] == a.my_rank)) {
     const Cand in = a.in[(size_t)b * a.kk + c];
-    if (in.pos != CAND_EMPTY_POS) {
+    if (in.pos != CAND_EMPTY_POS && in.pos < a.n_rows) {
       const uint64_t rrow = a.ix.raw_by_global ? global_pos_of(a.ix, in.pos) : (uint64_t)in.pos;
       const float d = exact_distance(sq, a.ix.raw, a.ix.raw_dtype, rrow, a.ix.dim, a.ix.metric, s_qq);
       if (in_range(d, a.range)) {
@@ -986,8 +999,42 @@ static __global__ void k_pack_cands(const uint64_t* __restrict__ ids, const floa
 
 // maximum_nprobes expansion: the short queries' vectors gathered into a dense batch, and their
 // second-pass results written back over the first pass's rows
+// the queries whose ANN stage found fewer than kk rows, in ascending query order: rows[0 .. *n_short)
+// (one 1024-thread block; the count stays on the device, see ActiveMask) and the counter of the call
+static __global__ __launch_bounds__(1024) void k_compact_short(const uint32_t* __restrict__ cnt_ann, uint32_t nq, uint32_t kk,
+                                                               uint32_t* __restrict__ rows, uint32_t* __restrict__ n_short,
+                                                               DevCtl* __restrict__ ctl) {
+  __shared__ uint32_t s_wave[16], s_base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (uint32_t q0 = 0; q0 < nq; q0 += 1024u) {
+    const uint32_t q = q0 + tid;
+    const bool is_short = q < nq && cnt_ann[q] < kk;
+    const unsigned long long bal = __ballot(is_short);
+    if (lane == 0) s_wave[wid] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wid; ++w) base += s_wave[w];
+    if (is_short) rows[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = q;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = s_base;
+      for (uint32_t w = 0; w < 16; ++w) t += s_wave[w];
+      s_base = t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *n_short = s_base;
+    if (ctl) atomicAdd(&ctl->short_queries, s_base);
+  }
+}
+
 static __global__ __launch_bounds__(256) void k_gather_rows_f32(const float* __restrict__ src, const uint32_t* __restrict__ rows,
-                                                              uint32_t dim, float* __restrict__ dst) {
+                                                              uint32_t dim, float* __restrict__ dst,
+                                                              ActiveMask act = ActiveMask()) {
+  if (!act.on(blockIdx.x)) return;
   const float* s = src + (size_t)rows[blockIdx.x] * dim;
   float* d = dst + (size_t)blockIdx.x * dim;
   for (uint32_t i = threadIdx.x; i < dim; i += 256) d[i] = s[i];
@@ -996,7 +1043,9 @@ static __global__ __launch_bounds__(256) void k_gather_rows_f32(const float* __r
 static __global__ __launch_bounds__(64) void k_scatter_results(const uint32_t* __restrict__ rows, uint32_t k,
                                                               const uint64_t* __restrict__ s_ids, const float* __restrict__ s_dist,
                                                               const uint32_t* __restrict__ s_cnt, uint64_t* __restrict__ ids,
-                                                              float* __restrict__ dist, uint32_t* __restrict__ cnt) {
+                                                              float* __restrict__ dist, uint32_t* __restrict__ cnt,
+                                                              ActiveMask act = ActiveMask()) {
+  if (!act.on(blockIdx.x)) return;
   const uint32_t i = blockIdx.x, q = rows[i];
   for (uint32_t g = threadIdx.x; g < k; g += 64) {
     ids[(size_t)q * k + g] = s_ids[(size_t)i * k + g];

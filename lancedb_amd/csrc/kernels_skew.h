@@ -237,11 +237,14 @@ struct PlanArgs {
   const uint64_t* code_off; // [nlist]
   Cand* cand;               // [n_pairs][kk]
   uint32_t kk;
+  uint32_t nprobe;          // pairs per query (for the mask)
+  ActiveMask act;           // device-side batch size: pairs of inactive queries make no item, no slot writes
 };
 
 static __global__ void k_plan_count(PlanArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_pairs) return;
+  if (!a.act.on(i / a.nprobe)) return;
   const uint32_t p = a.probes[i];
   if (p < a.nlist && a.plen[p])  // ids outside the index (mi355_search_probes) are empty items
     atomicAdd(&a.cnt[p], 1u);
@@ -294,6 +297,7 @@ static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
 static __global__ void k_plan_fill(PlanArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_pairs) return;
+  if (!a.act.on(i / a.nprobe)) return;
   const uint32_t p = a.probes[i];
   const uint32_t len = p < a.nlist ? a.plen[p] : 0u;
   if (!len) return;

@@ -40,8 +40,12 @@ def unique_id():
 
 
 def exchange_id_via_file(path, rank, timeout_s=120.0):
-    """Rank 0 writes the id to `path` (atomically), the others wait for it."""
+    """Rank 0 writes the id to `path` (atomically), the others wait for it.  `path` must be
+    fresh per launch (e.g. carry the launcher's pid): a file left by an earlier run would hand
+    the other ranks a dead id, so rank 0 refuses to start over an existing one."""
     if rank == 0:
+        if os.path.exists(path):
+            raise FileExistsError(f"{path} exists: a communicator id file must be new for every launch")
         uid = unique_id()
         tmp = f"{path}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
@@ -62,16 +66,28 @@ def exchange_id_via_file(path, rank, timeout_s=120.0):
 
 
 class Comm(_Handle):
-    """One rank's RCCL communicator (mi355_comm_create is collective: every rank calls it)."""
+    """One rank's communicator.  `Comm(uid, rank, world)` is RCCL (mi355_comm_create is collective:
+    every rank calls it, one process per GPU); `Comm.loopback(world)` returns the `world`
+    communicators of a loopback group — all ranks in this process on one device, each driven
+    from its own thread (`run_ranks`)."""
     _close_fn = "mi355_comm_destroy"
 
-    def __init__(self, uid, rank, world, device=0):
+    def __init__(self, uid, rank, world, device=0, _handle=None):
         super().__init__()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        if _handle is not None:
+            self._h = _handle
+            return
         if len(uid) != _abi.COMM_ID_BYTES:
             raise ValueError(f"communicator id must be {_abi.COMM_ID_BYTES} bytes")
-        self.rank, self.world, self.device = int(rank), int(world), int(device)
         check(lib().mi355_comm_create(C.c_char_p(uid), C.c_uint32(rank), C.c_uint32(world), C.c_int32(device),
                                       C.byref(self._h)))
+
+    @classmethod
+    def loopback(cls, world, device=0):
+        hs = (C.c_void_p * int(world))()
+        check(lib().mi355_comm_create_loopback(C.c_uint32(world), C.c_int32(device), hs))
+        return [cls(None, r, world, device, _handle=C.c_void_p(hs[r])) for r in range(int(world))]
 
     def stats(self):
         """Load report of the last sharded search (identical on every rank): per-rank scanned
@@ -80,7 +96,32 @@ class Comm(_Handle):
         s.struct_size = C.sizeof(_abi.CommStats)
         check(lib().mi355_comm_last_stats(self._h, C.byref(s)))
         return {"world": s.world, "rank": s.rank, "n_gathers": s.n_gathers, "bytes_gathered": s.bytes_gathered,
-                "rows_scanned": [int(s.rows_scanned[r]) for r in range(s.world)], "imbalance": float(s.imbalance)}
+                "rows_scanned": [int(s.rows_scanned[r]) for r in range(s.world)], "imbalance": float(s.imbalance),
+                "us_exchange": float(s.us_exchange), "overlapped": bool(s.overlapped)}
+
+
+def run_ranks(fns):
+    """Run one callable per rank of a loopback group, each on its own thread (the collective
+    calls rendezvous inside the library; ctypes drops the GIL for their duration).  Returns the
+    results in rank order; the first exception of any rank is re-raised."""
+    import threading
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def work(i):
+        try:
+            out[i] = fns[i]()
+        except BaseException as e:  # noqa: BLE001 - handed to the caller below
+            err[i] = e
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
 
 
 class ShardedSearcher:
@@ -90,12 +131,14 @@ class ShardedSearcher:
     candidates are merged first, then every rank refines the ones whose raw vectors it
     owns) and `maximum_nprobes`."""
 
-    def __init__(self, index, comm, shard_coarse=False):
+    def __init__(self, index, comm, shard_coarse=False, overlap=True):
         """shard_coarse: two-phase search (C4, nlist = 65536): every rank scores only its
         slice of the centroids; one extra all-gather of `nprobe` (partition, distance) records
-        per query per rank selects the global probe list before the scan."""
+        per query per rank selects the global probe list before the scan.
+        overlap: device-I/O calls queue their exchange on the communicator's stream so that
+        the next call's scan overlaps it (results are complete after `index.sync()`)."""
         self.index, self.comm = index, comm
-        self.flags = _abi.SHARD_COARSE if shard_coarse else 0
+        self.flags = (_abi.SHARD_COARSE if shard_coarse else 0) | (0 if overlap else _abi.SHARD_NO_OVERLAP)
 
     def search(self, queries, params, out=None):
         def fn(handle, q, nq, params_ref, ids, dist, cnt):
@@ -116,5 +159,5 @@ class ShardedFlatSearcher:
         return _run_search(fn, self.flat._h, self.flat.dim, queries, params, out)
 
 
-__all__ = ["Comm", "ShardedSearcher", "ShardedFlatSearcher", "coarse_slice", "unique_id", "exchange_id_via_file",
+__all__ = ["Comm", "ShardedSearcher", "ShardedFlatSearcher", "coarse_slice", "unique_id", "exchange_id_via_file", "run_ranks",
            "SearchResult"]

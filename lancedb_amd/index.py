@@ -154,11 +154,18 @@ class IvfPqIndex(_Handle):
         check(lib().mi355_index_open(C.byref(d), C.byref(self._h)))
         self._keep = [raw] if raw_host_mapped else []  # the library copied everything else it needs
 
-    def configure(self, scan_variant=_abi.SCAN_AUTO, slice_rows=0, profile=0, graph=False, coalesce=False):
+    def configure(self, scan_variant=_abi.SCAN_AUTO, slice_rows=0, profile=0, graph=None, coalesce=None):
         """profile: 0 counters only, 1 per-stage times of the last search,
-        2 accumulate over searches until the next configure().  graph / coalesce:
-        the latency and concurrency modes of host-I/O searches (both on after open)."""
-        mode = int(profile) | (_abi.CFG_GRAPH if graph else 0) | (_abi.CFG_COALESCE if coalesce else 0)
+        2 accumulate over searches until the next configure().  graph / coalesce: the
+        hipGraph-replay and coalescing-queue modes of host-I/O searches; None keeps the current
+        setting (after open: coalescing on, graph replay off — measured slower than eager launches
+        on the driver's box, profiles/r02 latency leg)."""
+        if graph is not None:
+            self._graph = bool(graph)
+        if coalesce is not None:
+            self._coalesce = bool(coalesce)
+        mode = int(profile) | (_abi.CFG_GRAPH if getattr(self, "_graph", False) else 0) | \
+            (_abi.CFG_COALESCE if getattr(self, "_coalesce", True) else 0)
         check(lib().mi355_index_configure(self._h, C.c_uint32(scan_variant), C.c_uint32(slice_rows), C.c_uint32(mode)))
 
     def set_stream(self, hip_stream):

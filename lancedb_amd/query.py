@@ -375,9 +375,11 @@ def create_plan(table, req: VectorQueryRequest, options: QueryExecutionOptions) 
 
 
 def requires_local_execution(req: VectorQueryRequest) -> bool:
-    """table/query.rs:91-105: the push-down request has no approx_mode / use_lsm field, so such
-    queries must not be pushed down."""
-    return req.use_lsm is not None or req.approx_mode is not None
+    """table/query.rs:91-105: a query carrying a field the push-down request cannot express must not be
+    pushed down — approx_mode / use_lsm in the reference; here also an evaluated row-id mask (the wire
+    carries a SQL `filter`, which this layer never sees)."""
+    return (req.use_lsm is not None or req.approx_mode is not None or req.allow_rowids is not None
+            or req.block_rowids is not None)
 
 
 def execute_query(table, req: VectorQueryRequest, options: QueryExecutionOptions):
@@ -387,9 +389,47 @@ def execute_query(table, req: VectorQueryRequest, options: QueryExecutionOptions
     pushdown = getattr(table, "pushdown", None)
     if pushdown is not None and not requires_local_execution(req):
         from . import wire
-        cols = wire.response_from_ipc(pushdown(wire.request_to_json(req)))
-        return _batches(cols, options, time.monotonic())
+        t0 = time.monotonic()  # the deadline covers the round trip (the client's request timeout, remote/table.rs:697)
+        body = wire.request_to_json(req)
+        try:
+            data = pushdown(body, timeout=options.timeout)
+        except TypeError:  # an endpoint without a timeout parameter
+            data = pushdown(body)
+        cols = wire.response_from_ipc(data)
+        # the server already applied columns / order_by (they travel in the body); a server that predates
+        # them returns everything in (_distance, _rowid) order, so apply them here as well (idempotent)
+        cols = _order_and_project(cols, req)
+        return _batches(cols, options, t0)
     return execute_generic_query(table, req, options)
+
+
+def _order_by(out, order_by):
+    """Stable multi-key sort over the produced columns: last key first; a DESCENDING key sorts its
+    ranks negated, so ties of that key keep the order the less significant keys gave them."""
+    order = np.arange(len(next(iter(out.values()))) if out else 0)
+    for col, asc in reversed(list(order_by)):
+        if col not in out:
+            raise InvalidInput(1, f"cannot order by {col!r}: not produced by the vector-search path")
+        keys = out[col][order]
+        if asc:
+            idx = np.argsort(keys, kind="stable")
+        else:
+            _, rank = np.unique(keys, return_inverse=True)
+            idx = np.argsort(-rank.astype(np.int64), kind="stable")
+        order = order[idx]
+    return {k2: v[order] for k2, v in out.items()}
+
+
+def _order_and_project(out, req: VectorQueryRequest):
+    if req.order_by:
+        out = _order_by(out, req.order_by)
+    if req.select is not None:
+        unknown = [c for c in req.select if c not in out]
+        if unknown:
+            raise InvalidInput(1, f"columns {unknown} are not produced by the vector-search path "
+                                  "(user columns are taken by the table layer from _rowid)")
+        out = {c: v for c, v in out.items() if c in req.select}
+    return out
 
 
 def execute_generic_query(table, req: VectorQueryRequest, options: QueryExecutionOptions):
@@ -411,15 +451,8 @@ def execute_generic_query(table, req: VectorQueryRequest, options: QueryExecutio
     out = {"_rowid": np.concatenate(rid), "_distance": np.concatenate(dist)}
     if q.shape[0] > 1:
         out["query_index"] = np.concatenate(qidx)
-    if req.order_by:  # over the produced columns; stable, last key first
-        order = np.arange(len(out["_rowid"]))
-        for col, asc in reversed(list(req.order_by)):
-            if col not in out:
-                raise InvalidInput(1, f"cannot order by {col!r}: not produced by the vector-search path")
-            keys = out[col][order]
-            idx = np.argsort(keys, kind="stable")
-            order = order[idx if asc else idx[::-1]]
-        out = {k2: v[order] for k2, v in out.items()}
+    if req.order_by:
+        out = _order_by(out, req.order_by)
     out = {c: out[c] for c in plan.output_columns()}
     return _batches(out, options, t0)
 

@@ -24,8 +24,14 @@ def request_to_json(req: VectorQueryRequest, version=None) -> dict:
     if req.offset is not None:
         body["offset"] = int(req.offset)
     body["k"] = _ISIZE_MAX if req.limit is None else int(req.limit)
+    if req.select is not None:  # Select::Columns (remote/table.rs:762-771)
+        body["columns"] = [str(c) for c in req.select]
+    if req.fast_search:  # remote/table.rs:796-798
+        body["fast_search"] = True
     if req.with_row_id:
         body["with_row_id"] = True
+    if req.order_by:  # remote/table.rs:820-833
+        body["order_by"] = [{"column_name": c, "ascending": bool(asc), "nulls_first": False} for c, asc in req.order_by]
     if req.distance_type is not None:
         body["distance_type"] = req.distance_type
     if req.approx_mode is not None:  # remote/table.rs:844-846; body pinned at :4694-4745
@@ -67,6 +73,14 @@ def request_from_json(body) -> VectorQueryRequest:
     req.offset = body.get("offset")
     req.prefilter = bool(body.get("prefilter", True))
     req.with_row_id = bool(body.get("with_row_id", False))
+    cols = body.get("columns")
+    if cols is not None:
+        if isinstance(cols, dict):  # Select::Dynamic / Select::Expr: SQL expressions belong to the table layer
+            raise NotSupported(4, "computed columns are evaluated by the table layer, not by the vector-search path")
+        req.select = [str(c) for c in cols]
+    req.fast_search = bool(body.get("fast_search", False))
+    if body.get("order_by"):
+        req.order_by = [(o["column_name"], bool(o.get("ascending", True))) for o in body["order_by"]]
     req.distance_type = body.get("distance_type")
     am = body.get("approx_mode")
     if am is not None:
@@ -95,11 +109,12 @@ def response_to_ipc(columns: dict, with_row_id=True) -> bytes:
     what the reference's client parses (table/query.rs:636-682)."""
     import pyarrow as pa
     arrays, names = [], []
-    if with_row_id:
+    if with_row_id and "_rowid" in columns:
         arrays.append(pa.array(columns["_rowid"], type=pa.uint64()))
         names.append("_rowid")
-    arrays.append(pa.array(columns["_distance"], type=pa.float32()))
-    names.append("_distance")
+    if "_distance" in columns:  # absent only when `columns` projected it away
+        arrays.append(pa.array(columns["_distance"], type=pa.float32()))
+        names.append("_distance")
     if "query_index" in columns:
         arrays.append(pa.array(columns["query_index"], type=pa.int32()))
         names.append("query_index")

@@ -60,6 +60,7 @@ def test_graph_replay_serves_small_batches_and_stays_exact(oracle):
     ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
     o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
     rng = np.random.default_rng(2)
+    ix.configure(graph=True)  # opt in: replay is off after open (it measured slower than eager launches)
     for kw in (dict(k=10, nprobe_min=8, nprobe_max=8), dict(k=10, nprobe_min=8, nprobe_max=8, refine_factor=5),
                dict(k=10, nprobe_min=8, nprobe_max=8, upper_bound=30.0)):
         for rep in range(5):  # 1st eager (sizes the workspace), 2nd captures, 3rd.. replay

@@ -5,7 +5,7 @@ import pytest
 
 import lancedb_amd
 from lancedb_amd import VectorQuery, VectorQueryRequest
-from lancedb_amd.query import VectorTable
+from lancedb_amd.query import QueryExecutionOptions, VectorTable
 
 
 class _FakeTable(VectorTable):
@@ -153,6 +153,43 @@ def test_pushdown_dispatch_follows_the_reference_rules():
     assert t.vector_search([1, 2, 3, 4]).limit(2).approx_mode("fast").execute()["_rowid"].tolist() == [0, 1]   # local
     assert t.vector_search([1, 2, 3, 4]).limit(2).use_lsm(False).execute()["_rowid"].tolist() == [0, 1]       # local
     assert len(bodies) == 1
+    # an evaluated row-id mask has no field on the wire (the wire carries SQL): such a query stays local
+    t.vector_search([1, 2, 3, 4]).limit(2).only_if_rowids(allow=[3, 4]).execute()
+    assert len(bodies) == 1 and t.index.params.n_filter == 2
+    # columns / fast_search / order_by travel in the body (remote/table.rs:762-833) and are honoured on the response
+    r = t.vector_search([1, 2, 3, 4]).limit(2).select(["_distance"]).fast_search().order_by([("_distance", False)]).execute()
+    b = bodies[1]
+    assert b["columns"] == ["_distance"] and b["fast_search"] is True
+    assert b["order_by"] == [{"column_name": "_distance", "ascending": False, "nulls_first": False}]
+    assert list(r) == ["_distance"] and r["_distance"].tolist() == [0.75, 0.5]
+    # the server side reads the same fields back
+    req = wire.request_from_json(b)
+    assert req.select == ["_distance"] and req.fast_search and req.order_by == [("_distance", False)]
+    # the deadline covers the round trip and is handed to the endpoint
+    seen = []
+
+    def slow(body, timeout=None):
+        seen.append(timeout)
+        import time as _t
+        _t.sleep(0.05)
+        return endpoint(body)
+
+    t.pushdown = slow
+    with pytest.raises(lancedb_amd.QueryTimeout):
+        t.vector_search([1, 2, 3, 4]).limit(2).execute(QueryExecutionOptions(timeout=0.01))
+    assert seen == [0.01]
+
+
+def test_multi_key_order_by_with_a_descending_primary_key():
+    """A descending key must not reverse the order its less significant keys established."""
+    t = VectorTable(index=_ArrayIndex(6))
+    r = t.vector_search(np.zeros((2, 4))).limit(3).order_by([("query_index", False), ("_distance", True)]).execute()
+    assert r["query_index"].tolist() == [1, 1, 1, 0, 0, 0]
+    assert r["_distance"][:3].tolist() == sorted(r["_distance"][:3].tolist())
+    assert r["_distance"][3:].tolist() == sorted(r["_distance"][3:].tolist())
+    r = t.vector_search(np.zeros((2, 4))).limit(3).order_by([("query_index", True), ("_distance", False)]).execute()
+    assert r["query_index"].tolist() == [0, 0, 0, 1, 1, 1]
+    assert r["_distance"][:3].tolist() == sorted(r["_distance"][:3].tolist(), reverse=True)
 
 
 def test_default_vector_column_and_supported_types():

@@ -67,6 +67,9 @@ def parse():
                     help="rows of the TRAINED index recall@10 is measured on (0 = skip); the 100 M throughput "
                          "index has random codes, so recall is only meaningful on a trained one")
     ap.add_argument("--recall-queries", type=int, default=10_000)
+    ap.add_argument("--recall2-rows", type=int, default=1_000_000,
+                    help="rows of the second, embedding-like recall set (1536-d unit vectors of low intrinsic dimension, cosine; 0 = skip)")
+    ap.add_argument("--recall2-queries", type=int, default=2_000)
     ap.add_argument("--recall-iters", type=int, default=25, help="Lloyd iterations of the IVF and PQ trainers")
     ap.add_argument("--secondary", type=int, default=1, help="0 = skip the secondary lines (refine operating point, flat C2)")
     ap.add_argument("--workload", default="ivfpq", choices=["ivfpq", "flat"],
@@ -83,6 +86,12 @@ def parse():
     ap.add_argument("--force-sharded-path", action="store_true",
                     help="dev: run the N > 1 code path (process group, RCCL communicator behind the C ABI, "
                          "mi355_search_sharded, teardown) in a world of one rank: what a 1-GPU box can verify")
+    ap.add_argument("--loopback-world", type=int, default=8,
+                    help="N = 1 secondary leg: the N-rank sharded search of the same index with all ranks on this one GPU "
+                         "(loopback communicator): per-rank stage times of an N-rank step, exchange time, full-size parity "
+                         "with the unsharded search (0 / 1 = skip)")
+    ap.add_argument("--c5-rows", type=int, default=100_000_000,
+                    help="rows of the C5 line (BASELINE.json configs[4]: 100 M x 1536 cosine, refine_factor 10); 0 = skip")
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--slice-rows", type=int, default=0)
     return ap.parse_args()
@@ -173,8 +182,10 @@ def main():
         h_rowids = row_ids.cpu().numpy().astype(np.uint64, copy=False)
     h_centroids = centroids.cpu().numpy()
     h_codebook = codebook.cpu().numpy()
-    del codes, row_ids
-    torch.cuda.empty_cache()
+    keep_arrays = rank == 0 and not sharded and a.secondary and a.loopback_world > 1
+    if not keep_arrays:  # (the loopback leg cuts its shard handles out of the same device arrays)
+        del codes, row_ids
+        torch.cuda.empty_cache()
 
     # ---- query batches (resident in HBM before the timed region)
     P = 4
@@ -288,9 +299,19 @@ def main():
 
     if rank == 0 and not sharded and a.recall_rows > 0:
         result["recall_at_10"] = recall_at_10(a, np, dim, m)
+    if rank == 0 and not sharded and a.recall2_rows > 0:
+        result["recall_at_10_embedding_like"] = recall_embedding_like(a, np)
     if rank == 0 and not sharded and a.secondary:
-        result["secondary"] = {"latency_c3": latency_and_concurrency(a, np, ix, qpool)}
+        result["secondary"] = {}
+        if keep_arrays:
+            result["secondary"]["loopback_world%d" % a.loopback_world] = loopback_world(
+                a, torch, np, ix, centroids, codebook, part_offsets, codes, row_ids, qpool, params, dev)
+            del codes, row_ids
+            torch.cuda.empty_cache()
+        result["secondary"]["latency_c3"] = latency_and_concurrency(a, np, ix, qpool)
         result["secondary"].update(refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev))
+        if a.c5_rows > 0:
+            result["secondary"]["c5_refine10"] = c5_refine10(a, torch, np, dev)
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(a, np, h_centroids, h_codebook, part_offsets, h_codes, h_rowids,
                                               qpool[(a.steps - 1) % P], last, params)
@@ -439,6 +460,257 @@ def refine_operating_point(a, torch, ix, qpool, n_rows, dim, dev):
     return res
 
 
+
+def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, row_ids, qpool, params, dev):
+    """The N-rank sharded search of the SAME index with every rank on this GPU (mi355_comm_create_loopback:
+    one thread and one shard handle per rank, the gather = device copies into the slab layout ncclAllGather
+    fills).  Three things a 1-GPU box can measure about an N-GPU step: (1) each rank's own stage times with
+    the GPU to itself (its partitions' scan, the replicated coarse / select / plan, its local merge);
+    (2) the exchange (gather + merge of world slabs) on the communicator's stream; (3) that all N ranks
+    together return the unsharded result at full size.  `step_model_ms` = the slowest rank's stages (the
+    exchange overlaps the next step's scan) — a model of the N-GPU step built from measured terms, not a
+    measurement of N GPUs."""
+    import lancedb_amd
+    from lancedb_amd import _abi
+    from lancedb_amd.distributed import Comm, ShardedSearcher, run_ranks
+    world, B, k, P = a.loopback_world, a.batch, a.k, len(qpool)
+    t0 = time.perf_counter()
+    shards = [lancedb_amd.IvfPqIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
+                                     codes_layout=_abi.CODES_PART_TRANSPOSED, shard_count=world, shard_rank=r)
+              for r in range(world)]
+    t_open = time.perf_counter() - t0
+    comms = Comm.loopback(world)
+    outs = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+             torch.empty((B,), dtype=torch.int32, device=dev)) for _ in range(world)]
+    steps = max(4, a.steps // 2)
+    torch.cuda.synchronize()
+    # (1) one rank at a time: its stages with the GPU to itself
+    per_rank = []
+    for r in range(world):
+        # (the plain search of a shard handle = its local stages: replicated coarse / select / plan, the scan of
+        # the probed partitions it owns, its local merge)
+        shards[r].configure(profile=0)
+        shards[r].search(qpool[0], params, out=outs[r])
+        shards[r].sync()
+        shards[r].configure(profile=2)
+        t1 = time.perf_counter()
+        for i in range(steps):
+            shards[r].search(qpool[i % P], params, out=outs[r])
+        shards[r].sync()
+        dt = (time.perf_counter() - t1) / steps
+        st = shards[r].stats()
+        per_rank.append({"rows": shards[r].info()[0], "ms_per_step_wall": dt * 1e3,
+                         **{s2 + "_us": st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge")}})
+        shards[r].configure(profile=0)
+    # (2) + (3) all ranks together, one thread each
+    ref = ix.search(qpool[(steps - 1) % P], params)
+    torch.cuda.synchronize()
+    modes = {}
+    for mode, overlap in (("overlapped", True), ("serial", False)):
+        def rank_fn(r):
+            sh = ShardedSearcher(shards[r], comms[r], overlap=overlap)
+            sh.search(qpool[0], params, out=outs[r])
+            shards[r].sync()
+            t2 = time.perf_counter()
+            for i in range(steps):
+                sh.search(qpool[i % P], params, out=outs[r])
+            shards[r].sync()
+            return (time.perf_counter() - t2) / steps, comms[r].stats()
+        got = run_ranks([lambda r=r: rank_fn(r) for r in range(world)])
+        same = all(bool((outs[r][0] == ref.rowids).all().item() and (outs[r][1] == ref.distances).all().item())
+                   for r in range(world))
+        cs = got[0][1]
+        modes[mode] = {"all_ranks_on_one_gpu_ms_per_step": max(g[0] for g in got) * 1e3,
+                       "exchange_us_by_rank": [g[1]["us_exchange"] for g in got], "gathers_per_step": cs["n_gathers"],
+                       "bytes_gathered_per_step": cs["bytes_gathered"], "rows_scanned_by_rank": cs["rows_scanned"],
+                       "load_imbalance_max_over_mean": cs["imbalance"], "every_rank_equals_unsharded": same}
+    stages = [p["coarse_us"] + p["select_us"] + p["scan_us"] + p["merge_us"] for p in per_rank]
+    exch = float(np.median(modes["serial"]["exchange_us_by_rank"]))
+    res = {"world": world, "shard_open_s": round(t_open, 2), "steps": steps, "batch_queries": B,
+           "stage_us_per_step_by_rank_alone": per_rank, **modes,
+           "step_model": {"slowest_rank_stages_us": max(stages), "mean_rank_stages_us": float(np.mean(stages)),
+                          "exchange_us": exch,
+                          "overlapped_ms": max(stages) / 1e3, "serial_ms": (max(stages) + exch) / 1e3,
+                          "qps_overlapped": B / (max(stages) * 1e-6), "qps_serial": B / ((max(stages) + exch) * 1e-6),
+                          "of_linear_overlapped": (B / (max(stages) * 1e-6)) / world,
+                          "note": "per-rank stages measured with the GPU to one rank; exchange = loopback gather (device copies) + "
+                                  "merges, an RCCL all-gather of the same 2.7 MB over xGMI replaces the copies on a real node; "
+                                  "divide qps by the N = 1 value of this run for the modelled scaling efficiency"}}
+    for c in comms:
+        c.close()
+    for s2 in shards:
+        s2.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+def c5_refine10(a, torch, np, dev):
+    """BASELINE.json configs[4] (query.rs:1302-1332, table/query.rs:311-313): IVF-PQ + refine, 100 M x 1536, cosine,
+    nprobe 64, refine_factor 10; nlist 4096 and m = 96 = dim / 16 are the reference's default rules
+    (index/vector.rs:306-310) — BASELINE names neither.  The PQ codes live in HBM; the raw bf16 column is 307 GB,
+    more than the 288 GB of HBM, so it stays in HOST memory, page-locked and mapped (HostMappedArray ->
+    mi355_index_attach_raw): the refine kernel gathers k * refine_factor = 100 rows of 3 KiB per query over PCIe.
+    The column takes at most 70 % of the host memory the process may still use (MemAvailable and the container's
+    cgroup limit); when that is less than 100 M rows the line runs on the largest row count that fits and names it in
+    `config.workload` / `rows_note`; with no usable host memory it falls back to an HBM-resident column."""
+    import threading
+
+    import lancedb_amd
+    from lancedb_amd import _abi
+    n, dim, nlist, m, nprobe, k, rf, B = a.c5_rows, 1536, 4096, 96, a.nprobe, a.k, 10, a.batch
+    row_bytes = dim * 2
+    # host memory this PROCESS may still take: MemAvailable, and the container's cgroup limit when there is one
+    # (the MI355X boxes of this pool: 3 TB of RAM behind a 300 GiB cgroup — a 307 GB column gets the box killed)
+    avail = 0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            avail = int(line.split()[1]) * 1024
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+        if lim != "max":
+            avail = min(avail, int(lim) - cur)
+    except (OSError, ValueError):
+        try:
+            avail = min(avail, int(open("/sys/fs/cgroup/memory/memory.limit_in_bytes").read()) -
+                        int(open("/sys/fs/cgroup/memory/memory.usage_in_bytes").read()))
+        except (OSError, ValueError):
+            pass
+    n_full = n
+    budget = int(avail * 0.7) - (8 << 30)  # the column may take 70 % of what is left (+ the oracle leg's copy of the codes)
+    host_mapped = budget >= 20_000_000 * row_bytes
+    if host_mapped:
+        n = min(n, budget // (row_bytes + m + 8))
+    else:
+        free_hbm, _ = torch.cuda.mem_get_info(dev)
+        n_fit = int((free_hbm - (40 << 30)) // (row_bytes + 2 * m + 16))
+        if n_fit < 1_000_000:
+            return {"skipped": f"neither host RAM ({avail / 1e9:.0f} GB usable) nor HBM for a raw column"}
+        n = min(n, n_fit)
+    n = int(n) // 1_000_000 * 1_000_000
+    t_build = time.perf_counter()
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 5)
+    centroids = torch.randn((nlist, dim), generator=g, device=dev, dtype=torch.float32)
+    centroids /= centroids.norm(dim=1, keepdim=True)  # cosine: the coarse quantiser sees unit vectors
+    codebook = torch.randn((m, 256, dim // m), generator=g, device=dev, dtype=torch.float32) * (0.5 / np.sqrt(dim))
+    rng = np.random.default_rng(SEED + 5)
+    w = np.exp(rng.normal(0.0, a.skew, size=nlist))
+    lens = rng.multinomial(n, w / w.sum())
+    part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
+    part_offsets[1:] = np.cumsum(lens)
+    codes = torch.randint(0, 256, (n * m,), generator=g, device=dev, dtype=torch.uint8)  # lance's transposed blocks
+    mult = 982_451_653
+    while np.gcd(mult, n) != 1:
+        mult += 2
+    row_ids = (torch.arange(n, device=dev, dtype=torch.int64) * mult + 12_345) % n
+    torch.cuda.synchronize()
+    ix = lancedb_amd.IvfPqIndex(centroids, codebook, part_offsets, codes, row_ids, metric="cosine",
+                                codes_layout=_abi.CODES_PART_TRANSPOSED)
+    # raw vectors: bf16 bit patterns of finite values in (0, 2) (the gather and the exact-distance work do not
+    # depend on the values); host: filled by 64 threads from one random block
+    t_raw = time.perf_counter()
+    if host_mapped:
+        raw = np.empty((n, dim), dtype=np.uint16)
+        flat = raw.reshape(-1)
+        blk = np.random.default_rng(SEED + 6).integers(0, 0x4000, size=1 << 27, dtype=np.uint16)  # 256 MB
+
+        def fill(lo, hi):
+            for o in range(lo, hi, blk.size):
+                e = min(hi, o + blk.size)
+                flat[o:e] = blk[:e - o]
+        T = 64
+        th = [threading.Thread(target=fill, args=(flat.size * i // T, flat.size * (i + 1) // T)) for i in range(T)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        t_fill = time.perf_counter() - t_raw
+        t_raw = time.perf_counter()
+        col = lancedb_amd.HostMappedArray(raw)
+        t_map = time.perf_counter() - t_raw
+    else:
+        col = torch.empty((n, dim), dtype=torch.int16, device=dev)
+        gg = torch.Generator(device=dev)
+        gg.manual_seed(SEED + 6)
+        for r0 in range(0, n, 8_000_000):
+            col[r0:r0 + 8_000_000].random_(0, 0x4000, generator=gg)
+        torch.cuda.synchronize()
+        t_fill, t_map = time.perf_counter() - t_raw, 0.0
+    ix.attach_raw_vectors(col, _abi.DTYPE_BF16)
+    t_build = time.perf_counter() - t_build
+    P = 3
+    qpool = []
+    for _ in range(P):
+        pick = torch.randint(0, nlist, (B,), generator=g, device=dev)
+        qpool.append((centroids[pick] + (0.5 / np.sqrt(dim)) * torch.randn((B, dim), generator=g, device=dev)).contiguous())
+    params = _abi.make_params(k=k, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+    out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+           torch.empty((B,), dtype=torch.int32, device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+    ix.set_stream(stream)
+    ix.configure(profile=0)
+    for i in range(2):
+        ix.search(qpool[i % P], params, out=out)
+    torch.cuda.synchronize()
+    ix.configure(profile=2)
+    steps = max(3, a.steps // 2)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = ix.search(qpool[i % P], params, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = ix.stats()
+    refine_bytes = B * k * rf * row_bytes
+    res = {
+        "metric": "queries/sec, IVF-PQ + refine 100M×1536 cosine nprobe=64 refine_factor=10 (BASELINE.json configs[4])",
+        "value": B * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{nprobe}_k{k}_cosine_refine{rf}_raw_bf16_"
+                               + ("host_mapped" if host_mapped else "hbm_resident") + ("" if n == n_full else "_reduced_rows"),
+                   "rows_asked": n_full,
+                   "rows_note": None if n == n_full else
+                   f"{n_full} x {dim} bf16 = {n_full * row_bytes / 1e9:.0f} GB does not fit what this box lets the process use "
+                   f"({avail / 1e9:.0f} GB of host memory: MemAvailable / cgroup limit); the column is the largest that takes 70 % of it",
+                   "n_rows": n, "dim": dim, "nlist": nlist, "m": m, "nprobe": nprobe, "k": k, "refine_factor": rf,
+                   "batch_queries": B, "raw_vectors_gb": n * row_bytes / 1e9,
+                   "raw_vectors": "host memory, page-locked + mapped, gathered over PCIe" if host_mapped else "HBM (host RAM too small)",
+                   "host_mem_usable_gb": round(avail / 1e9), "build_s": round(t_build, 1), "raw_fill_s": round(t_fill, 1),
+                   "raw_page_lock_s": round(t_map, 2)},
+        "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge", "refine")},
+        "refine_gather": {"algorithmic_bytes_per_step": refine_bytes, "gb_per_s": refine_bytes / max(st["us_refine"] / steps, 1e-9) / 1e3,
+                          "peak": "PCIe Gen5 x16 ≈ 64 GB/s per direction" if host_mapped else "HBM 8 TB/s",
+                          "rows_per_step": B * k * rf, "row_bytes": row_bytes},
+        "scan_roofline": {"algorithmic_gb_per_s": st["code_bytes_scanned"] / max(st["us_scan"], 1e-9) / 1e3,
+                          "frac_of_8tbs": st["code_bytes_scanned"] / max(st["us_scan"], 1e-9) / 1e3 / HBM_PEAK_GBS}}
+    if a.cpu_seconds > 0:
+        from oracle import oracle as orc
+        orc.build()
+        cores = os.cpu_count() or 1
+        nq = min(B, cores)
+        h_raw = raw if host_mapped else col.cpu().numpy().view(np.uint16)
+        ox = orc.OracleIndex(centroids.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
+                             row_ids.cpu().numpy().astype(np.uint64), raw_vectors=h_raw, raw_dtype=_abi.DTYPE_BF16,
+                             metric="cosine", codes_layout=1, borrow=True)
+        hq = qpool[(steps - 1) % P][:nq].cpu().numpy()
+        t1 = time.perf_counter()
+        ids, dist, cnt, _ = ox.search(hq, params)
+        t_cpu = time.perf_counter() - t1
+        g_ids = last.rowids[:nq].cpu().numpy().astype(np.uint64)
+        g_dist = last.distances[:nq].cpu().numpy()
+        res["cpu_baseline"] = {"value": nq / t_cpu, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": f"{nq} queries of the last timed batch, one per thread, {t_cpu:.1f} s; C restatement "
+                                         "(oracle/ann_oracle.c), not the reference binary",
+                               "parity": {"queries": nq, "rowids_bit_exact": bool((g_ids == ids).all()),
+                                          "max_rel_distance_error": float(np.max(np.abs(g_dist - dist) / np.maximum(np.abs(dist), 1e-30)))}}
+        ox.close()
+    ix.detach_raw_vectors()
+    ix.close()
+    if host_mapped:
+        col.close()
+        del raw
+    del col, codes, row_ids
+    torch.cuda.empty_cache()
+    return res
+
+
 def flat_c2(a, metric, cpu_queries):
     """BASELINE.json configs[1]: flat KNN over 10 M x 768 bf16, 1024 queries per step, as the bf16 MFMA
     GEMM filter + exact re-rank.  `roofline` is the GEMM kernel's own (HIP events around its launches,
@@ -521,20 +793,11 @@ def flat_c2(a, metric, cpu_queries):
     return res
 
 
-def recall_at_10(a, np, dim, m):
-    """recall@10 of IVF-PQ search against exact flat search on a REAL index (SURVEY.md §8d):
-    `--recall-rows` Gaussian-mixture vectors; IVF centroids (sample_rate 256 rows per partition) and
-    residual PQ codebooks (256 x 256 rows) trained for `--recall-iters` Lloyd iterations and all rows
-    encoded by the engine's own build entry points (mi355_kmeans_train / mi355_ivf_residuals /
-    mi355_pq_train / mi355_ivfpq_encode; parameters as the reference's builder,
-    rust/lancedb/src/index/vector.rs:61-119, :266-319); `--recall-queries` held-out queries.
-    Reported for the ENGINE and for the CPU ORACLE (same index, same queries): with bit-exact row ids
-    the two must be equal.  The 100 M throughput index has random codes, so recall is only
-    meaningful here; `nprobe64_refine10` is the operating point of `secondary.c3_refine10`."""
+def recall_index(a, dim, m):
+    """The trained index of the recall leg (also used by tests/tools/parity_exposure.py): a Gaussian-mixture column,
+    IVF + residual PQ trained and the rows encoded by the engine's build entry points; everything stays on the device."""
     import torch
     import lancedb_amd
-    from lancedb_amd import _abi
-    t0 = time.perf_counter()
     n, nlist, nq, dsub = a.recall_rows, 1024, a.recall_queries, dim // m
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
@@ -570,6 +833,28 @@ def recall_at_10(a, np, dim, m):
     t_enc = time.perf_counter() - t_enc
     xs = x[order].contiguous()
     torch.cuda.synchronize()
+    return {"x": x, "q": q, "cen": cen, "codebook": codebook, "part_offsets": part_offsets, "codes": codes, "order": order,
+            "xs": xs, "n_comp": n_comp, "t_train": t_train, "t_enc": t_enc}
+
+
+def recall_at_10(a, np, dim, m):
+    """recall@10 of IVF-PQ search against exact flat search on a REAL index (SURVEY.md §8d):
+    `--recall-rows` Gaussian-mixture vectors; IVF centroids (sample_rate 256 rows per partition) and
+    residual PQ codebooks (256 x 256 rows) trained for `--recall-iters` Lloyd iterations and all rows
+    encoded by the engine's own build entry points (mi355_kmeans_train / mi355_ivf_residuals /
+    mi355_pq_train / mi355_ivfpq_encode; parameters as the reference's builder,
+    rust/lancedb/src/index/vector.rs:61-119, :266-319); `--recall-queries` held-out queries.
+    Reported for the ENGINE and for the CPU ORACLE (same index, same queries): with bit-exact row ids
+    the two must be equal.  The 100 M throughput index has random codes, so recall is only
+    meaningful here; `nprobe64_refine10` is the operating point of `secondary.c3_refine10`."""
+    import torch
+    import lancedb_amd
+    from lancedb_amd import _abi
+    t0 = time.perf_counter()
+    n, nlist, nq = a.recall_rows, 1024, a.recall_queries
+    R = recall_index(a, dim, m)
+    x, q, cen, codebook, part_offsets, codes, order, xs = (R[k2] for k2 in ("x", "q", "cen", "codebook", "part_offsets", "codes", "order", "xs"))
+    iters, n_comp, t_train, t_enc = a.recall_iters, R["n_comp"], R["t_train"], R["t_enc"]
     ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes, order, raw_vectors=xs)
     fl = lancedb_amd.FlatIndex(x.contiguous())
     torch.cuda.synchronize()
@@ -598,6 +883,83 @@ def recall_at_10(a, np, dim, m):
             o_ids, _, _, _ = ox.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
             out[key + "_cpu_oracle"] = rec(o_ids)
             out[key + "_rowids_bit_exact"] = bool((o_ids == got).all())
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def recall_embedding_like(a, np):
+    """A second recall set whose neighbours are NOT near-ties ("1 M x 1536, unit-normalised for cosine"):
+    unit vectors of intrinsic dimension 48 with a power-law spectrum (x = normalise(z W + 2 % noise), z from a
+    2000-cluster mixture) — the shape of text-embedding columns — indexed with the reference's defaults for the
+    dimension (m = dim / 16 = 96) and searched with cosine.  On the isotropic mixture of `recall_at_10` the true top-10
+    of a query are separated by less than the PQ error, so nprobe does not matter and only refine moves recall; here
+    both knobs do, which is what an nprobe / refine_factor sweep is for (BASELINE.md's chart: nprobes 25-100, rf 30-50)."""
+    import torch
+    import lancedb_amd
+    t0 = time.perf_counter()
+    n, nq, dim, m, nlist, idim = a.recall2_rows, a.recall2_queries, 1536, 96, 1024, 48
+    dsub = dim // m
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 11)
+    spec = 1.0 / torch.sqrt(1.0 + torch.arange(idim, device=dev, dtype=torch.float32))
+    W = torch.linalg.qr(torch.randn((dim, idim), generator=g, device=dev))[0].T.contiguous()  # [idim, dim], orthonormal rows
+    centers = torch.randn((2000, idim), generator=g, device=dev)
+
+    def draw(cnt):
+        z = (centers[torch.randint(0, 2000, (cnt,), generator=g, device=dev)] + 0.35 * torch.randn((cnt, idim), generator=g, device=dev)) * spec
+        v = z @ W + 0.02 * torch.randn((cnt, dim), generator=g, device=dev) * float(spec.norm()) / np.sqrt(dim)
+        return v / v.norm(dim=1, keepdim=True)
+    x = torch.empty((n, dim), device=dev)
+    for r0 in range(0, n, 250_000):
+        x[r0:r0 + 250_000] = draw(min(250_000, n - r0))
+    q = draw(nq)
+    iters = a.recall_iters
+    pick = torch.randperm(n, generator=g, device=dev)
+    ivf_rows = x[pick[:min(n, 256 * nlist)].sort().values].contiguous()
+    init = ivf_rows[torch.randperm(ivf_rows.shape[0], generator=g, device=dev)[:nlist].sort().values].contiguous()
+    torch.cuda.synchronize()
+    cen, _ = lancedb_amd.kmeans_train(ivf_rows, init, metric="cosine", iters=iters)
+    pq_rows = x[pick[:min(n, 256 * 256)].sort().values].contiguous()
+    torch.cuda.synchronize()
+    resid, _ = lancedb_amd.ivf_residuals(pq_rows, cen, metric="cosine")
+    seeds = resid[torch.randperm(resid.shape[0], generator=g, device=dev)[:256].sort().values]
+    cb0 = seeds.reshape(256, m, dsub).permute(1, 0, 2).contiguous()
+    torch.cuda.synchronize()
+    codebook = lancedb_amd.pq_train(resid, cb0, metric="cosine", iters=iters)
+    torch.cuda.synchronize()
+    del ivf_rows, pq_rows, resid
+    part_offsets, codes, order = lancedb_amd.ivfpq_encode(x, cen, codebook, metric="cosine")
+    xs = x[order].contiguous()
+    torch.cuda.synchronize()
+    ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes, order, raw_vectors=xs, metric="cosine")
+    fl = lancedb_amd.FlatIndex(x.contiguous())
+    hq = q.cpu().numpy()
+    from lancedb_amd import _abi
+    truth = fl.search(hq, k=10, metric=_abi.METRIC_COSINE).rowids
+    del fl
+
+    def rec(ids):
+        return round(float(np.mean([len(set(truth[i].tolist()) & set(ids[i].tolist())) / 10.0 for i in range(nq)])), 4)
+    out = {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "metric": "cosine", "queries": nq, "intrinsic_dim": idim,
+           "truth": "exact flat cosine search (engine flat path)"}
+    sweep = {}
+    for nprobe in (4, 16, 64):
+        for rf in (0, 5, 10, 25):
+            got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+            sweep[f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")] = rec(got.rowids)
+    out["recall_at_10"] = sweep
+    if a.cpu_seconds > 0:  # one operating point against the oracle, row for row
+        from oracle import oracle as orc
+        orc.build()
+        ox = orc.OracleIndex(cen.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
+                             order.cpu().numpy().astype(np.uint64), raw_vectors=xs.cpu().numpy(), metric="cosine")
+        sub = hq[:512]
+        got = ix.search(sub, k=10, nprobe_min=16, nprobe_max=16, refine_factor=10)
+        o_ids, o_d, _, _ = ox.search(sub, k=10, nprobe_min=16, nprobe_max=16, refine_factor=10)
+        out["nprobe16_refine10_rowids_bit_exact_512_queries"] = bool((o_ids == got.rowids).all())
+        out["nprobe16_refine10_distances_equal_512_queries"] = bool((o_d == got.distances).all())
+        ox.close()
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 

@@ -103,5 +103,47 @@ class DeviceArray:
             pass
 
 
+class HostMappedArray:
+    """A caller-owned host array, page-locked and mapped into the device's address space
+    (hipHostRegister, mapped): `data_ptr()` is the DEVICE view, so the array can be handed to
+    `IvfPqIndex.attach_raw_vectors` — the refine kernel then gathers its k * refine_factor rows
+    per query over PCIe while the codes stay in HBM (C5: 100 M x 1536 raw vectors are 307 GB).
+    The numpy array must outlive this object; `close()` (or the finaliser) unlocks the pages."""
+    is_cuda = True
+
+    def __init__(self, array, device=0):
+        a = np.ascontiguousarray(array)
+        if a is not array and a.base is not array:
+            raise ValueError("HostMappedArray needs a C-contiguous array (it maps the caller's own pages)")
+        self.host, self.shape, self.dtype, self.device, self.nbytes = a, a.shape, a.dtype, device, a.nbytes
+        rt = runtime()
+        rt.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+        rt.hipHostGetDevicePointer.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint]
+        rt.hipHostUnregister.argtypes = [C.c_void_p]
+        _check(rt.hipSetDevice(C.c_int(device)), "hipSetDevice")
+        self._hp = C.c_void_p(a.ctypes.data)
+        _check(rt.hipHostRegister(self._hp, C.c_size_t(a.nbytes), C.c_uint(2)), f"hipHostRegister({a.nbytes} B, mapped)")
+        self._dp = C.c_void_p()
+        err = rt.hipHostGetDevicePointer(C.byref(self._dp), self._hp, C.c_uint(0))
+        if err != 0:
+            rt.hipHostUnregister(self._hp)
+            self._hp = None
+            _check(err, "hipHostGetDevicePointer")
+
+    def data_ptr(self):
+        return self._dp.value or 0
+
+    def close(self):
+        if getattr(self, "_hp", None):
+            runtime().hipHostUnregister(self._hp)
+            self._hp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def synchronize():
     _check(runtime().hipDeviceSynchronize(), "hipDeviceSynchronize")

@@ -206,7 +206,8 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
       }
       gemm_blocks = std::min(gemm_blocks, slots);
     }
-    const size_t gemm_lds = (size_t)2 * (BM + BN) * FG_BK * 2;
+    // the 8-phase kernel keeps the epilogue's operands (|v|^2, qa, qg of the tile: 3 KiB) behind the stage buffers
+    const size_t gemm_lds = (size_t)2 * (BM + BN) * FG_BK * 2 + (oct ? 3072u : 0u);
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \
     if (oct) {                                                                                      \

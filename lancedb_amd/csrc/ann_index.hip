@@ -153,7 +153,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->cbT,       &ix->order,  &ix->xcd_first, &ix->p_cnt,  &ix->p_off,
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
-                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows};
+                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -162,6 +162,7 @@ static int32_t index_free(mi355_index* ix) {
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   if (ix->raw_mapped_host) hostmap_release(ix->raw_mapped_host);
   if (ix->xdone) (void)hipEventDestroy(ix->xdone);
+  if (ix->h_pin) (void)hipHostFree(ix->h_pin);
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
   delete ix;
   return MI355_OK;
@@ -184,7 +185,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   hipStream_t st = ix->stream;
   const uint32_t nlist = d->nlist, m = d->m, mb = ix->mb, cb_entries = 1u << d->nbits;
   for (DevBuf* b : {&ix->w_q, &ix->w_qp, &ix->w_qq, &ix->w_coarse, &ix->w_probes, &ix->w_cand, &ix->w_ids, &ix->w_dist,
-                    &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr,
+                    &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr, &ix->w_ccnt,
                     &ix->w_filter, &ix->w_probes64, &ix->w_spill})
     b->gen = &ix->ws_gen;  // a re-allocation of any of these invalidates the cached hipGraphs
 
@@ -367,14 +368,14 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     xcd_first[8] = nlist;
     ST_TRY(ix->order.ensure(sizeof(uint32_t) * nlist));
     ST_TRY(ix->xcd_first.ensure(sizeof(uint32_t) * 9));
-    ST_TRY(ix->p_cnt.ensure(sizeof(uint32_t) * nlist));
-    ST_TRY(ix->p_off.ensure(sizeof(uint32_t) * nlist));
-    ST_TRY(ix->p_fill.ensure(sizeof(uint32_t) * nlist));
+    ST_TRY(ix->p_cnt.ensure(sizeof(uint32_t) * 2 * nlist));  // two item classes per partition (PlanArgs::best_first)
+    ST_TRY(ix->p_off.ensure(sizeof(uint32_t) * 2 * nlist));
+    ST_TRY(ix->p_fill.ensure(sizeof(uint32_t) * 2 * nlist));
     ST_TRY(ix->q_start.ensure(sizeof(uint32_t) * 16));
     ST_TRY(ix->heads.ensure(sizeof(uint32_t) * 8 * SK_HEAD_STRIDE));
     HIP_TRY(hipMemcpyAsync(ix->order.p, order.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ix->xcd_first.p, xcd_first.data(), sizeof(uint32_t) * 9, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ix->p_cnt.p, 0, sizeof(uint32_t) * nlist, st));
+    HIP_TRY(hipMemsetAsync(ix->p_cnt.p, 0, sizeof(uint32_t) * 2 * nlist, st));
     HIP_TRY(hipStreamSynchronize(st));  // host vectors above go out of scope
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
@@ -589,6 +590,19 @@ extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) {
   return MI355_OK;
 }
 
+#ifdef MI355_DEV_COUNTERS
+// dev builds only (never in the product library): the scan's phase ticks and selection counters
+extern "C" int32_t mi355_dev_counters(mi355_index* ix, uint32_t* out8, int32_t reset) {
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  DevCtl h;
+  HIP_TRY(hipMemcpy(&h, ix->w_ctl.p, sizeof h, hipMemcpyDeviceToHost));
+  memcpy(out8, h.dev, sizeof h.dev);
+  if (reset) HIP_TRY(hipMemset(ix->w_ctl.as<DevCtl>()->dev, 0, sizeof h.dev));
+  return MI355_OK;
+}
+#endif
+
 // ------------------------------------------------------------------ search --
 int32_t validate_params(const mi355_search_params* p) {
   if (!p) return fail(MI355_ERR_INVALID_INPUT, "params is NULL");
@@ -687,7 +701,16 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     slice = std::max((ix->max_len + want - 1) / want, nt * vpt);
   }
   slice = (slice + 15u) & ~15u;
-  const uint32_t n_slices = skew ? 1u : std::max(1u, (ix->max_len + slice - 1) / slice);
+  // the production scan slices by tile positions instead (SkewArgs::n_slices): only when the batch cannot
+  // give every CU a work item, and never below ~2 k rows per slice (each slice rebuilds the distance table)
+  uint32_t sk_slices = 1;
+  if (skew) {
+    const uint64_t pairs = (uint64_t)nq * nprobe;
+    if (pairs && pairs * 2 <= ix->n_cus) sk_slices = (uint32_t)std::min<uint64_t>(8, ix->n_cus / pairs);
+    sk_slices = std::max(1u, std::min(sk_slices, ix->max_len / 2048u));
+    if (pl.kk > 256u) sk_slices = 1;  // (multi-pass selection re-scans per pass: keep whole partitions)
+  }
+  const uint32_t n_slices = skew ? sk_slices : std::max(1u, (ix->max_len + slice - 1) / slice);
 
   // chunk the batch so the workspace stays bounded
   const size_t spill_per_item = (size_t)(ix->m - m_lds) * 1024;  // table tail of one work item (k_scan_pair SPILL)
@@ -696,8 +719,9 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / std::max<size_t>(per_q, 1)));
   chunk = std::min(chunk, 65535u);  // grid.z limit
   if (skew) {
-    ST_TRY(ix->items.ensure(sizeof(SkewItem) * (size_t)chunk * nprobe));
+    ST_TRY(ix->items.ensure(sizeof(SkewItem) * (size_t)chunk * nprobe * n_slices));
     ST_TRY(ix->qthr.ensure(sizeof(uint32_t) * chunk));
+    ST_TRY(ix->w_ccnt.ensure(sizeof(uint32_t) * (size_t)chunk * nprobe * n_slices));
   }
   ST_TRY(ix->w_qp.ensure(sizeof(float) * (size_t)chunk * ix->dim));
   ST_TRY(ix->w_qq.ensure(sizeof(float) * chunk));
@@ -771,9 +795,15 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       pa.lrow0 = view.lrow0;
       pa.grow0 = view.grow0;
       pa.code_off = view.code_off;
-      pa.cand = ix->w_cand.as<Cand>();
+      pa.cand_cnt = ix->w_ccnt.as<uint32_t>();
       pa.kk = pl.kk;
       pa.nprobe = nprobe;
+      // every query's nearest partition first: its kk-th best bounds the other partitions' admissions
+      // (measured: scan -3 % at kk = 10, -5 % at kk = 64, -38 % at kk = 250 together with the block merge,
+      // profiles/r03_g_*); an external probe list has its nearest partition at rank 0 when it comes from the
+      // sharded coarse merge, otherwise rank 0 is just the caller's first probe
+      pa.best_first = (pl.kk >= dev_knob("MI355_BEST_FIRST_MIN_KK", 1) && nprobe > 1u) ? 1u : 0u;
+      pa.n_slices = n_slices;
       pa.act = act;
       const uint32_t pb = (pa.n_pairs + 255) / 256;
       HIP_TRY(hipMemsetAsync(ix->qthr.p, 0xFF, sizeof(uint32_t) * n, st));
@@ -795,9 +825,11 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ka.range = pl.range;
       ka.filter = pl.filter;
       ka.cand = ix->w_cand.as<Cand>();
+      ka.cand_cnt = ix->w_ccnt.as<uint32_t>();
+      ka.n_slices = n_slices;
       ka.dbg = dev_knob("MI355_DBG_SKIP", 0);
       ka.ctl = d_ctl;
-      const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(ix->n_cus, (uint64_t)n * nprobe);
+      const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(ix->n_cus, (uint64_t)n * nprobe * n_slices);
       ST_TRY(launch_scan_skew(ka, ix->m, std::max(n_blocks, 1u), ix->dim, pl.kk, st));
     } else {
       ScanArgs sa;
@@ -823,6 +855,11 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     MergeArgs ma = merge_args_dense(ix->w_cand.as<Cand>(), nprobe * n_slices, pl.kk, n, pl.k);
     ma.ctl = d_ctl;
     ma.act = act;
+    if (skew) {  // the scan's work items report how many of their kk slots they filled ([query][probe rank])
+      ma.src_cnt = ix->w_ccnt.as<uint32_t>();
+      ma.cnt_stride = 1;
+      ma.cnt_q_stride = nprobe * n_slices;
+    }
     if (pl.out_cand) {
       // sharded search: the kk best ANN records of this shard; refine runs after the cross-rank merge
       ma.k_out = pl.kk;
@@ -873,9 +910,9 @@ static int32_t launch_sequence(mi355_index* ix, const float* d_q, uint32_t nq, c
                                float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann, uint32_t timeout_ms) {
   hipStream_t st = ix->stream;
   DevCtl* ctl = ix->w_ctl.as<DevCtl>();
-  if ((ix->profile & MI355_PROFILE_MASK) != 2)  // 2 = cumulative: the row counter runs until the next configure()
-    HIP_TRY(hipMemsetAsync(ctl, 0, DEVCTL_COUNTER_BYTES, st));
-  hipLaunchKernelGGL(k_arm_deadline, dim3(1), dim3(1), 0, st, ctl, (unsigned long long)timeout_ms * ix->wall_khz);
+  // (profile 2 = cumulative: the row counter runs until the next configure())
+  hipLaunchKernelGGL(k_arm_deadline, dim3(1), dim3(1), 0, st, ctl, (unsigned long long)timeout_ms * ix->wall_khz,
+                     (ix->profile & MI355_PROFILE_MASK) != 2 ? 1u : 0u);
   HIP_TRY(hipGetLastError());
   return run_ivfpq(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann);
 }
@@ -1070,21 +1107,51 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   uint64_t* d_ids = calls[0].out_rowids;
   float* d_dist = calls[0].out_dist;
   uint32_t* d_cnt = calls[0].out_counts;
+  // Small host batches (the latency path) travel through ONE page-locked staging block of the handle:
+  // pageable hipMemcpyAsync stages (and, device-to-host, blocks) per call — four round trips for the
+  // results of a single query.  Here: one H2D of the queries, the three result arrays carved out of one
+  // device buffer and copied back by one D2H (+ the 64-byte control word), one synchronisation.
+  const size_t q_bytes = sizeof(float) * (size_t)n_queries * ix->dim;
+  const size_t r_bytes = (size_t)n_queries * k * (sizeof(uint64_t) + sizeof(float)) + sizeof(uint32_t) * (size_t)n_queries;
+  const bool pinned = host_io && q_bytes + r_bytes <= ((size_t)4 << 20);
+  unsigned char* h_pin = nullptr;
   if (host_io) {
-    ST_TRY(ix->w_q.ensure(sizeof(float) * (size_t)n_queries * ix->dim));
-    ST_TRY(ix->w_ids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
-    ST_TRY(ix->w_dist.ensure(sizeof(float) * (size_t)n_queries * k));
-    ST_TRY(ix->w_cnt.ensure(sizeof(uint32_t) * n_queries));
-    uint32_t off = 0;
-    for (const SearchCall& c : calls) {
-      HIP_TRY(hipMemcpyAsync(ix->w_q.as<float>() + (size_t)off * ix->dim, c.queries, sizeof(float) * (size_t)c.nq * ix->dim,
-                             hipMemcpyHostToDevice, st));
-      off += c.nq;
+    ST_TRY(ix->w_q.ensure(q_bytes));
+    if (pinned) {
+      const size_t need = q_bytes + r_bytes + sizeof(DevCtl) + 64;
+      if (ix->h_pin_cap < need) {
+        if (ix->h_pin) (void)hipHostFree(ix->h_pin);
+        ix->h_pin = nullptr;
+        ix->h_pin_cap = 0;
+        HIP_TRY(hipHostMalloc(&ix->h_pin, need * 2, hipHostMallocDefault));
+        ix->h_pin_cap = need * 2;
+      }
+      h_pin = (unsigned char*)ix->h_pin;
+      ST_TRY(ix->w_ids.ensure(r_bytes));
+      size_t off = 0;
+      for (const SearchCall& c : calls) {
+        memcpy(h_pin + off, c.queries, sizeof(float) * (size_t)c.nq * ix->dim);
+        off += sizeof(float) * (size_t)c.nq * ix->dim;
+      }
+      HIP_TRY(hipMemcpyAsync(ix->w_q.p, h_pin, q_bytes, hipMemcpyHostToDevice, st));
+      d_ids = ix->w_ids.as<uint64_t>();
+      d_dist = (float*)(d_ids + (size_t)n_queries * k);
+      d_cnt = (uint32_t*)(d_dist + (size_t)n_queries * k);
+    } else {
+      ST_TRY(ix->w_ids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
+      ST_TRY(ix->w_dist.ensure(sizeof(float) * (size_t)n_queries * k));
+      ST_TRY(ix->w_cnt.ensure(sizeof(uint32_t) * n_queries));
+      uint32_t off = 0;
+      for (const SearchCall& c : calls) {
+        HIP_TRY(hipMemcpyAsync(ix->w_q.as<float>() + (size_t)off * ix->dim, c.queries, sizeof(float) * (size_t)c.nq * ix->dim,
+                               hipMemcpyHostToDevice, st));
+        off += c.nq;
+      }
+      d_ids = ix->w_ids.as<uint64_t>();
+      d_dist = ix->w_dist.as<float>();
+      d_cnt = ix->w_cnt.as<uint32_t>();
     }
     d_q = ix->w_q.as<float>();
-    d_ids = ix->w_ids.as<uint64_t>();
-    d_dist = ix->w_dist.as<float>();
-    d_cnt = ix->w_cnt.as<uint32_t>();
   }
   SearchPlan pl;
   pl.k = k;
@@ -1123,16 +1190,35 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   if (sh.np_max > sh.np_min) ST_TRY(expand_short_queries(ix, d_q, n_queries, pl, sh.np_max, d_ids, d_dist, d_cnt, d_cnt_ann));
 
   if (host_io) {
-    uint32_t off = 0;
-    for (const SearchCall& c : calls) {
-      HIP_TRY(hipMemcpyAsync(c.out_rowids, d_ids + (size_t)off * k, sizeof(uint64_t) * (size_t)c.nq * k, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(c.out_dist, d_dist + (size_t)off * k, sizeof(float) * (size_t)c.nq * k, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(c.out_counts, d_cnt + off, sizeof(uint32_t) * c.nq, hipMemcpyDeviceToHost, st));
-      off += c.nq;
-    }
     DevCtl h_ctl;
-    HIP_TRY(hipMemcpyAsync(&h_ctl, ix->w_ctl.p, sizeof(DevCtl), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (pinned) {
+      unsigned char* h_res = h_pin + q_bytes;
+      DevCtl* h_c = (DevCtl*)(h_pin + ((q_bytes + r_bytes + 63) & ~(size_t)63));
+      HIP_TRY(hipMemcpyAsync(h_res, d_ids, r_bytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_c, ix->w_ctl.p, sizeof(DevCtl), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      h_ctl = *h_c;
+      const uint64_t* r_ids = (const uint64_t*)h_res;
+      const float* r_dist = (const float*)(r_ids + (size_t)n_queries * k);
+      const uint32_t* r_cnt = (const uint32_t*)(r_dist + (size_t)n_queries * k);
+      uint32_t off = 0;
+      for (const SearchCall& c : calls) {
+        memcpy(c.out_rowids, r_ids + (size_t)off * k, sizeof(uint64_t) * (size_t)c.nq * k);
+        memcpy(c.out_dist, r_dist + (size_t)off * k, sizeof(float) * (size_t)c.nq * k);
+        memcpy(c.out_counts, r_cnt + off, sizeof(uint32_t) * c.nq);
+        off += c.nq;
+      }
+    } else {
+      uint32_t off = 0;
+      for (const SearchCall& c : calls) {
+        HIP_TRY(hipMemcpyAsync(c.out_rowids, d_ids + (size_t)off * k, sizeof(uint64_t) * (size_t)c.nq * k, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(c.out_dist, d_dist + (size_t)off * k, sizeof(float) * (size_t)c.nq * k, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(c.out_counts, d_cnt + off, sizeof(uint32_t) * c.nq, hipMemcpyDeviceToHost, st));
+        off += c.nq;
+      }
+      HIP_TRY(hipMemcpyAsync(&h_ctl, ix->w_ctl.p, sizeof(DevCtl), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
     ix->stats.timed_out = h_ctl.timed_out;
     ix->stats.bad_probes = h_ctl.bad_probes;
     // ids outside 0..nlist-1 are a caller error: report instead of returning a partial scan

@@ -190,13 +190,15 @@ struct mi355_index {
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2, w_dist2, w_cnt2, w_ctl,
-      w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann, w_spill, w_srows;
+      w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann, w_spill, w_srows, w_ccnt;
   uint32_t ws_gen = 0;  // bumped by every workspace re-allocation
   uint32_t second_np = 0;  // nprobe of the last maximum_nprobes second pass (stats: DevCtl.short_queries x this)
   // overlapped sharded search (ann_comm.hip): the exchange of the last call may still run on the
   // communicator's stream; `xdone` is recorded behind it and every other entry point joins it first
   hipEvent_t xdone = nullptr;
   bool xpending = false;
+  void* h_pin = nullptr;  // page-locked staging block of small host-I/O batches (queries in, results out)
+  size_t h_pin_cap = 0;
   // config
   uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
   bool use_graph = false, coalesce = true;  // graph replay measured slower than eager launches

@@ -32,7 +32,7 @@ struct DevCtl {
   unsigned long long deadline;      // wall_clock64() value after which kernels stop; 0 = none
   uint32_t timed_out;
   uint32_t bad_probes;              // probe ids outside 0..nlist-1 (mi355_search_probes)
-  uint32_t pad[8];
+  uint32_t dev[8];                  // -DMI355_DEV_COUNTERS builds only: per-phase ticks / selection counters of the scan
 };
 #define DEVCTL_COUNTER_BYTES 16u
 
@@ -48,9 +48,14 @@ __device__ __forceinline__ bool ctl_expired(DevCtl* ctl) {
 }
 
 // first kernel of a call with a timeout: deadline = now + ticks of the constant-rate device clock
-static __global__ void k_arm_deadline(DevCtl* ctl, unsigned long long ticks) {
+// (`reset_counters`: also zero the per-call counters — one launch instead of a memset and a launch)
+static __global__ void k_arm_deadline(DevCtl* ctl, unsigned long long ticks, uint32_t reset_counters = 0) {
   ctl->deadline = ticks ? (unsigned long long)wall_clock64() + ticks : 0ull;
   ctl->timed_out = 0;
+  if (reset_counters) {
+    ctl->rows_scanned = 0ull;
+    ctl->short_queries = 0u;
+  }
 }
 
 // Correctly rounded sqrt / divide.  NOT __fsqrt_rn / __fdiv_rn: without

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BM = 256, BN = 256, MI = 8, NI = 4, WN = 4;
   constexpr int A_BYTES = BM * FG_BK * 2, B_BYTES = BN * FG_BK * 2, BUF = A_BYTES + B_BYTES;
+  // behind the two stage buffers: the epilogue's operands of the current tile, |v|^2 [256] | qa [256] | qg [256] f32
+  constexpr int EPI_OFF = 2 * BUF;
   static_assert(FG_BK == 64, "128-B LDS rows");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,6 +173,22 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     return true;
   };
 
+  // The epilogue's operands travel the same way as the tiles: three 1-KiB LDS-DMA pieces (waves 0-2,
+  // one each) issued in the tile's LAST k-tile at q3, i.e. BEFORE the two half-tiles that q4's counted
+  // wait leaves in flight — that wait retires them for free and the epilogue runs on ds_reads alone.
+  // (With plain loads the epilogue's first use forced s_waitcnt vmcnt(0): vmcnt retires in order, so
+  // it drained the next tile's prefetched stages, and every 32-row group paid an L2 round trip behind
+  // the previous group's stores — four serial round trips per tile with the matrix pipe idle.)
+  auto stage_epi = [&](const TileRef& t) {
+    if (FG_ABL(1) && abl_dma_off) return;
+    if (wid == 0)
+      fg_glds16(a.vv + t.row0 + (uint32_t)lane * 4u, smem + EPI_OFF);
+    else if (wid == 1)
+      fg_glds16(a.qa + t.q0 + (uint32_t)lane * 4u, smem + EPI_OFF + 1024);
+    else if (wid == 2)
+      fg_glds16(a.qg + t.q0 + (uint32_t)lane * 4u, smem + EPI_OFF + 2048);
+  };
+
   fg_f32x4 acc[MI][NI];
   // one phase's 16 MFMAs (rows mi0..mi0+3, queries ni0..ni0+1, both k-halves)
   auto mfma_block = [&](const fg_bf16x8 (&fa)[2][MI], const fg_bf16x8 (&fb)[2][NI], int mi0, int ni0) {
@@ -209,19 +227,35 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
 
   // ---- epilogue of one finished tile (reads acc)
   auto epilogue = [&](const TileRef& t) {
+    // operands from the EPI region by inline-asm ds_reads: hipcc orders a plain LDS read behind every
+    // LDS-DMA in flight with s_waitcnt vmcnt(0) (it cannot know the DMA targets another region), which
+    // would drain the next tile's stages here; the pieces that filled the region were retired by q4's
+    // counted wait a barrier ago
+    const uint32_t ebase = (uint32_t)(size_t)smem + EPI_OFF;
     float qa[NI], qg[NI];
+    fg_f32x4 vvq[MI / 2][2];
+    {
+      const uint32_t aq = ebase + 1024u + (wc * NI * 16 + fr) * 4u;
+      const uint32_t av = ebase + (wr * MI * 16 + fk * 4) * 4u;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const uint32_t n = t.q0 + wc * NI * 16 + ni * 16 + fr;
-      qa[ni] = a.qa[n];
-      qg[ni] = a.qg[n];
+      for (int ni = 0; ni < NI; ++ni) {
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(qa[ni]) : "v"(aq), "n"(ni * 64));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(qg[ni]) : "v"(aq), "n"(1024 + ni * 64));
+      }
+#pragma unroll
+      for (int g = 0; g < MI / 2; ++g) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vvq[g][0]) : "v"(av), "n"(g * 128));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vvq[g][1]) : "v"(av), "n"(g * 128 + 64));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
     const bool full = t.lim == (uint32_t)(BM - 1);  // wave-uniform
 #pragma unroll
     for (int g = 0; g < MI / 2; ++g) {  // the wave's groups of 32 rows (two MFMA row tiles each)
       const uint64_t rg = t.row0 + wr * MI * 16 + g * 32 + fk * 4;
-      const float4 va = *(const float4*)(a.vv + rg), vb4 = *(const float4*)(a.vv + rg + 16);
-      const float vvr[2][4] = {{va.x, va.y, va.z, va.w}, {vb4.x, vb4.y, vb4.z, vb4.w}};
+      const float vvr[2][4] = {{vvq[g][0][0], vvq[g][0][1], vvq[g][0][2], vvq[g][0][3]},
+                               {vvq[g][1][0], vvq[g][1][1], vvq[g][1][2], vvq[g][1][3]}};
       float outv[NI];
       if (EPI == 0 || !full) {
         // k_flat_gemm's arithmetic, element by element (also the ragged last row tile of EPI = 1)
@@ -386,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
     }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (u + 1 == KT) stage_epi(cur);  // older than everything q4's wait leaves in flight
     (void)stage_ahead(true, 0, u, 2, par);
     asm volatile("" ::: "memory");
     FG_BARRIER();

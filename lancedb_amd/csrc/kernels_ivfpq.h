@@ -288,8 +288,8 @@ static __global__ __launch_bounds__(256) void k_select_probes(
     const uint32_t* __restrict__ plen, uint32_t* __restrict__ probes /*[nq, nprobe]*/,
     unsigned long long* __restrict__ stat_rows, ActiveMask act = ActiveMask()) {
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_need, s_less, s_wave_cnt[4], s_running;
-  __shared__ unsigned long long s_rows;
+  __shared__ uint32_t s_prefix, s_need, s_less, s_wave_cnt[4], s_running, s_best_at;
+  __shared__ unsigned long long s_rows, s_best;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t b = blockIdx.x;
   const float* src = coarse + (size_t)b * nlist;
@@ -301,6 +301,8 @@ static __global__ __launch_bounds__(256) void k_select_probes(
     s_less = 0;
     s_running = 0;
     s_rows = 0;
+    s_best = ~0ull;
+    s_best_at = 0;
   }
   uint32_t mask = 0;
   for (int byte = 3; byte >= 0; --byte) {
@@ -336,6 +338,7 @@ static __global__ __launch_bounds__(256) void k_select_probes(
     if (less) {
       out[atomicAdd(&s_less, 1u)] = p;
       rows += plen[p];
+      atomicMin(&s_best, ((unsigned long long)key << 32) | p);
     }
     // ordered rank among the equal keys (ascending partition id)
     uint64_t bal = __ballot(eq);
@@ -347,6 +350,7 @@ static __global__ __launch_bounds__(256) void k_select_probes(
     if (eq && rank < need_eq) {
       out[n_less + rank] = p;
       rows += plen[p];
+      atomicMin(&s_best, ((unsigned long long)key << 32) | p);
     }
     __syncthreads();
     if (tid == 0) s_running = base + s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
@@ -355,6 +359,20 @@ static __global__ __launch_bounds__(256) void k_select_probes(
   if (rows) atomicAdd(&s_rows, rows);
   __syncthreads();
   if (tid == 0 && stat_rows) atomicAdd(stat_rows, s_rows);
+  // The NEAREST partition (ties: lowest id) moves to rank 0 — the order of the other ranks stays
+  // arbitrary.  The scan's planner can then run every query's nearest partition first
+  // (PlanArgs::best_first), so the query's distance bound exists before its other partitions are
+  // scanned; the result set does not depend on the order.
+  if (nprobe > 1) {
+    const uint32_t best = (uint32_t)s_best;
+    for (uint32_t i = tid; i < nprobe; i += 256)
+      if (out[i] == best) s_best_at = i;
+    __syncthreads();
+    if (tid == 0 && s_best_at != 0) {
+      out[s_best_at] = out[0];
+      out[0] = best;
+    }
+  }
 }
 
 // two-phase search helpers (mi355_coarse_topn / mi355_search_probes)
@@ -708,6 +726,8 @@ struct MergeArgs {
   const uint32_t* src_cnt;  // valid entries per (source, query) at src_cnt[s * cnt_stride + b], or nullptr
                             // (= kk_in, empties marked by pos)
   uint64_t cnt_stride;      // u32 words between two sources' count arrays
+  uint64_t cnt_q_stride;    // u32 words between two queries' counts of one source (1: [source][query] arrays;
+                            // the scan's per-item counts are [query][source]: cnt_stride 1, cnt_q_stride n_src)
   uint32_t nq;
   uint32_t k_out;     // rows written per query (k, or k*refine_factor)
   uint64_t* out_ids;  // [nq, k_out] or nullptr
@@ -730,6 +750,7 @@ static inline MergeArgs merge_args_dense(const Cand* cand, uint32_t n_src, uint3
   m.q_stride = (uint64_t)n_src * kk_in;
   m.src_cnt = nullptr;
   m.cnt_stride = nq;
+  m.cnt_q_stride = 1;
   m.nq = nq;
   m.k_out = k_out;
   m.out_ids = nullptr;
@@ -771,6 +792,27 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
   }
   // `pos` travels through the selector as the candidate's slot index t (source = t / kk_in)
   auto gen = [&](WaveTopK<KPL>& top) {
+    if (a.src_cnt && a.kk_in > 32u) {
+      // long lists with counts: walk source by source and read only the filled part (with a query bound in
+      // place most of a scan's work items return a handful of rows, or none, in their kk slots)
+      for (uint32_t sidx = 0; sidx < a.n_src; ++sidx) {
+        const uint32_t lim = min(a.src_cnt[(size_t)sidx * a.cnt_stride + (size_t)b * a.cnt_q_stride], a.kk_in);
+        for (uint32_t i0 = 0; i0 < lim; i0 += MI355_WAVE) {
+          const uint32_t i = i0 + lane;
+          Cand c;
+          c.d = 0.f;
+          c.pos = CAND_EMPTY_POS;
+          c.id = 0;
+          bool ok = false;
+          if (i < lim) {
+            c = src[(size_t)sidx * a.src_stride + i];
+            ok = c.pos != CAND_EMPTY_POS && c.d == c.d;
+          }
+          top.offer(ok, c.d, sidx * a.kk_in + i, c.id, lane);
+        }
+      }
+      return;
+    }
     for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
       const uint32_t t = t0 + lane;
       Cand c;
@@ -780,7 +822,7 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
       bool ok = false;
       if (t < n) {
         const uint32_t sidx = t / a.kk_in, i = t % a.kk_in;
-        const uint32_t lim = a.src_cnt ? min(a.src_cnt[(size_t)sidx * a.cnt_stride + b], a.kk_in) : a.kk_in;
+        const uint32_t lim = a.src_cnt ? min(a.src_cnt[(size_t)sidx * a.cnt_stride + (size_t)b * a.cnt_q_stride], a.kk_in) : a.kk_in;
         if (i < lim) {
           c = src[(size_t)sidx * a.src_stride + i];
           ok = c.pos != CAND_EMPTY_POS && c.d == c.d;

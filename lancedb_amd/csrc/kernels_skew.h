@@ -226,45 +226,68 @@ struct PlanArgs {
   const uint32_t* plen;     // [nlist]
   const uint32_t* order;    // [nlist] static partition order
   const uint32_t* xcd_first;  // [9] index into order where queue x starts
-  uint32_t* cnt;            // [nlist] (zeroed by k_plan_scan for the next batch)
-  uint32_t* off;            // [nlist]
-  uint32_t* fill;           // [nlist]
+  uint32_t* cnt;            // [2 * nlist] (zeroed by k_plan_scan for the next batch); second half: class "nearest"
+  uint32_t* off;            // [2 * nlist]
+  uint32_t* fill;           // [2 * nlist]
   uint32_t* q_start;        // [9]
   uint32_t* heads;          // [8 * SK_HEAD_STRIDE]
   SkewItem* items;          // [n_pairs]
   const uint32_t* lrow0;    // [nlist]
   const uint64_t* grow0;    // [nlist]
   const uint64_t* code_off; // [nlist]
-  Cand* cand;               // [n_pairs][kk]
+  uint32_t* cand_cnt;       // [n_pairs] rows each work item left in its kk candidate slots (0 until it ran)
   uint32_t kk;
   uint32_t nprobe;          // pairs per query (for the mask)
+  // 1: every queue runs the (query, NEAREST partition) items first — probe rank 0 of every query,
+  // k_select_probes puts the nearest partition there — and the partition-major rest behind them.  The
+  // nearest partition's kk-th best is the tightest bound a single partition can give (qthr), so the
+  // other 63 items of a query admit a handful of rows instead of filling their lists: what long
+  // candidate lists cost is selection, and selection work follows the rows admitted.  The price is one
+  // extra, un-shared read of ~one partition per query (+13 % L2 fills at C3, HBM is 15 % busy).
+  uint32_t best_first;
+  uint32_t n_slices;        // work items per pair (SkewArgs::n_slices)
   ActiveMask act;           // device-side batch size: pairs of inactive queries make no item, no slot writes
 };
+
+// work-item class of a pair: 1 = the query's nearest partition under best_first
+__device__ __forceinline__ uint32_t plan_class(const PlanArgs& a, uint32_t i) {
+  return (a.best_first && (i % a.nprobe) == 0u) ? 1u : 0u;
+}
 
 static __global__ void k_plan_count(PlanArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_pairs) return;
   if (!a.act.on(i / a.nprobe)) return;
   const uint32_t p = a.probes[i];
-  if (p < a.nlist && a.plen[p])  // ids outside the index (mi355_search_probes) are empty items
-    atomicAdd(&a.cnt[p], 1u);
-  else {  // empty / not owned here: no work item, the slot is empty
-    Cand c;
-    c.d = __builtin_huge_valf();
-    c.pos = CAND_EMPTY_POS;
-    c.id = ~0ull;
-    for (uint32_t g = 0; g < a.kk; ++g) a.cand[(size_t)i * a.kk + g] = c;
-  }
+  // ids outside the index (mi355_search_probes), empty and not-owned partitions make no work item; a
+  // pair's candidate slots hold cand_cnt[i] rows: 0 until (and unless) its item ran
+  for (uint32_t sl = 0; sl < a.n_slices; ++sl) a.cand_cnt[(size_t)i * a.n_slices + sl] = 0u;
+  if (p < a.nlist && a.plen[p]) atomicAdd(&a.cnt[p + plan_class(a, i) * a.nlist], a.n_slices);
 }
 
-// one 1024-thread block: exclusive scan of cnt[] in `order`
+// one 1024-thread block: exclusive scan of the item counts in queue order.  The virtual sequence is,
+// queue by queue, [class-1 counts of the queue's partitions (best_first only)] [class-0 counts of the
+// same partitions], partitions in the index's static `order`.
 static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
   __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_xf[9];
   const uint32_t tid = threadIdx.x;
-  const uint32_t per = (a.nlist + 1023u) / 1024u;
-  const uint32_t i0 = tid * per, i1 = sk_min_u32(a.nlist, i0 + per);
+  const uint32_t ncls = a.best_first ? 2u : 1u;
+  const uint32_t nv = ncls * a.nlist;
+  if (tid < 9) s_xf[tid] = a.xcd_first[tid];
+  __syncthreads();
+  // virtual index -> key into cnt / off / fill (partition + class * nlist)
+  auto key_of = [&](uint32_t v) -> uint32_t {
+    uint32_t x = 0;
+    for (uint32_t y = 1; y < 8; ++y) x += (v >= ncls * s_xf[y]) ? 1u : 0u;  // queue of v (empty queues are skipped over)
+    const uint32_t len = s_xf[x + 1] - s_xf[x], r = v - ncls * s_xf[x];
+    const uint32_t cls = (ncls == 2u && r < len) ? 1u : 0u, idx = r < len ? r : r - len;
+    return a.order[s_xf[x] + idx] + cls * a.nlist;
+  };
+  const uint32_t per = (nv + 1023u) / 1024u;
+  const uint32_t i0 = tid * per, i1 = sk_min_u32(nv, i0 + per);
   uint32_t sum = 0;
-  for (uint32_t i = i0; i < i1; ++i) sum += a.cnt[a.order[i]];
+  for (uint32_t i = i0; i < i1; ++i) sum += a.cnt[key_of(i)];
   s_part[tid] = sum;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -275,21 +298,21 @@ static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
   }
   uint32_t run = s_part[tid] - sum;
   for (uint32_t i = i0; i < i1; ++i) {
-    const uint32_t p = a.order[i];
-    const uint32_t c = a.cnt[p];
-    a.off[p] = run;
-    a.fill[p] = 0;
-    a.cnt[p] = 0;
-    // queue boundaries: the first partition of each queue records its offset
+    const uint32_t k = key_of(i);
+    const uint32_t c = a.cnt[k];
+    a.off[k] = run;
+    a.fill[k] = 0;
+    a.cnt[k] = 0;
+    // queue boundaries: the first virtual index of each queue records its offset
     for (uint32_t x = 0; x < 8; ++x)
-      if (a.xcd_first[x] == i) a.q_start[x] = run;
+      if (ncls * s_xf[x] == i) a.q_start[x] = run;
     run += c;
   }
   if (tid == 1023) {
     const uint32_t total = s_part[1023];
     a.q_start[8] = total;
     for (uint32_t x = 0; x < 8; ++x)
-      if (a.xcd_first[x] >= a.nlist) a.q_start[x] = total;
+      if (s_xf[x] >= a.nlist) a.q_start[x] = total;
   }
   if (tid < 8) a.heads[tid * SK_HEAD_STRIDE] = 0;
 }
@@ -308,7 +331,12 @@ static __global__ void k_plan_fill(PlanArgs a) {
   it.lrow0 = a.lrow0[p];
   it.grow0 = a.grow0[p];
   it.code_off = a.code_off[p];
-  a.items[a.off[p] + atomicAdd(&a.fill[p], 1u)] = it;
+  const uint32_t key = p + plan_class(a, i) * a.nlist;
+  const uint32_t at = a.off[key] + atomicAdd(&a.fill[key], a.n_slices);
+  for (uint32_t sl = 0; sl < a.n_slices; ++sl) {
+    it.pair = a.n_slices > 1u ? (i | (sl << 24)) : i;
+    a.items[at + sl] = it;
+  }
 }
 
 // ------------------------------------------------------------------- scan ----
@@ -325,6 +353,12 @@ struct SkewArgs {
   RangeFilter range;
   RowFilter filter;
   Cand* cand;               // [nq * nprobe][kk]
+  uint32_t* cand_cnt;       // [nq * nprobe] rows an item left in its slots (k_merge_cands reads only those)
+  // Latency mode (a batch too small to give every CU a work item): a (query, partition) pair becomes
+  // n_slices work items, slice s scanning tile positions [nt*s/n_slices, nt*(s+1)/n_slices) of every
+  // stream of the partition; each slice builds the distance table again (12 us) and writes its own kk
+  // slots.  > 1: SkewItem::pair carries the slice in its top 8 bits.
+  uint32_t n_slices;
   uint32_t dbg;
   DevCtl* ctl;              // deadline / counters of the call
 };
@@ -376,6 +410,14 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
 // adversarial row order, or hundreds of equal distances) raises `s_ovf`, that pass is discarded
 // and it and all later passes of the item select SK_SAFE_PASS rows each, which fit any list.
 #define SK_SAFE_PASS 128u
+// dev builds (-DMI355_DEV_COUNTERS): thread 0 adds the item's phase times (wall_clock64 ticks) and the
+// selection's counters to DevCtl.dev[]: 0 LUT build, 1 scan, 2 merge (ticks), 3 items, 4 rows in the lists
+// at the merge, 5 optimistic passes redone, 6 ticks wave 0 waited for the slowest wave, 7 rows admitted
+#ifdef MI355_DEV_COUNTERS
+#define SK_DEV(...) __VA_ARGS__
+#else
+#define SK_DEV(...)
+#endif
 template <int M, int LR, int NT, bool MULTI, bool OPT = false>
 __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   static_assert(!OPT || (MULTI && LR * 64 >= (int)SK_SAFE_PASS), "OPT rides on the pass machinery");
@@ -432,7 +474,8 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   // every thread's share of the first residual
   float pre_q[4], pre_c[4];  // up to 4 elements per thread (dim <= 4 * NT, checked at open)
   auto prefetch_res = [&](const SkewItem& it) {
-    const float* q = a.qp + (size_t)(it.pair / a.nprobe) * ix.dim;
+    const uint32_t pr = a.n_slices > 1u ? (it.pair & 0xFFFFFFu) : it.pair;  // (sliced pairs carry the slice on top)
+    const float* q = a.qp + (size_t)(pr / a.nprobe) * ix.dim;
     const float* c = ix.centroids + (size_t)it.part * ix.dim;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -452,15 +495,19 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     const SkewItem* rec = s_rec + slot;
     auto uni32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     auto uni64 = [&](uint64_t v) -> uint64_t { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | (uint64_t)uni32((uint32_t)v); };
-    const uint32_t pair = uni32(rec->pair);
-    if (pair == SK_NONE) break;
+    const uint32_t pair_f = uni32(rec->pair);
+    if (pair_f == SK_NONE) break;
+    const uint32_t pair = a.n_slices > 1u ? (pair_f & 0xFFFFFFu) : pair_f;
+    const uint32_t slice = a.n_slices > 1u ? (pair_f >> 24) : 0u;
+    const uint32_t oslot = pair * a.n_slices + slice;  // candidate slots / count of this work item
     const uint32_t len = uni32(rec->len);
     const uint32_t lrow0 = uni32(rec->lrow0);
     const uint64_t grow0 = uni64(rec->grow0);
     const uint64_t code_off = uni64(rec->code_off);
     const uint32_t b = pair / a.nprobe;
     const uint32_t n_tiles = (len + SK_TILE - 1) / SK_TILE;
-    Cand* out = a.cand + (size_t)pair * a.kk;
+    Cand* out = a.cand + (size_t)oslot * a.kk;
+    SK_DEV(const unsigned long long dv_t0 = wall_clock64(); unsigned long long dv_scan = 0, dv_merge = 0; uint32_t dv_adm = 0;)
 
     // ---- pop the NEXT item now; its index arrives behind the LUT phase's loads
     uint32_t pf = SK_NONE, pf_q0 = 0, pf_n = 0;
@@ -570,15 +617,23 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     }
     __syncthreads();
 
+    SK_DEV(const unsigned long long dv_t1 = wall_clock64();
+           if (tid == 0) { atomicAdd(&a.ctl->dev[0], (uint32_t)(dv_t1 - dv_t0)); atomicAdd(&a.ctl->dev[3], 1u);
+                         })
     // ---- K3 + K4: skewed ADC scan, one stream per wave ----------------------
     auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
     const uint8_t* pcodes = ix.codes + code_off;
     const uint32_t thr0_key = *s_thr;  // the query's bound when this item started (valid for every pass)
     uint32_t pass_rows = SCAN_PASS_ROWS;  // (OPT: optimistic passes of SCAN_PASS_ROWS rows, SK_SAFE_PASS after an overflow)
     bool optimistic = OPT;
+    bool rec_stored = false;   // thread 0: the next item's record reached s_rec from inside its wave's scan
+    bool tail_done = false;    // the next item's residual operands were requested (after its record was popped)
+    bool tail_popped = false;  // the pop half already ran in an optimistic pass that was voided
     for (uint32_t pass_base = 0;; pass_base += pass_rows) {
     const uint32_t kk_pass = MULTI ? min(a.kk - pass_base, pass_rows) : a.kk;
-    const bool last_known = !MULTI;  // single pass: the item's tail work overlaps the merge below
+    // the item's tail work (next item's record + residual operands) overlaps the merge of the pass that
+    // is known to be the last one by its row budget (a voided optimistic pass re-runs; the tail does not)
+    const bool last_known = !tail_done && (!MULTI || pass_base + pass_rows >= a.kk);
     bool fl_on = false;
     float fl_d = 0.f;
     uint64_t fl_id = 0;
@@ -587,6 +642,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       fl_d = s_floor->d;
       fl_id = s_floor->id;
     }
+    SK_DEV(const unsigned long long dv_p0 = wall_clock64();)
     WaveList<LR, QSHARE> wl;
     const uint32_t q_share = (kk_pass + NW - 1) / NW;
     wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass, q_share);
@@ -627,6 +683,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
             }
           }
         }
+        SK_DEV(dv_adm += (uint32_t)__popcll((unsigned long long)__ballot(ok));)
         wl.append(ok, d, lrow0 + row, thr, lane, idof);
         if (wl.t_run < published) {  // a compaction tightened this wave's kk-th best: share it
           published = wl.t_run;
@@ -669,12 +726,18 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         c = sk_min_u32(c, n_chunks - 1);
         sk_load2(ra[slot], rb[slot], src + (size_t)c * 128);
       };
+      // this work item's tile positions of the unit (the whole unit unless the pair is sliced).  A slice that
+      // starts inside the stream meets the tails of tile n0 - 1 in its first steps (they only feed Y, which the
+      // n > n0 test below never consumes) and ends like the stream does: the first two chunks of position n1
+      // hold the tails of tile n1 - 1 (their tile-n1 bytes go to a dummy accumulator)
+      const uint32_t n0 = (uint32_t)((uint64_t)nt * slice / a.n_slices), n1 = (uint32_t)((uint64_t)nt * (slice + 1u) / a.n_slices);
+      if (n0 == n1) continue;
 #pragma unroll
-      for (int g = 0; g < RING; ++g) fetch(g, g);
+      for (int g = 0; g < RING; ++g) fetch(g, n0 * CPT + g);
       sk_f32x2 x = {0.f, 0.f}, y = {0.f, 0.f};
       uint32_t r = lb, r2 = lb;  // [bit 16: slab][byte 1: code][byte 0: column origin]; r2: chain B's copy (nreg=2)
       const uint32_t sa = u * SK_CHAINS, sb = sa + 1;
-      for (uint32_t n = 0; n < nt; ++n) {
+      for (uint32_t n = n0; n < n1; ++n) {
         const uint32_t c0 = n * CPT;
         auto chunks = [&](auto self, auto gtag) -> void {
           constexpr int G = decltype(gtag)::value;
@@ -683,11 +746,14 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
             skew_dchunk<G>(ra[G % RING], rb[G % RING], r, r2, slab_bit, x, y);
             fetch(G % RING, c0 + G + RING);
             if constexpr (G == 1) {
-              if (n > 0) {  // rows of tile position n-1 are complete on every lane after step 30
+              if (n > n0) {  // rows of tile position n-1 are complete on every lane after step 30
                 consume(y.x, sa, n - 1);
                 consume(y.y, sb, n - 1);
               }
-              if (n == 0 && tid == 0 && nxt_valid) s_rec[slot ^ 1u] = nxt;
+              if (n == n0 && tid == 0 && nxt_valid) {
+                s_rec[slot ^ 1u] = nxt;
+                rec_stored = true;
+              }
             }
             self(self, std::integral_constant<int, G + 1>{});
           }
@@ -704,8 +770,8 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         sk_wait_codes<0>(ra[1 % RING], rb[1 % RING]);
         skew_dchunk<0>(ra[0], rb[0], r, r2, slab_bit, dummy, y);
         skew_dchunk<1>(ra[1 % RING], rb[1 % RING], r, r2, slab_bit, dummy, y);
-        consume(y.x, sa, nt - 1);
-        consume(y.y, sb, nt - 1);
+        consume(y.x, sa, n1 - 1);
+        consume(y.y, sb, n1 - 1);
       }
     }
 #else
@@ -731,7 +797,10 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         skew_chunk_split0<0>(cv[0], lb, pb, x, y);
         skew_chunk_split1<64>(cv[1], lb, pb, x, y);
         if (n > 0) consume(y, w, n - 1);  // row n-1 is complete on every lane after step 30
-        if (n == 0 && tid == 0 && nxt_valid) s_rec[slot ^ 1u] = nxt;  // landed long ago; frees its registers
+        if (n == 0 && tid == 0 && nxt_valid) {  // landed long ago; frees its registers
+          s_rec[slot ^ 1u] = nxt;
+          rec_stored = true;
+        }
         skew_plain_chunks<2, CPT>(cv, lb, pb, x, y);
         y = x;
         x = 0.f;
@@ -761,6 +830,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
 
 #endif
 
+    SK_DEV(const unsigned long long dv_pw = wall_clock64();)  // this wave's streams are done
     // ---- block result: exact kk_pass best of all waves' lists, written sorted ----
     if (wl.cnt > kk_pass) wl.compact(lane, idof);
     if (lane == 0) s_cnt[wid] = wl.cnt;
@@ -776,13 +846,17 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       }
       s_rec[slot ^ 1u] = nxt;
     };
-    if (last_known && tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) next_item_fallback();
+    if (last_known && !tail_popped && tid == 0 && (!nxt_valid || !rec_stored)) next_item_fallback();
     __syncthreads();
+    SK_DEV(const unsigned long long dv_p1 = wall_clock64(); dv_scan += dv_p1 - dv_p0;  // every wave is done
+           )
     if constexpr (OPT) {
       if (optimistic && *s_ovf) {  // (workgroup-uniform after the barrier)
         // this pass is void: redo it, and run whatever follows, in passes that fit any list; the floor
         // it started from is untouched (s_floor is only written by a pass's merge)
         optimistic = false;
+        tail_popped = tail_popped || last_known;
+        SK_DEV(if (tid == 0) atomicAdd(&a.ctl->dev[5], 1u);)
         __syncthreads();  // every thread has read the flag
         if (tid == 0) {
           *s_ovf = 0u;
@@ -796,50 +870,132 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       }
     }
     // the next item's residual operands travel while this item's lists are merged
-    if (last_known && s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
-    uint32_t total = 0;
+    if (last_known) {
+      if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
+      tail_done = true;
+    }
+    // Exact (distance, rowid) ranks of the lists' rows, one row per WAVE at a time, the 64 lanes
+    // comparing it with 64 rows of the concatenated lists per step: every step is an independent
+    // LDS read per lane and one ballot.  (A row per THREAD walking all the lists serially is a chain of
+    // dependent LDS reads run by the few lanes whose slots are filled: 13 us of a 100 us item at
+    // kk = 250 with 124 rows in the lists, 600 us for an item whose lists are full.)
+    // Long lists first shrink to what can still win: an item that ran without a query bound (every
+    // query's first one — under best_first its nearest partition) ends with up to LR * 64 rows per wave,
+    // admitted under thresholds that were looser than the final one.  Every wave sorts its own list
+    // (exact kk-th / q-th best of the wave), the workgroup bound is rebuilt from those, and each list is
+    // cut at it: the ranking below then sees ~kk rows instead of ~NW * LR * 64 (its cost is quadratic).
+    {
+      uint32_t tot0 = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) total += s_cnt[w2];
-    const uint32_t n_out = min(total, kk_pass);
-    for (uint32_t g = tid; g < (uint32_t)NW * kk_pass; g += NT) {
-      const uint32_t w = g / kk_pass, j = g % kk_pass;
-      if (j >= s_cnt[w]) continue;
-      const ListEnt mine = lists[(size_t)w * LR * MI355_WAVE + j];
-      uint32_t rank = 0;
-      for (int w2 = 0; w2 < NW; ++w2) {
-        const ListEnt* l2 = lists + (size_t)w2 * LR * MI355_WAVE;
-        const uint32_t c2 = s_cnt[w2];
-        for (uint32_t j2 = 0; j2 < c2; ++j2) {
-          const ListEnt c = l2[j2];
-          bool lt = c.d < mine.d;
-          if (c.d == mine.d && c.pos != mine.pos) lt = idof(c.pos) < idof(mine.pos);
-          rank += lt ? 1u : 0u;
+      for (int w2 = 0; w2 < NW; ++w2) tot0 += s_cnt[w2];
+      if (tot0 > kk_pass + 2u * MI355_WAVE) {  // workgroup-uniform
+        wl.compact(lane, idof);
+        if (wl.t_run < published) {
+          published = wl.t_run;
+          if (lane == 0) atomicMin(s_thr, f32_sort_key(published));
         }
+        if constexpr (QSHARE) {
+          if (lane == 0 && wl.t_q < pub_q) __hip_atomic_store(s_part + wid, f32_sort_key(wl.t_q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        if constexpr (QSHARE) {
+          if (tid < MI355_WAVE) {  // wave 0: the maximum of the waves' q-th bests bounds NW * q >= kk rows
+            uint32_t v = lane < NW ? s_part[lane] : 0u;
+#pragma unroll
+            for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+            if (lane == 0 && v != 0xFFFFFFFFu) atomicMin(s_thr, v);
+          }
+          __syncthreads();
+        }
+        const uint32_t tk = *s_thr;
+        if (tk != 0xFFFFFFFFu) wl.prune(f32_from_sort_key(tk), lane);
+        if (lane == 0) s_cnt[wid] = wl.cnt;
+        __syncthreads();
       }
-      if (rank < kk_pass) {
+    }
+    SK_DEV(const unsigned long long dv_m0 = wall_clock64();)
+    uint32_t pre[NW + 1];  // wave-uniform prefix sums of the list lengths
+    pre[0] = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) pre[w2 + 1] = pre[w2] + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[w2]);
+    const uint32_t total = pre[NW];
+    const uint32_t n_out = min(total, kk_pass);
+    SK_DEV(if (tid == 0) atomicAdd(&a.ctl->dev[4], total);)
+    auto locate = [&](uint32_t c, uint32_t& w2, uint32_t& j2) {  // flat position -> (list, entry)
+      w2 = 0;
+#pragma unroll
+      for (int x = 1; x < NW; ++x) w2 += (c >= pre[x]) ? 1u : 0u;
+      uint32_t base = 0;
+#pragma unroll
+      for (int x = 1; x < NW; ++x) base = (c >= pre[x]) ? pre[x] : base;
+      j2 = c - base;
+    };
+    // ranks are wave-uniform; lane i of the wave parks the i-th row it ranked and the rows are written
+    // 64 at a time, so the row-id loads of the output records (one random 8-B read each) run in parallel
+    uint32_t parked = 0, r_rank = 0xFFFFFFFFu;
+    ListEnt r_ent;
+    r_ent.d = 0.f;
+    r_ent.pos = 0;
+    auto flush = [&]() {
+      if ((uint32_t)lane < parked && r_rank < kk_pass) {
         Cand o;
-        o.d = mine.d;
-        o.pos = mine.pos;
-        o.id = idof(mine.pos);
-        out[pass_base + rank] = o;
-        // kk rows at or below mine.d exist: a bound for every other partition of this query
-        if (pass_base + rank == a.kk - 1) atomicMin(a.qthr + b, f32_sort_key(mine.d));
-        if (MULTI && rank == kk_pass - 1) {  // the next pass starts strictly above this row
+        o.d = r_ent.d;
+        o.pos = r_ent.pos;
+        o.id = idof(r_ent.pos);
+        out[pass_base + r_rank] = o;
+        // kk rows at or below this distance exist: a bound for every other partition of this query
+        if (pass_base + r_rank == a.kk - 1) atomicMin(a.qthr + b, f32_sort_key(o.d));
+        if (MULTI && r_rank == kk_pass - 1) {  // the next pass starts strictly above this row
           s_floor->d = o.d;
           s_floor->id = o.id;
           s_floor->on = 1;
         }
       }
-    }
-    const bool more = MULTI && total >= kk_pass && pass_base + kk_pass < a.kk;
-    if (!more) {
-      for (uint32_t g = pass_base + n_out + tid; g < a.kk; g += NT) {
-        Cand o;
-        o.d = __builtin_huge_valf();
-        o.pos = CAND_EMPTY_POS;
-        o.id = ~0ull;
-        out[g] = o;
+      parked = 0;
+    };
+    for (uint32_t e = (uint32_t)wid; e < total; e += NW) {  // wave-uniform
+      uint32_t ew, ej;
+      locate(e, ew, ej);
+      const ListEnt mine = lists[(size_t)ew * LR * MI355_WAVE + ej];  // broadcast
+      uint32_t rank = 0;
+      uint64_t mine_id = 0;
+      bool have_id = false;
+      for (uint32_t c0 = 0; c0 < total && rank < kk_pass; c0 += MI355_WAVE) {
+        const uint32_t c = c0 + lane;
+        bool lt = false, tie = false;
+        ListEnt o;
+        o.d = 0.f;
+        o.pos = 0;
+        if (c < total) {
+          uint32_t w2, j2;
+          locate(c, w2, j2);
+          o = lists[(size_t)w2 * LR * MI355_WAVE + j2];
+          lt = o.d < mine.d;
+          tie = o.d == mine.d && o.pos != mine.pos;
+        }
+        if (__any(tie)) {  // equal distances: the row id decides (fetched only here)
+          if (!have_id) {
+            mine_id = idof(mine.pos);
+            have_id = true;
+          }
+          if (tie) lt = idof(o.pos) < mine_id;
+        }
+        rank += (uint32_t)__popcll((unsigned long long)__ballot(lt));
       }
+      if ((uint32_t)lane == parked) {
+        r_rank = rank;
+        r_ent = mine;
+      }
+      if (++parked == MI355_WAVE) flush();
+    }
+    SK_DEV(const unsigned long long dv_m1 = wall_clock64();)
+    if (parked) flush();
+    SK_DEV(if (tid == 0) { atomicAdd(&a.ctl->dev[6], (uint32_t)(dv_m0 - dv_p1)); atomicAdd(&a.ctl->dev[7], (uint32_t)(dv_m1 - dv_m0)); })
+    const bool more = MULTI && total >= kk_pass && pass_base + kk_pass < a.kk;
+    SK_DEV(__syncthreads(); dv_merge += wall_clock64() - dv_p1;)
+    if (!more) {
+      // the item's slots hold this many rows, ranks 0 .. in (distance, rowid) order; the rest is not written
+      if (tid == 0) a.cand_cnt[oslot] = pass_base + n_out;
       break;
     }
     __syncthreads();  // the floor is published; the lists and the block threshold are rebuilt
@@ -847,8 +1003,8 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
     __syncthreads();
     }  // passes
-    if (MULTI) {  // the tail work of the item, once (it overlaps the merge in the single-pass kernel)
-      if (tid == 0 && (!nxt_valid || n_tiles == 0 || (a.dbg & 2u))) {
+    if (MULTI && !tail_done) {  // the tail work of an item whose last pass was not known in advance
+      if (tid == 0 && (!nxt_valid || !rec_stored)) {
         if (!nxt_valid) {
           if (q_tried < 8) {
             q_cur = (q_cur + 1) & 7u;
@@ -863,6 +1019,8 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       __syncthreads();
       if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     }
+    SK_DEV(if (tid == 0) { atomicAdd(&a.ctl->dev[1], (uint32_t)dv_scan); atomicAdd(&a.ctl->dev[2], (uint32_t)dv_merge); }
+           (void)dv_adm;)
     __syncthreads();  // LDS is rebuilt by the next item
   }
 }

@@ -241,6 +241,12 @@ class VectorQuery:
     def explain_plan(self, verbose=False):  # query.rs:1495-1498
         return self._table.create_plan(self.request, QueryExecutionOptions()).explain(verbose)
 
+    def analyze_plan(self, options: Optional[QueryExecutionOptions] = None):
+        """Run the query and return its plan with runtime metrics (query.rs:1500-1510 -> table/query.rs:105-112;
+        sample python/python/lancedb/query.py:1414-1440): the engine's per-stage device times and counters
+        (mi355_last_stats / mi355_flat_last_stats) rendered on the plan nodes they stand for."""
+        return self._table.analyze_plan(self.request, options or QueryExecutionOptions())
+
     to_arrays = execute
 
 
@@ -287,6 +293,9 @@ class VectorTable:
     def query_stream(self, req: VectorQueryRequest, options: Optional[QueryExecutionOptions] = None):
         return execute_query(self, req, options or QueryExecutionOptions())
 
+    def analyze_plan(self, req: VectorQueryRequest, options: Optional[QueryExecutionOptions] = None):
+        return analyze_query_plan(self, req, options or QueryExecutionOptions())
+
     def _execute_vector_query(self, req: VectorQueryRequest):
         batches = list(execute_query(self, req, QueryExecutionOptions(max_batch_length=0)))
         return batches[0] if len(batches) == 1 else {k: np.concatenate([b[k] for b in batches]) for k in batches[0]}
@@ -307,32 +316,62 @@ class VectorPlan:
     params: Any                 # mi355_search_params
     queries: np.ndarray         # [n, dim] f32
 
-    def explain(self, verbose=False):
+    def explain(self, verbose=False, metrics=None):
+        """`metrics` (analyze_plan): {"elapsed_s", "rows", "stats"} of one execution — every node then carries
+        `elapsed=..., metrics=[...]` like DataFusion's AnalyzeExec rendering (python/python/lancedb/query.py:1414-1440)."""
         r, lines = self.request, []
+        st = (metrics or {}).get("stats") or {}
+
+        def us(*names):  # device time of the stages a node stands for
+            return sum(float(st.get("us_" + n, 0.0)) for n in names)
+
+        def m(elapsed_us=None, **kv):
+            if metrics is None:
+                return ""
+            parts = [f"{k2}={v}" for k2, v in kv.items() if v is not None]
+            if elapsed_us is not None:
+                parts.append(f"elapsed_compute={elapsed_us:.1f}us")
+            head = f", elapsed={elapsed_us:.1f}us" if elapsed_us is not None else ""
+            return f"{head}, metrics=[{', '.join(parts)}]"
+
+        rows = (metrics or {}).get("rows")
+        nq = len(self.queries)
         lim = f"fetch={self.k - (r.offset or 0)}" + (f", skip={r.offset}" if r.offset else "")
-        lines.append(f"ProjectionExec: expr=[{', '.join(self.output_columns())}]")
+        lines.append(f"ProjectionExec: expr=[{', '.join(self.output_columns())}]" + m(output_rows=rows))
         if r.offset:
-            lines.append(f"  GlobalLimitExec: {lim}")
+            lines.append(f"  GlobalLimitExec: {lim}" + m(output_rows=rows))
         if r.order_by:
-            lines.append("  SortExec: expr=[" + ", ".join(f"{c} {'ASC' if a else 'DESC'}" for c, a in r.order_by) + "]")
+            lines.append("  SortExec: expr=[" + ", ".join(f"{c} {'ASC' if a else 'DESC'}" for c, a in r.order_by) + "]" + m(output_rows=rows))
         if (r.allow_rowids is not None or r.block_rowids is not None) and not self.prefilter:
-            lines.append("  FilterExec: postfilter on _rowid")
+            lines.append("  FilterExec: postfilter on _rowid" + m(output_rows=rows))
         if self.use_index:
+            kk = self.k * (r.refine_factor or 1)
             if r.refine_factor:
-                lines.append(f"  SortExec: TopK(fetch={self.k}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]")
-                lines.append("    KNNVectorDistance: refine, metric=" + (r.distance_type or "index"))
-                lines.append("      Take: raw vectors of k * refine_factor = %d rows" % (self.k * r.refine_factor))
-            lines.append(f"  SortExec: TopK(fetch={self.k * (r.refine_factor or 1)}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]")
-            lines.append(f"    ANNSubIndex: name=mi355_ivf_pq, k={self.k * (r.refine_factor or 1)}, deltas=1"
-                         + (", prefilter=rowid mask" if self.prefilter and (r.allow_rowids is not None or r.block_rowids is not None) else ""))
+                lines.append(f"  SortExec: TopK(fetch={self.k}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]" + m(output_rows=rows))
+                lines.append("    KNNVectorDistance: refine, metric=" + (r.distance_type or "index")
+                             + m(us("refine"), rows_reranked=nq * kk if metrics is not None else None))
+                lines.append("      Take: raw vectors of k * refine_factor = %d rows" % kk)
+            lines.append(f"  SortExec: TopK(fetch={kk}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]"
+                         + m(us("merge"), candidate_lists=st.get("work_items")))
+            lines.append(f"    ANNSubIndex: name=mi355_ivf_pq, k={kk}, deltas=1"
+                         + (", prefilter=rowid mask" if self.prefilter and (r.allow_rowids is not None or r.block_rowids is not None) else "")
+                         + m(us("scan"), rows_scanned=st.get("vectors_scanned"), bytes_read=st.get("code_bytes_scanned"),
+                             work_items=st.get("work_items"), scan_variant=st.get("scan_variant"), timed_out=st.get("timed_out")))
             lines.append(f"      ANNIvfPartition: uuid=mi355, minimum_nprobes={r.minimum_nprobes}, "
-                         f"maximum_nprobes={r.maximum_nprobes}, deltas=1")
+                         f"maximum_nprobes={r.maximum_nprobes}, deltas=1"
+                         + m(us("coarse", "select"), partitions_ranked=st.get("partitions_probed"), queries=st.get("n_queries")))
         else:
-            lines.append(f"  SortExec: TopK(fetch={self.k}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]")
-            lines.append("    KNNVectorDistance: metric=" + (r.distance_type or "l2"))
+            lines.append(f"  SortExec: TopK(fetch={self.k}), expr=[_distance ASC NULLS LAST, _rowid ASC NULLS LAST]"
+                         + m(float(st.get("us_rest", 0.0)) if "us_rest" in st else None, fallback_queries=st.get("fallback_queries")))
+            lines.append("    KNNVectorDistance: metric=" + (r.distance_type or "l2")
+                         + m(float(st.get("us_gemm", 0.0)) if "us_gemm" in st else None, flops=st.get("gemm_flops"),
+                             gemm_variant=st.get("gemm_variant")))
             lines.append("      LanceRead: raw column resident in HBM")
         if len(self.queries) > 1:  # create_multi_vector_plan (table/query.rs:334-381)
             lines = ["UnionExec / query_index: %d query vectors in ONE device batch" % len(self.queries)] + ["  " + ln for ln in lines]
+        if metrics is not None:
+            lines = [f"AnalyzeExec verbose=true, elapsed={metrics.get('elapsed_s', 0.0) * 1e6:.1f}us, metrics=[output_rows={rows}]"] + \
+                    ["  " + ln for ln in lines]
         if verbose:
             lines.append(f"-- engine: k={self.params.k} nprobe=[{self.params.nprobe_min},{self.params.nprobe_max or 'all'}] "
                          f"refine_factor={self.params.refine_factor} timeout_ms={self.params.timeout_ms}")
@@ -430,6 +469,29 @@ def _order_and_project(out, req: VectorQueryRequest):
                                   "(user columns are taken by the table layer from _rowid)")
         out = {c: v for c, v in out.items() if c in req.select}
     return out
+
+
+def analyze_query_plan(table, req: VectorQueryRequest, options: QueryExecutionOptions) -> str:
+    """table::query::analyze_query_plan (table/query.rs:105-112): create the plan, execute it locally with the
+    handle's per-stage timers on, render plan + metrics."""
+    plan = create_plan(table, req, options)
+    handle = table.index if plan.use_index else table.flat
+    profiled = False
+    try:
+        if hasattr(handle, "configure"):
+            handle.configure(profile=1) if plan.use_index else handle.configure(profile=True)
+            profiled = True
+    except TypeError:
+        pass
+    t0 = time.perf_counter()
+    rows = 0
+    for batch in execute_generic_query(table, req, options):
+        rows += len(next(iter(batch.values()))) if batch else 0
+    elapsed = time.perf_counter() - t0
+    stats = handle.stats() if hasattr(handle, "stats") else {}
+    if profiled:
+        handle.configure(profile=0) if plan.use_index else handle.configure(profile=False)
+    return plan.explain(verbose=True, metrics={"elapsed_s": elapsed, "rows": rows, "stats": stats})
 
 
 def execute_generic_query(table, req: VectorQueryRequest, options: QueryExecutionOptions):

@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correct
 OBJS=$(ls lancedb_amd/build/*.o | grep -v ann_flat.o)
 for mask in "$@"; do
   ( /opt/rocm/bin/hipcc $FLAGS -DMI355_FLAT_ABLATE=$mask -c lancedb_amd/csrc/ann_flat.hip -o lancedb_amd/variants/ann_flat_abl$mask.o 2>/dev/null &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC $OBJS lancedb_amd/variants/ann_flat_abl$mask.o -shared -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o lancedb_amd/variants/lib_abl$mask.so &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC $OBJS lancedb_amd/variants/ann_flat_abl$mask.o -shared -ldl -Wl,-rpath,/opt/rocm/lib -o lancedb_amd/variants/lib_abl$mask.so &&
     echo "built abl$mask" ) &
 done
 wait

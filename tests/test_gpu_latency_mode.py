@@ -1,0 +1,46 @@
+"""Latency mode of the production scan: a batch too small to give every CU a (query, partition) work item
+is cut into slices of tile positions (SkewArgs::n_slices, csrc/kernels_skew.h) — one query then runs on
+all 256 CUs instead of on `nprobe` of them.  Results must not depend on the slicing: every case is the
+unsliced oracle result, bit for bit (callers are single-query tokio workers,
+python/src/runtime.rs:31-37)."""
+import numpy as np
+import pytest
+
+import lancedb_amd
+from oracle import train
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, exp):
+    ids, dist, cnt, st = exp
+    assert st == 0
+    assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()
+
+
+@pytest.mark.parametrize("m,dim", [(32, 128), (96, 768)])
+def test_sliced_work_items_return_the_unsliced_result(oracle, m, dim):
+    rng = np.random.default_rng(m)
+    n, nlist = 600_000, 40
+    # strong skew: partitions from a few hundred rows (streams with 0-2 tiles: empty slices) to ~80 k rows
+    s = train.synthetic_index(n, dim, nlist, m, seed=4, skew=1.2, empty_parts=2)
+    raw = rng.normal(size=(n, dim)).astype(np.float32)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
+    ix.configure(graph=False, coalesce=False)
+    allow = np.sort(rng.choice(n, size=n // 3, replace=False).astype(np.uint64))
+    for nq, nprobe in ((1, 8), (1, 32), (3, 12), (2, 40)):
+        q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.5, size=(nq, dim))).astype(np.float32)
+        ub = float(o.search(q, k=40, nprobe_min=nprobe, nprobe_max=nprobe)[1][0, 30])
+        for kw in (dict(k=10), dict(k=100), dict(k=250), dict(k=10, refine_factor=10), dict(k=25, upper_bound=ub),
+                   dict(k=10, allow_rowids=allow)):
+            kw = dict(nprobe_min=nprobe, nprobe_max=nprobe, **kw)
+            _same(ix.search(q, **kw), o.search(q, **kw))
+        st = ix.stats()
+        pairs = nq * nprobe
+        slices = max(1, min(8, 256 // pairs)) if pairs * 2 <= 256 else 1
+        assert st["work_items"] == pairs * slices, (st["work_items"], pairs, slices)
+    # a batch that fills the chip keeps whole partitions
+    q = rng.normal(size=(64, dim)).astype(np.float32)
+    _same(ix.search(q, k=10, nprobe_min=8, nprobe_max=8), o.search(q, k=10, nprobe_min=8, nprobe_max=8))
+    assert ix.stats()["work_items"] == 64 * 8

@@ -435,6 +435,12 @@ def test_vector_table_mirror_end_to_end(oracle):
     flat = t.vector_search(q[1]).bypass_vector_index().limit(4).execute()
     fi, fd, _, _ = oracle.flat_search(raw, q[1:], k=4)
     assert flat["_rowid"].tolist() == fi[0].tolist() and (flat["_distance"] == fd[0]).all()
+    # analyze_plan (table/query.rs:105-112): the engine's own counters on the plan nodes
+    text = t.vector_search(q[0]).nprobes(4).limit(5).analyze_plan()
+    assert text.startswith("AnalyzeExec verbose=true, elapsed=") and "output_rows=5" in text
+    scanned = sum(int(s["part_offsets"][p + 1] - s["part_offsets"][p]) for p in o.select_probes(o.coarse(q[0]), 4))
+    assert f"rows_scanned={scanned}" in text and "partitions_ranked=4" in text and "elapsed_compute=" in text
+    assert "KNNVectorDistance" in t.vector_search(q[1]).bypass_vector_index().limit(4).analyze_plan()
 
 
 def test_c4_config_shape_nlist_65536_nprobe_128_sharded_coarse(oracle):

@@ -136,6 +136,30 @@ def test_plan_names_the_nodes_it_replaces():
     assert multi.k == 10 and len(multi.queries) == 3 and "query_index" in multi.explain()
 
 
+def test_analyze_plan_renders_runtime_metrics_on_the_plan_nodes():
+    """query.rs:1500-1510 / table/query.rs:105-112; the reference's sample output (python/python/lancedb/query.py:
+    1414-1440) carries `elapsed=` and `metrics=[...]` on every node under an AnalyzeExec root."""
+    class _Timed(_ArrayIndex):
+        def stats(self):
+            return {"us_coarse": 40.0, "us_select": 60.0, "us_scan": 300.0, "us_merge": 20.0, "us_refine": 9.0, "n_queries": 1,
+                    "partitions_probed": 7, "vectors_scanned": 12345, "code_bytes_scanned": 12345 * 96, "work_items": 7,
+                    "scan_variant": 2, "timed_out": 0}
+
+        def configure(self, **kw):
+            self.cfg = kw
+    t = VectorTable(index=_Timed(100), flat=_Timed(100))
+    text = t.vector_search([0, 0, 0, 0]).nprobes(7).refine_factor(4).limit(5).analyze_plan()
+    first = text.splitlines()[0]
+    assert first.startswith("AnalyzeExec verbose=true, elapsed=") and "output_rows=5" in first
+    for needle in ("ANNIvfPartition", "elapsed=100.0us", "partitions_ranked=7", "ANNSubIndex", "rows_scanned=12345",
+                   "bytes_read=1185120", "elapsed_compute=300.0us", "KNNVectorDistance: refine", "rows_reranked=20",
+                   "TopK(fetch=20)", "elapsed=20.0us"):
+        assert needle in text, (needle, text)
+    assert t.index.cfg == {"profile": 0}  # the timers are switched off again
+    # explain_plan stays free of metrics
+    assert "metrics=" not in t.vector_search([0, 0, 0, 0]).explain_plan()
+
+
 def test_pushdown_dispatch_follows_the_reference_rules():
     """table/query.rs:51-65, :91-105: queries go to the push-down endpoint unless approx_mode or
     use_lsm is set (the wire request has no field for them)."""

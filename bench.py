@@ -297,6 +297,19 @@ def main():
             result["multi_gpu"]["sharded_equals_unsharded"] = bool(
                 (plain.rowids == last[0]).all().item() and (plain.distances == last[1]).all().item())
 
+    if rank == 0 and not sharded:
+        # SURVEY.md section 8d ends the timed region "on host-visible memory"; `value` leaves the results in HBM.  The same
+        # K steps again with each step's result (ids, distances, counts: 0.25 MB) copied to page-locked host memory:
+        h_out = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out]
+        fence()
+        t1 = time.perf_counter()
+        for i in range(a.steps):
+            r3 = step(i)
+            for h, d in zip(h_out, r3):
+                h.copy_(d, non_blocking=True)
+        fence()
+        result["config"]["timed_region"] = ("queries resident in HBM -> results in HBM (value); with every step's results copied to "
+                                            f"page-locked host memory: {(time.perf_counter() - t1) / a.steps * 1e3:.3f} ms per step")
     if rank == 0 and not sharded and a.recall_rows > 0:
         result["recall_at_10"] = recall_at_10(a, np, dim, m)
     if rank == 0 and not sharded and a.recall2_rows > 0:
@@ -322,6 +335,12 @@ def main():
         torch.cuda.empty_cache()
         for metric in ("l2", "cosine"):
             result["secondary"]["flat_c2_" + metric] = flat_c2(a, metric, cpu_queries=32 if metric == "l2" else 16)
+    if rank == 0 and "secondary" in result and "recall_at_10" in result:
+        rec, sec = result["recall_at_10"], result["secondary"]
+        result["qps_vs_recall_at_10"] = [
+            {"refine_factor": 0, "queries_per_s": result["value"], "recall_at_10_mixture_2M": rec.get("nprobe64")},
+            {"refine_factor": 10, "queries_per_s": sec.get("c3_refine10", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine10")},
+            {"refine_factor": 25, "queries_per_s": sec.get("c3_refine25", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine25")}]
     if rank == 0:
         print(json.dumps(result), flush=True)
     if sharded:
@@ -524,18 +543,19 @@ def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, r
                        "exchange_us_by_rank": [g[1]["us_exchange"] for g in got], "gathers_per_step": cs["n_gathers"],
                        "bytes_gathered_per_step": cs["bytes_gathered"], "rows_scanned_by_rank": cs["rows_scanned"],
                        "load_imbalance_max_over_mean": cs["imbalance"], "every_rank_equals_unsharded": same}
-    stages = [p["coarse_us"] + p["select_us"] + p["scan_us"] + p["merge_us"] for p in per_rank]
-    exch = float(np.median(modes["serial"]["exchange_us_by_rank"]))
+    stages = [p["ms_per_step_wall"] * 1e3 for p in per_rank]  # wall per step of one rank alone: its stages + planner + launch gaps
     res = {"world": world, "shard_open_s": round(t_open, 2), "steps": steps, "batch_queries": B,
            "stage_us_per_step_by_rank_alone": per_rank, **modes,
-           "step_model": {"slowest_rank_stages_us": max(stages), "mean_rank_stages_us": float(np.mean(stages)),
-                          "exchange_us": exch,
-                          "overlapped_ms": max(stages) / 1e3, "serial_ms": (max(stages) + exch) / 1e3,
-                          "qps_overlapped": B / (max(stages) * 1e-6), "qps_serial": B / ((max(stages) + exch) * 1e-6),
-                          "of_linear_overlapped": (B / (max(stages) * 1e-6)) / world,
-                          "note": "per-rank stages measured with the GPU to one rank; exchange = loopback gather (device copies) + "
-                                  "merges, an RCCL all-gather of the same 2.7 MB over xGMI replaces the copies on a real node; "
-                                  "divide qps by the N = 1 value of this run for the modelled scaling efficiency"}}
+           "step_model": {"slowest_rank_us": max(stages), "mean_rank_us": float(np.mean(stages)),
+                          "overlapped_ms": max(stages) / 1e3, "qps_overlapped": B / (max(stages) * 1e-6),
+                          "qps_if_ranks_were_balanced": B / (float(np.mean(stages)) * 1e-6),
+                          "note": "per-rank wall time of a step measured with the GPU to one rank; with the exchange on the "
+                                  "communicator's stream the N-GPU step is the slowest rank's own stages.  exchange_us_by_rank above is "
+                                  "the span first gather .. final merge with N ranks time-sharing ONE GPU — it mostly waits for "
+                                  "the other ranks' scans; its own cost is the world-of-one RCCL figure in "
+                                  "profiles/r03_a_bench_sharded_world1_*.json (58 us) plus the copies of N slabs.  A model from "
+                                  "measured terms, not a measurement of N GPUs; divide qps by this run's N = 1 value for the "
+                                  "modelled scaling efficiency"}}
     for c in comms:
         c.close()
     for s2 in shards:
@@ -652,7 +672,7 @@ def c5_refine10(a, torch, np, dev):
         ix.search(qpool[i % P], params, out=out)
     torch.cuda.synchronize()
     ix.configure(profile=2)
-    steps = max(3, a.steps // 2)
+    steps = max(6, a.steps)  # (the re-rank of step i runs beside the scan of step i + 1: the last one drains inside the timed region)
     t0 = time.perf_counter()
     for i in range(steps):
         last = ix.search(qpool[i % P], params, out=out)
@@ -944,7 +964,7 @@ def recall_embedding_like(a, np):
     out = {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "metric": "cosine", "queries": nq, "intrinsic_dim": idim,
            "truth": "exact flat cosine search (engine flat path)"}
     sweep = {}
-    for nprobe in (4, 16, 64):
+    for nprobe in (1, 2, 4, 16, 64):
         for rf in (0, 5, 10, 25):
             got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
             sweep[f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")] = rec(got.rowids)

@@ -523,6 +523,7 @@ static int32_t sharded_body(mi355_index* ix, mi355_comm* c, const float* queries
                             const mi355_search_params* p, uint32_t flags, const SearchShape& sh, uint64_t* out_rowids,
                             float* out_dist, uint32_t* out_counts) {
   hipStream_t st = ix->stream;
+  (void)hipGetLastError();  // report this call's errors only
   const bool host_io = p->io_mem == MI355_MEM_HOST;
   const uint32_t k = sh.k;
   const bool second_pass = sh.np_max > sh.np_min;

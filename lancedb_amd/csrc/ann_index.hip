@@ -163,7 +163,13 @@ static int32_t index_free(mi355_index* ix) {
   if (ix->raw_mapped_host) hostmap_release(ix->raw_mapped_host);
   if (ix->xdone) (void)hipEventDestroy(ix->xdone);
   if (ix->h_pin) (void)hipHostFree(ix->h_pin);
+  for (int i = 0; i < 2; ++i) {
+    if (ix->r_scan[i]) (void)hipEventDestroy(ix->r_scan[i]);
+    if (ix->r_done[i]) (void)hipEventDestroy(ix->r_done[i]);
+  }
+  if (ix->rstream) (void)hipStreamDestroy(ix->rstream);
   if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+  (void)hipGetLastError();  // never leave a sticky error of the teardown behind for the thread's next launch check
   delete ix;
   return MI355_OK;
 }
@@ -423,6 +429,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     }
     ix->has_raw = true;
     ix->raw_dtype = d->raw_dtype;
+    ix->raw_is_host = true;
   } else if (d->raw_vectors) {
     ST_TRY(gather_rows(ix->raw, d->raw_vectors, dtype_size(d->raw_dtype) * d->dim));
     ix->has_raw = true;
@@ -514,6 +521,11 @@ extern "C" int32_t mi355_index_attach_raw(mi355_index* ix, const void* raw_vecto
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->raw_attached = raw_vectors;
   ix->raw_attached_dtype = raw_dtype;
+  {  // a borrowed column that lives in (mapped) HOST memory makes the re-rank a PCIe gather: it is then deferred
+    hipPointerAttribute_t at{};
+    ix->raw_is_host = hipPointerGetAttributes(&at, raw_vectors) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+  }
   ++ix->ws_gen;  // captured graphs hold the old column's address
   return MI355_OK;
 }
@@ -525,6 +537,7 @@ extern "C" int32_t mi355_index_detach_raw(mi355_index* ix) {
   ST_TRY(join_exchange(ix));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->raw_attached = nullptr;
+  ix->raw_is_host = ix->raw_mapped_dev != nullptr;
   ++ix->ws_gen;
   return MI355_OK;
 }
@@ -640,7 +653,7 @@ int32_t make_row_filter(const mi355_search_params* p, DevBuf& stage, hipStream_t
 // given) into `out` [nq, kk]; the top-k over them is a k_merge_cands launch by the caller
 int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,
                       const uint32_t* in_cnt, const uint32_t* owner, uint32_t my_rank, uint32_t kk,
-                      const RangeFilter& range, Cand* out, hipStream_t st, ActiveMask act) {
+                      const RangeFilter& range, Cand* out, hipStream_t st, ActiveMask act, uint32_t max_blocks_y) {
   RefineArgs ra;
   ra.ix = view;
   ra.q = q;
@@ -664,7 +677,12 @@ int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, ui
     rb.in_owner = owner ? owner + (size_t)q0 * kk : nullptr;
     rb.out = out + (size_t)q0 * kk;
     rb.act.base = act.base + q0;
-    hipLaunchKernelGGL(k_refine_dist, dim3((kk + 255) / 256, n), dim3(256), rl, st, rb);
+    rb.nq = n;
+    rb.side_slots = kk <= 64 ? 64u : kk <= 128 ? 128u : 256u;
+    if (max_blocks_y)  // the re-rank beside the next call's scan: a few LDS-free workgroups striding over the queries
+      hipLaunchKernelGGL(k_refine_dist<true>, dim3((kk + 255) / 256, std::min(n, max_blocks_y)), dim3(256), 0, st, rb);
+    else
+      hipLaunchKernelGGL(k_refine_dist<false>, dim3((kk + 255) / 256, n), dim3(256), rl, st, rb);
   }
   HIP_TRY(hipGetLastError());
   return MI355_OK;
@@ -706,7 +724,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   uint32_t sk_slices = 1;
   if (skew) {
     const uint64_t pairs = (uint64_t)nq * nprobe;
-    if (pairs && pairs * 2 <= ix->n_cus) sk_slices = (uint32_t)std::min<uint64_t>(8, ix->n_cus / pairs);
+    if (pairs && pairs * 2 <= ix->n_cus) sk_slices = (uint32_t)std::min<uint64_t>(dev_knob("MI355_LAT_SLICES_MAX", 8), 2 * ix->n_cus / pairs);
     sk_slices = std::max(1u, std::min(sk_slices, ix->max_len / 2048u));
     if (pl.kk > 256u) sk_slices = 1;  // (multi-pass selection re-scans per pass: keep whole partitions)
   }
@@ -729,7 +747,22 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   ST_TRY(ix->w_probes.ensure(sizeof(uint32_t) * (size_t)chunk * nprobe));
   ST_TRY(ix->w_cand.ensure(sizeof(Cand) * (size_t)chunk * nprobe * n_slices * pl.kk));
   if (spill_per_item) ST_TRY(ix->w_spill.ensure(spill_per_item * (size_t)chunk * nprobe * n_slices));
-  if (pl.refine && !pl.out_cand) ST_TRY(ix->w_cand2.ensure(sizeof(Cand) * (size_t)chunk * pl.kk * 2));
+  // (refine: the ANN list and the exact list of a chunk; two sets when the refine of one call overlaps the next call's scan)
+  const bool defer = pl.defer_refine && pl.refine && !pl.out_cand && chunk >= nq;
+  if (pl.defer_refine && !defer) ST_TRY(join_exchange(ix));  // (a batch that needs several chunks keeps the serial path)
+  if (pl.refine && !pl.out_cand) ST_TRY(ix->w_cand2.ensure(sizeof(Cand) * (size_t)chunk * pl.kk * 2 * (defer ? 2 : 1)));
+  uint32_t rset = 0;
+  if (defer) {
+    if (!ix->rstream) {
+      HIP_TRY(hipStreamCreateWithFlags(&ix->rstream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&ix->r_scan[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ix->r_done[i], hipEventDisableTiming));
+      }
+    }
+    rset = (uint32_t)(ix->r_seq++ & 1u);
+    if (ix->r_busy[rset]) HIP_TRY(hipStreamWaitEvent(st, ix->r_done[rset], 0));  // the refine two calls back: this set is free again
+  }
   DevCtl* d_ctl = ix->w_ctl.as<DevCtl>();
   unsigned long long* d_stat = &d_ctl->rows_scanned;
   const bool prof = ix->profile != 0;
@@ -749,18 +782,30 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       }
       HIP_TRY(hipEventRecord(es.ev[0], st));
     }
-    hipLaunchKernelGGL(k_prep_queries, dim3((n + 3) / 4), dim3(256), 4 * (((size_t)ix->dim + 3) & ~(size_t)3) * 4, st,
-                       q, n, ix->dim, ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
+    // latency mode: a handful of queries run prep + coarse as one launch of single-wave workgroups
+    const size_t small_lds = ((size_t)n * (((size_t)ix->dim + 3) & ~(size_t)3) + n) * sizeof(float);
+    const bool small_front = !pl.ext_probes && !pl.act.n && n <= CS_MAXQ && small_lds <= 96u * 1024 && !dev_knob("MI355_COARSE_VALU", 0) &&
+                             dev_knob("MI355_LAT_SMALL_FRONT", 1);
+    if (!small_front)
+      hipLaunchKernelGGL(k_prep_queries, dim3((n + 3) / 4), dim3(256), 4 * (((size_t)ix->dim + 3) & ~(size_t)3) * 4, st,
+                         q, n, ix->dim, ix->metric, ix->w_qp.as<float>(), ix->w_qq.as<float>());
     if (pl.ext_probes) {
       // the probe list came from the two-phase coarse stage
       HIP_TRY(hipMemsetAsync(&d_ctl->bad_probes, 0, 4, st));
       const uint32_t np = n * nprobe;
       hipLaunchKernelGGL(k_take_probes, dim3((np + 255) / 256), dim3(256), 0, st, pl.ext_probes + (size_t)q0 * nprobe, np,
-                         ix->nlist, view.plen, ix->w_probes.as<uint32_t>(), d_stat, &d_ctl->bad_probes, nprobe, act);
+                         ix->nlist, view.plen, ix->w_probes.as<uint32_t>(), d_stat, &d_ctl->bad_probes, nprobe, act,
+                         skew ? ix->qthr.as<uint32_t>() : (uint32_t*)nullptr);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
     } else {
-    if (dev_knob("MI355_COARSE_VALU", 0))  // dev knob: the register-tiled VALU kernel (same bits)
+    if (small_front) {
+      if (small_lds > 48u * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+      hipLaunchKernelGGL(k_coarse_small, dim3((ix->nlist + 63) / 64), dim3(64), small_lds, st, q, n, ix->dim, ix->metric,
+                         view.centroids, view.cnorm, ix->nlist, ix->w_qp.as<float>(), ix->w_qq.as<float>(),
+                         ix->w_coarse.as<float>());
+    } else if (dev_knob("MI355_COARSE_VALU", 0))  // dev knob: the register-tiled VALU kernel (same bits)
       hipLaunchKernelGGL(k_coarse_tile, dim3((ix->nlist + CO_T - 1) / CO_T, (n + CO_T - 1) / CO_T),
                          dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
                          view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
@@ -773,7 +818,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
     hipLaunchKernelGGL(k_select_probes, dim3(n), dim3(256), 0, st, ix->w_coarse.as<float>(),
-                       ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat, act);
+                       ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat, act,
+                       skew ? ix->qthr.as<uint32_t>() : (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(es.ev[2], st));
@@ -806,7 +852,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       pa.n_slices = n_slices;
       pa.act = act;
       const uint32_t pb = (pa.n_pairs + 255) / 256;
-      HIP_TRY(hipMemsetAsync(ix->qthr.p, 0xFF, sizeof(uint32_t) * n, st));
+      // (qthr, the queries' running distance bounds, was reset by k_select_probes / k_take_probes)
       hipLaunchKernelGGL(k_plan_count, dim3(pb), dim3(256), 0, st, pa);
       hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, pa);
       hipLaunchKernelGGL(k_plan_fill, dim3(pb), dim3(256), 0, st, pa);
@@ -829,7 +875,10 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ka.n_slices = n_slices;
       ka.dbg = dev_knob("MI355_DBG_SKIP", 0);
       ka.ctl = d_ctl;
-      const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(ix->n_cus, (uint64_t)n * nprobe * n_slices);
+      // a handle whose re-rank runs beside its scans (deferred refine over a host column) keeps a few CUs free for it:
+      // a scan workgroup takes a whole CU (128 VGPRs x 16 waves), so nothing can share one with it
+      const uint32_t scan_cus = (pl.defer_refine && ix->n_cus > 4 * MI355_REFINE_SIDE_CUS) ? ix->n_cus - MI355_REFINE_SIDE_CUS : ix->n_cus;
+      const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(scan_cus, (uint64_t)n * nprobe * n_slices);
       ST_TRY(launch_scan_skew(ka, ix->m, std::max(n_blocks, 1u), ix->dim, pl.kk, st));
     } else {
       ScanArgs sa;
@@ -877,23 +926,43 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
     } else {
       // refine (query.rs:1313-1317): the kk ANN winners -> exact distances -> (distance, rowid) top k
-      Cand* ann = ix->w_cand2.as<Cand>();
+      Cand* ann = ix->w_cand2.as<Cand>() + (size_t)rset * chunk * pl.kk * 2;
       Cand* exact = ann + (size_t)chunk * pl.kk;
       ma.k_out = pl.kk;
       ma.out_cand = ann;
       ma.out_cnt = d_cnt_ann + q0;
       launch_by_kpl(kpl_kk, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
       HIP_TRY(hipGetLastError());
-      if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
-      ST_TRY(launch_refine(ix, view, q, n, ann, d_cnt_ann + q0, nullptr, 0, pl.kk, pl.range, exact, st, act));
+      hipStream_t rs = st;
+      if (defer) {  // the re-rank leaves the search stream: the next call's scan does not wait for it
+        rs = ix->rstream;
+        HIP_TRY(hipEventRecord(ix->r_scan[rset], st));
+        HIP_TRY(hipStreamWaitEvent(rs, ix->r_scan[rset], 0));
+      }
+      if (prof) HIP_TRY(hipEventRecord(es.ev[4], rs));
+      // (deferred: MI355_REFINE_SIDE_CUS workgroups in all — the CUs the scans of this handle leave free meanwhile)
+      ST_TRY(launch_refine(ix, view, q, n, ann, d_cnt_ann + q0, nullptr, 0, pl.kk, pl.range, exact, rs, act,
+                           defer ? std::max(1u, MI355_REFINE_SIDE_CUS / ((pl.kk + 255u) / 256u)) : 0u));
       MergeArgs mr = merge_args_dense(exact, 1, pl.kk, n, pl.k);
       mr.ctl = d_ctl;
       mr.act = act;
       mr.out_ids = d_ids + (size_t)q0 * pl.k;
       mr.out_dist = d_dist + (size_t)q0 * pl.k;
       mr.out_cnt = d_cnt + q0;
-      launch_by_kpl(kpl_k, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, mr);
+      launch_by_kpl(kpl_k, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, rs, mr);
       HIP_TRY(hipGetLastError());
+      if (prof) {
+        HIP_TRY(hipEventRecord(es.ev[5], rs));
+        ix->ev_pending.push_back(es);
+      }
+      if (defer) {
+        HIP_TRY(hipEventRecord(ix->r_done[rset], rs));
+        ix->r_busy[rset] = true;
+        if (!ix->xdone) HIP_TRY(hipEventCreateWithFlags(&ix->xdone, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ix->xdone, rs));
+        ix->xpending = true;
+      }
+      continue;
     }
     if (prof) {
       HIP_TRY(hipEventRecord(es.ev[5], st));
@@ -1079,6 +1148,7 @@ int32_t join_exchange(mi355_index* ix) {
   if (ix->xpending) {
     HIP_TRY(hipStreamWaitEvent(ix->stream, ix->xdone, 0));
     ix->xpending = false;
+    ix->r_busy[0] = ix->r_busy[1] = false;  // the search stream is now behind every deferred refine
   }
   return MI355_OK;
 }
@@ -1088,10 +1158,17 @@ int32_t join_exchange(mi355_index* ix) {
 static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& calls, const mi355_search_params* p,
                              const SearchShape& sh, const uint64_t* ext_probes, uint32_t ext_nprobe) {
   HIP_TRY(hipSetDevice(ix->device));
-  ST_TRY(join_exchange(ix));
+  (void)hipGetLastError();  // the launch checks below must report THIS call's errors, not what another HIP user of the thread left
+  const bool host_io = p->io_mem == MI355_MEM_HOST;
+  // A device-I/O refine call without a deadline and without maximum_nprobes expansion leaves its exact re-rank on the
+  // handle's refine stream (its outputs are complete at mi355_index_sync; the caller keeps queries and outputs
+  // untouched until then, as for any device-I/O call): the NEXT call's scan starts at once.  With a host-mapped raw
+  // column (C5) the re-rank is a PCIe gather, the scan an LDS / VALU loop: the two overlap almost entirely.
+  const bool defer = !host_io && p->refine_factor != 0 && p->timeout_ms == 0 && sh.np_max == sh.np_min && !ext_probes &&
+                     (ix->profile & MI355_PROFILE_MASK) != 1 && calls.size() == 1 && ix->raw_is_host;
+  if (!defer) ST_TRY(join_exchange(ix));
   hipStream_t st = ix->stream;
   auto t_start = std::chrono::steady_clock::now();
-  const bool host_io = p->io_mem == MI355_MEM_HOST;
   const uint32_t k = sh.k;
   uint32_t n_queries = 0;
   for (const SearchCall& c : calls) n_queries += c.nq;
@@ -1174,8 +1251,9 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   }
   uint32_t* d_cnt_ann = d_cnt;
   if (pl.refine) {
-    ST_TRY(ix->w_cnt2.ensure(sizeof(uint32_t) * n_queries));
-    d_cnt_ann = ix->w_cnt2.as<uint32_t>();
+    ST_TRY(ix->w_cnt2.ensure(sizeof(uint32_t) * n_queries * 2));
+    d_cnt_ann = ix->w_cnt2.as<uint32_t>() + (defer ? (size_t)(ix->r_seq & 1u) * n_queries : 0);  // (the set run_ivfpq takes next)
+    pl.defer_refine = defer;
   }
   // latency mode: small host batches without profiling / prefilter / external probes replay a graph
   const bool graphable = ix->use_graph && host_io && n_queries <= 64 && (ix->profile & MI355_PROFILE_MASK) == 0 &&

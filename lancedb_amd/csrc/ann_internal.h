@@ -108,6 +108,9 @@ static inline uint32_t dev_knob(const char* name, uint32_t dflt) {
 static inline uint32_t dev_knob(const char*, uint32_t dflt) { return dflt; }
 #endif
 
+// CUs the scans of a handle leave free while its deferred re-rank (a PCIe gather) runs beside them
+#define MI355_REFINE_SIDE_CUS 16u
+
 // top-k selection width: slots per lane of the in-register selector (64 lanes each);
 // k > 256 runs the same selector in several passes (device_common.h, WaveTopK floor)
 static inline int kpl_for(uint32_t kk) { return kk <= 64 ? 1 : kk <= 128 ? 2 : 4; }
@@ -199,6 +202,13 @@ struct mi355_index {
   bool xpending = false;
   void* h_pin = nullptr;  // page-locked staging block of small host-I/O batches (queries in, results out)
   size_t h_pin_cap = 0;
+  // deferred refine (device-I/O calls): the exact re-rank of call i runs on `rstream` under the scan of call i+1
+  // (a host-mapped raw column makes it PCIe-bound while the scan is LDS / VALU-bound); two sets of its buffers
+  bool raw_is_host = false;  // the refine column is host memory (mapped): only then is the re-rank deferred
+  hipStream_t rstream = nullptr;
+  hipEvent_t r_scan[2] = {nullptr, nullptr}, r_done[2] = {nullptr, nullptr};
+  bool r_busy[2] = {false, false};
+  uint64_t r_seq = 0;
   // config
   uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
   bool use_graph = false, coalesce = true;  // graph replay measured slower than eager launches
@@ -254,6 +264,7 @@ struct SearchPlan {
   Cand* out_cand = nullptr;
   ActiveMask act;      // device-side batch size: the maximum_nprobes second pass (slots past *act.n are skipped)
   uint32_t ws_mb = 0;  // workspace budget of this pass in MiB (0 = the default)
+  bool defer_refine = false;  // run refine + final merge on the handle's refine stream (results complete at mi355_index_sync)
 };
 int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl, uint64_t* d_ids,
                   float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann);
@@ -272,7 +283,8 @@ int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint
 struct IndexView;
 int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,
                       const uint32_t* in_cnt, const uint32_t* owner, uint32_t my_rank, uint32_t kk,
-                      const RangeFilter& range, Cand* out, hipStream_t st, ActiveMask act = ActiveMask());
+                      const RangeFilter& range, Cand* out, hipStream_t st, ActiveMask act = ActiveMask(),
+                      uint32_t max_blocks_y = 0);
 IndexView make_view(const mi355_index* ix);
 
 // pieces of the search path shared with the sharded search (ann_comm.hip)

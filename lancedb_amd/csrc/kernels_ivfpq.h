@@ -278,6 +278,103 @@ static __global__ __launch_bounds__(256) void k_coarse_mfma(
   }
 }
 
+// ------------------------------------------------------------------ K0+K1 (latency mode) ----
+// Up to CS_MAXQ queries: prep and coarse in ONE launch, the centroid matrix streamed by nlist / 64
+// single-wave workgroups (lane = centroid, its row read in 16-B pieces, sixteen in flight), every
+// accumulator the contract's d-ascending fmaf chain (bit-identical to k_coarse_mfma / k_coarse_tile).
+// Each workgroup prepares the queries for itself in LDS (cosine normalisation, |q|^2 chains: 1.3 us
+// of serial fmas per query, one lane each); workgroup 0 also writes qp / qq for the scan.  The
+// MFMA kernel at one query is 64 workgroups x 24 barrier-bound k-steps: 45 us; this is ~8 us.
+#define CS_MAXQ 8
+static __global__ __launch_bounds__(64) void k_coarse_small(const float* __restrict__ q, uint32_t nq, uint32_t dim, uint32_t metric,
+                                                            const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist,
+                                                            float* __restrict__ qp, float* __restrict__ qq_out,
+                                                            float* __restrict__ out /*[nq, nlist]*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t dimp = (dim + 3u) & ~3u;
+  float* sq = (float*)smem;                 // [nq][dimp]
+  float* sqq = sq + (size_t)nq * dimp;      // [nq]
+  const int lane = threadIdx.x;
+  for (uint32_t j = 0; j < nq; ++j)
+    for (uint32_t d = lane; d < dimp; d += 64) sq[(size_t)j * dimp + d] = d < dim ? q[(size_t)j * dim + d] : 0.f;
+  __syncthreads();
+  auto chain_sq = [&](const float* v) -> float {  // sum of squares, d ascending (fma(0,0,acc) of the padding is exact)
+    float acc = 0.f;
+    for (uint32_t d = 0; d < dimp; d += 4) {
+      const float4 x = *(const float4*)(v + d);
+      acc = __fmaf_rn(x.x, x.x, acc);
+      acc = __fmaf_rn(x.y, x.y, acc);
+      acc = __fmaf_rn(x.z, x.z, acc);
+      acc = __fmaf_rn(x.w, x.w, acc);
+    }
+    return acc;
+  };
+  if ((uint32_t)lane < nq) sqq[lane] = chain_sq(sq + (size_t)lane * dimp);
+  __syncthreads();
+  if (metric == MI355_METRIC_COSINE) {
+    for (uint32_t j = 0; j < nq; ++j) {
+      const float nrm = ieee_sqrtf(sqq[j]);
+      for (uint32_t d = lane; d < dim; d += 64) sq[(size_t)j * dimp + d] = ieee_divf(sq[(size_t)j * dimp + d], nrm);
+    }
+    __syncthreads();
+    if ((uint32_t)lane < nq) sqq[lane] = chain_sq(sq + (size_t)lane * dimp);
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    for (uint32_t j = 0; j < nq; ++j)
+      for (uint32_t d = lane; d < dim; d += 64) qp[(size_t)j * dim + d] = sq[(size_t)j * dimp + d];
+    if ((uint32_t)lane < nq) qq_out[lane] = sqq[lane];
+  }
+  const uint32_t c = blockIdx.x * 64u + lane;
+  if (c >= nlist) return;
+  const float* row = cen + (size_t)c * dim;
+  float acc[CS_MAXQ];
+#pragma unroll
+  for (int j = 0; j < CS_MAXQ; ++j) acc[j] = 0.f;
+  if ((dim & 3u) == 0) {
+    constexpr int PF = 16;  // 16-B pieces in flight per lane: the kernel is one wave per 64 centroids, latency-bound
+    for (uint32_t d0 = 0; d0 < dim; d0 += 4 * PF) {
+      float4 r[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (d0 + 4 * u < dim) r[u] = *(const float4*)(row + d0 + 4 * u);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (d0 + 4 * u >= dim) break;
+#pragma unroll
+        for (int j = 0; j < CS_MAXQ; ++j) {
+          if ((uint32_t)j < nq) {
+            const float4 x = *(const float4*)(sq + (size_t)j * dimp + d0 + 4 * u);  // broadcast
+            acc[j] = __fmaf_rn(x.x, r[u].x, acc[j]);
+            acc[j] = __fmaf_rn(x.y, r[u].y, acc[j]);
+            acc[j] = __fmaf_rn(x.z, r[u].z, acc[j]);
+            acc[j] = __fmaf_rn(x.w, r[u].w, acc[j]);
+          }
+        }
+      }
+    }
+  } else {
+    for (uint32_t d = 0; d < dim; ++d) {
+      const float r = row[d];
+#pragma unroll
+      for (int j = 0; j < CS_MAXQ; ++j)
+        if ((uint32_t)j < nq) acc[j] = __fmaf_rn(sq[(size_t)j * dimp + d], r, acc[j]);
+    }
+  }
+  const float cnv = cn[c];
+#pragma unroll
+  for (int j = 0; j < CS_MAXQ; ++j) {
+    if ((uint32_t)j < nq) {
+      float v;
+      if (metric == MI355_METRIC_DOT)
+        v = 1.0f - acc[j];
+      else
+        v = __fmaf_rn(-2.0f, acc[j], sqq[j] + cnv);
+      out[(size_t)j * nlist + c] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ K1b ----
 // One 256-thread block per query: 4-pass byte radix select of the nprobe-th
 // smallest coarse key, then emit {key < T} (any order) followed by the
@@ -286,7 +383,7 @@ static __global__ __launch_bounds__(256) void k_coarse_mfma(
 static __global__ __launch_bounds__(256) void k_select_probes(
     const float* __restrict__ coarse, uint32_t nlist, uint32_t nprobe,
     const uint32_t* __restrict__ plen, uint32_t* __restrict__ probes /*[nq, nprobe]*/,
-    unsigned long long* __restrict__ stat_rows, ActiveMask act = ActiveMask()) {
+    unsigned long long* __restrict__ stat_rows, ActiveMask act = ActiveMask(), uint32_t* __restrict__ qthr = nullptr) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_prefix, s_need, s_less, s_wave_cnt[4], s_running, s_best_at;
   __shared__ unsigned long long s_rows, s_best;
@@ -296,6 +393,7 @@ static __global__ __launch_bounds__(256) void k_select_probes(
   uint32_t* out = probes + (size_t)b * nprobe;
   if (!act.on(b)) return;  // inactive slot: the planner, the scan and the merge skip it too
   if (tid == 0) {
+    if (qthr) qthr[b] = 0xFFFFFFFFu;  // the query's running distance bound of the scan: none yet
     s_prefix = 0;
     s_need = nprobe;
     s_less = 0;
@@ -314,14 +412,27 @@ static __global__ __launch_bounds__(256) void k_select_probes(
       if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * byte)) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t need = s_need, cum = 0, bin = 0;
-      for (bin = 0; bin < 256; ++bin) {
-        if (cum + hist[bin] >= need) break;
-        cum += hist[bin];
+    {
+      // the bin holding the need-th smallest key: inclusive scan of the 256 counts over the 256 threads (a
+      // serial walk by one thread was 4 x 256 dependent LDS reads — most of this kernel's single-query time)
+      const uint32_t h = hist[tid];
+      uint32_t inc = h;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += v;
       }
-      s_need = need - cum;
-      s_prefix = prefix | (bin << (8 * byte));
+      if (lane == 63) s_wave_cnt[wid] = inc;
+      __syncthreads();
+      uint32_t base = 0;
+      for (int w = 0; w < wid; ++w) base += s_wave_cnt[w];
+      inc += base;
+      const uint32_t need = s_need;
+      __syncthreads();  // every thread has read s_need / s_wave_cnt
+      if (inc >= need && inc - h < need) {  // exactly one thread
+        s_need = need - (inc - h);
+        s_prefix = prefix | ((uint32_t)tid << (8 * byte));
+      }
     }
     mask |= 255u << (8 * byte);
     __syncthreads();
@@ -399,10 +510,11 @@ static __global__ void k_emit_coarse_pairs(const uint32_t* __restrict__ probes, 
 static __global__ void k_take_probes(const uint64_t* __restrict__ in, uint32_t n, uint32_t nlist,
                               const uint32_t* __restrict__ plen, uint32_t* __restrict__ out,
                               unsigned long long* __restrict__ stat_rows, uint32_t* __restrict__ bad,
-                              uint32_t nprobe = 1, ActiveMask act = ActiveMask()) {
+                              uint32_t nprobe = 1, ActiveMask act = ActiveMask(), uint32_t* __restrict__ qthr = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (!act.on(i / nprobe)) return;
+  if (qthr && i % nprobe == 0u) qthr[i / nprobe] = 0xFFFFFFFFu;
   const uint64_t p = in[i];
   if (p >= nlist) {  // not a partition of this index: counted (mi355_stats.bad_probes; host-I/O calls fail) and
     atomicAdd(bad, 1u);  // turned into an EMPTY work item (the planner and the scan treat ids >= nlist as length 0)
@@ -813,22 +925,36 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
       }
       return;
     }
-    for (uint32_t t0 = 0; t0 < n; t0 += MI355_WAVE) {
-      const uint32_t t = t0 + lane;
-      Cand c;
-      c.d = 0.f;
-      c.pos = CAND_EMPTY_POS;
-      c.id = 0;
-      bool ok = false;
-      if (t < n) {
-        const uint32_t sidx = t / a.kk_in, i = t % a.kk_in;
-        const uint32_t lim = a.src_cnt ? min(a.src_cnt[(size_t)sidx * a.cnt_stride + (size_t)b * a.cnt_q_stride], a.kk_in) : a.kk_in;
-        if (i < lim) {
-          c = src[(size_t)sidx * a.src_stride + i];
-          ok = c.pos != CAND_EMPTY_POS && c.d == c.d;
+    // eight steps of 64 slots at a time: their count loads, then their record loads, are all in flight
+    // together (a step-by-step loop is two dependent global round trips per 64 slots: 60 us for the 2560
+    // slots of one sliced single query)
+    constexpr int G = 8;
+    for (uint32_t t0 = 0; t0 < n; t0 += G * MI355_WAVE) {
+      uint32_t lim[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t t = t0 + u * MI355_WAVE + lane;
+        lim[u] = 0;
+        if (t < n) lim[u] = a.src_cnt ? min(a.src_cnt[(size_t)(t / a.kk_in) * a.cnt_stride + (size_t)b * a.cnt_q_stride], a.kk_in) : a.kk_in;
+      }
+      Cand c[G];
+      bool ok[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t t = t0 + u * MI355_WAVE + lane;
+        c[u].d = 0.f;
+        c[u].pos = CAND_EMPTY_POS;
+        c[u].id = 0;
+        ok[u] = false;
+        if (t < n && t % a.kk_in < lim[u]) {
+          c[u] = src[(size_t)(t / a.kk_in) * a.src_stride + t % a.kk_in];
+          ok[u] = c[u].pos != CAND_EMPTY_POS && c[u].d == c[u].d;
         }
       }
-      top.offer(ok, c.d, t, c.id, lane);
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (t0 + u * MI355_WAVE < n) top.offer(ok[u], c[u].d, t0 + u * MI355_WAVE + lane, c[u].id, lane);
+      }
     }
   };
   const uint32_t n_out = wave_select_sorted<KPL>(a.k_out, lane, gen, [&](uint32_t rk, float d, uint32_t t, uint64_t id) {
@@ -916,6 +1042,7 @@ __device__ __forceinline__ float dist_finish(const DistAcc& a, uint32_t metric, 
   return 1.0f - ieee_divf(a.qv, ieee_sqrtf(qq) * ieee_sqrtf(a.vv));
 }
 
+template <int PIECES = 4>  // 16-B pieces of the row in flight per lane (8 for rows that arrive over PCIe)
 __device__ __forceinline__ float exact_distance(const float* __restrict__ q, const void* raw,
                                                 uint32_t dtype, uint64_t row, uint32_t dim,
                                                 uint32_t metric, float qq) {
@@ -928,13 +1055,13 @@ __device__ __forceinline__ float exact_distance(const float* __restrict__ q, con
     const uint32_t n_pieces = dim / per;
     const uint4* pv = (const uint4*)p;
     uint32_t d = 0;
-    for (uint32_t i0 = 0; i0 < n_pieces; i0 += 4) {
-      uint4 buf[4];
+    for (uint32_t i0 = 0; i0 < n_pieces; i0 += PIECES) {
+      uint4 buf[PIECES];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < PIECES; ++u)
         if (i0 + u < n_pieces) buf[u] = pv[i0 + u];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < PIECES; ++u) {
         if (i0 + u >= n_pieces) break;
         const uint32_t w[4] = {buf[u].x, buf[u].y, buf[u].z, buf[u].w};
         if (dtype == MI355_DTYPE_F32) {
@@ -978,46 +1105,73 @@ struct RefineArgs {
   const DevCtl* ctl;
   uint32_t n_rows;         // rows on this handle: a position at or past it is not refined (a peer's slab
                            // that a timed-out scan left unwritten must not become an address)
+  uint32_t nq;             // queries of this launch (grid.y may be smaller: the workgroups stride over them)
+  uint32_t side_slots;     // SIDE kernel: threads per query, a multiple of 64 that divides 256 (256 when kk > 128)
   ActiveMask act;
 };
 
+// SIDE = false: the query and its |q|^2 live in LDS (one workgroup per query).
+// SIDE = true (the deferred re-rank that runs BESIDE the next call's scan on a few reserved CUs): no LDS at
+// all and a small grid striding over the queries — the scan's workgroups take a whole CU each (128 VGPRs x 16
+// waves, 159 KiB of LDS), so whatever overlaps them must fit on the CUs they leave free; the query is read with
+// wave-uniform (scalar) loads, |q|^2 is one lane's chain broadcast by readlane, eight row pieces in flight per lane.
+template <bool SIDE>
 static __global__ __launch_bounds__(256) void k_refine_dist(RefineArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* sq = (float*)smem;  // [dim]
-  __shared__ float s_qq;
+  __shared__ float s_qq_lds[SIDE ? 1 : 2];
   const int tid = threadIdx.x;
-  const uint32_t b = blockIdx.y;
   if (a.ctl && a.ctl->timed_out) return;
-  if (!a.act.on(b)) return;
-  const float* q = a.q + (size_t)b * a.ix.dim;
-  for (uint32_t d = tid; d < a.ix.dim; d += 256) sq[d] = q[d];
-  __syncthreads();
-  if (tid == 0) {
-    float acc = 0.f;
-    for (uint32_t d = 0; d < a.ix.dim; ++d) acc = __fmaf_rn(sq[d], sq[d], acc);
-    s_qq = acc;
-  }
-  __syncthreads();
-  const uint32_t cnt = min(a.in_cnt[b], a.kk);
-  const uint32_t c = blockIdx.x * 256 + tid;
-  if (c >= a.kk) return;
-  Cand o;
-  o.d = __builtin_huge_valf();
-  o.pos = CAND_EMPTY_POS;
-  o.id = ~0ull;
-  if (c < cnt && (!a.in_owner || a.in_owner[(size_t)b * a.kk + c] == a.my_rank)) {
-    const Cand in = a.in[(size_t)b * a.kk + c];
-    if (in.pos != CAND_EMPTY_POS && in.pos < a.n_rows) {
-      const uint64_t rrow = a.ix.raw_by_global ? global_pos_of(a.ix, in.pos) : (uint64_t)in.pos;
-      const float d = exact_distance(sq, a.ix.raw, a.ix.raw_dtype, rrow, a.ix.dim, a.ix.metric, s_qq);
-      if (in_range(d, a.range)) {
-        o.d = d;
-        o.pos = in.pos;
-        o.id = in.id;
+  // SIDE: a workgroup takes 256 / slots queries at a time (slots = kk rounded up to whole waves), so that all its
+  // threads keep row pieces in flight; otherwise one query per workgroup (grid.x covers kk)
+  const uint32_t slots = SIDE ? a.side_slots : 256u, qpb = 256u / slots;
+  for (uint32_t b0 = blockIdx.y * qpb; b0 < a.nq; b0 += gridDim.y * qpb) {
+    const uint32_t b = b0 + (SIDE ? (uint32_t)tid / slots : 0u);
+    if (b >= a.nq) continue;  // (SIDE has no barrier below)
+    if (!a.act.on(b)) continue;
+    const float* q = a.q + (size_t)b * a.ix.dim;
+    const float* sq = q;
+    float qq;
+    if constexpr (!SIDE) {
+      float* l = (float*)smem;  // [dim]
+      for (uint32_t d = tid; d < a.ix.dim; d += 256) l[d] = q[d];
+      __syncthreads();
+      if (tid == 0) {
+        float acc = 0.f;
+        for (uint32_t d = 0; d < a.ix.dim; ++d) acc = __fmaf_rn(l[d], l[d], acc);
+        s_qq_lds[0] = acc;
       }
+      __syncthreads();
+      sq = l;
+      qq = s_qq_lds[0];
+    } else {
+      float acc = 0.f;
+      if ((tid & 63) == 0)
+        for (uint32_t d = 0; d < a.ix.dim; ++d) acc = __fmaf_rn(q[d], q[d], acc);
+      qq = readlane_f(acc, 0);
     }
+    const uint32_t cnt = min(a.in_cnt[b], a.kk);
+    const uint32_t c = SIDE ? blockIdx.x * 256 + (uint32_t)tid % slots : blockIdx.x * 256 + tid;
+    if (c < a.kk) {
+      Cand o;
+      o.d = __builtin_huge_valf();
+      o.pos = CAND_EMPTY_POS;
+      o.id = ~0ull;
+      if (c < cnt && (!a.in_owner || a.in_owner[(size_t)b * a.kk + c] == a.my_rank)) {
+        const Cand in = a.in[(size_t)b * a.kk + c];
+        if (in.pos != CAND_EMPTY_POS && in.pos < a.n_rows) {
+          const uint64_t rrow = a.ix.raw_by_global ? global_pos_of(a.ix, in.pos) : (uint64_t)in.pos;
+          const float d = exact_distance<SIDE ? 8 : 4>(sq, a.ix.raw, a.ix.raw_dtype, rrow, a.ix.dim, a.ix.metric, qq);
+          if (in_range(d, a.range)) {
+            o.d = d;
+            o.pos = in.pos;
+            o.id = in.id;
+          }
+        }
+      }
+      a.out[(size_t)b * a.kk + c] = o;
+    }
+    if constexpr (!SIDE) __syncthreads();  // the LDS copy of the query is rebuilt for the next one
   }
-  a.out[(size_t)b * a.kk + c] = o;
 }
 
 // arrays-of-fields result lists ([nq, k] ids / distances + [nq] counts) -> packed Cand records

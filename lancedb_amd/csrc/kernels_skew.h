@@ -544,52 +544,57 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         if (j >= (uint32_t)(M - 31)) lut[c * P + j - (M - 32)] = acc;
 #endif
       };
-      if (dsub == 8) {
-        // 4 entries per thread per round: 8 independent 16-B loads in flight
+      // sub-vector lengths 4 / 8 / 16 (dim / m of the reference's defaults, index/vector.rs:306-310: 768 / 96,
+      // 1536 / 96): whole entries as 16-B loads, 8 of them in flight per thread, the chain in element order
+      auto lut_fast = [&](auto ds_tag) {
+        constexpr int DS = decltype(ds_tag)::value;
+        constexpr int V = DS / 4;    // 16-B pieces per codebook entry
+        constexpr int EPR = 8 / V;   // entries per thread per round
         constexpr uint32_t TOTAL = 256u * M;
-        for (uint32_t e0 = tid; e0 < TOTAL; e0 += 4 * NT) {
-          float4 cv4[4][2];
+        for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
+          float4 cv4[EPR][V];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < EPR; ++u) {
             const uint32_t e = e0 + u * NT;
             if (e < TOTAL) {
-              cv4[u][0] = *(const float4*)(a.cbT + (size_t)e * 8);
-              cv4[u][1] = *(const float4*)(a.cbT + (size_t)e * 8 + 4);
+#pragma unroll
+              for (int v = 0; v < V; ++v) cv4[u][v] = *(const float4*)(a.cbT + (size_t)e * DS + 4 * v);
             }
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < EPR; ++u) {
             const uint32_t e = e0 + u * NT;
             if (e < TOTAL) {
-              const float* rj = res + (e % (uint32_t)M) * 8;
-              const float4 r0 = *(const float4*)rj, r1 = *(const float4*)(rj + 4);
-              const float4 c0 = cv4[u][0], c1 = cv4[u][1];
+              const float* rj = res + (e % (uint32_t)M) * DS;
               float acc = 0.f;
-              if (dotm) {
-                acc = __fmaf_rn(r0.x, c0.x, acc);
-                acc = __fmaf_rn(r0.y, c0.y, acc);
-                acc = __fmaf_rn(r0.z, c0.z, acc);
-                acc = __fmaf_rn(r0.w, c0.w, acc);
-                acc = __fmaf_rn(r1.x, c1.x, acc);
-                acc = __fmaf_rn(r1.y, c1.y, acc);
-                acc = __fmaf_rn(r1.z, c1.z, acc);
-                acc = __fmaf_rn(r1.w, c1.w, acc);
-              } else {
-                float d0 = r0.x - c0.x, d1 = r0.y - c0.y, d2 = r0.z - c0.z, d3 = r0.w - c0.w;
-                float d4 = r1.x - c1.x, d5 = r1.y - c1.y, d6 = r1.z - c1.z, d7 = r1.w - c1.w;
-                acc = __fmaf_rn(d0, d0, acc);
-                acc = __fmaf_rn(d1, d1, acc);
-                acc = __fmaf_rn(d2, d2, acc);
-                acc = __fmaf_rn(d3, d3, acc);
-                acc = __fmaf_rn(d4, d4, acc);
-                acc = __fmaf_rn(d5, d5, acc);
-                acc = __fmaf_rn(d6, d6, acc);
-                acc = __fmaf_rn(d7, d7, acc);
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                const float4 r = *(const float4*)(rj + 4 * v);
+                const float4 c = cv4[u][v];
+                if (dotm) {
+                  acc = __fmaf_rn(r.x, c.x, acc);
+                  acc = __fmaf_rn(r.y, c.y, acc);
+                  acc = __fmaf_rn(r.z, c.z, acc);
+                  acc = __fmaf_rn(r.w, c.w, acc);
+                } else {
+                  const float d0 = r.x - c.x, d1 = r.y - c.y, d2 = r.z - c.z, d3 = r.w - c.w;
+                  acc = __fmaf_rn(d0, d0, acc);
+                  acc = __fmaf_rn(d1, d1, acc);
+                  acc = __fmaf_rn(d2, d2, acc);
+                  acc = __fmaf_rn(d3, d3, acc);
+                }
               }
               put(e, acc);
             }
           }
         }
+      };
+      if (dsub == 8) {
+        lut_fast(std::integral_constant<int, 8>{});
+      } else if (dsub == 16) {
+        lut_fast(std::integral_constant<int, 16>{});
+      } else if (dsub == 4) {
+        lut_fast(std::integral_constant<int, 4>{});
       } else {
         for (uint32_t e = tid; e < 256u * M; e += NT) {
           const float* cb = a.cbT + (size_t)e * dsub;

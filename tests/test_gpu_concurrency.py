@@ -162,3 +162,33 @@ def test_refine_from_host_mapped_raw_vectors(oracle):
         got = g.search(q, k=10, nprobe_min=12, nprobe_max=12, refine_factor=6)
         ids, dist, cnt, _ = o.search(q, k=10, nprobe_min=12, nprobe_max=12, refine_factor=6)
         assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()
+
+
+def test_deferred_refine_overlaps_the_next_call_and_stays_exact(oracle):
+    """Device-I/O refine calls leave their exact re-rank on the handle's refine stream (two buffer sets): several
+    calls in flight, results complete at sync(), every batch == the oracle; other entry points join first."""
+    rng = np.random.default_rng(12)
+    n, dim, m = 120000, 128, 32
+    s = train.synthetic_index(n, dim, 48, m, seed=6, skew=0.7)
+    raw = rng.normal(size=(n, dim)).astype(np.float32)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
+    DA = lancedb_amd.DeviceArray
+    for host_mapped in (False, True):
+        ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw,
+                                    raw_host_mapped=host_mapped)
+        qs = [rng.normal(size=(40, dim)).astype(np.float32) for _ in range(6)]
+        dq = [DA.from_numpy(q) for q in qs]
+        outs = [(DA((40, 10), np.int64), DA((40, 10), np.float32), DA((40,), np.int32)) for _ in qs]
+        p = _abi.make_params(k=10, nprobe_min=12, nprobe_max=12, refine_factor=8)
+        res = [ix.search(dq[i], p, out=outs[i]) for i in range(len(qs))]  # no sync in between
+        ix.sync()
+        for q, r in zip(qs, res):
+            ids, dist, cnt, _ = o.search(q, k=10, nprobe_min=12, nprobe_max=12, refine_factor=8)
+            assert (r.rowids.numpy().view(np.uint64) == ids).all() and (r.distances.numpy() == dist).all() and (r.counts.numpy() == cnt).all()
+        # a deferred call followed at once by a host-I/O call and by stats(): both join the pending re-rank
+        r = ix.search(dq[0], p, out=outs[0])
+        h = ix.search(qs[1], k=10, nprobe_min=12, nprobe_max=12)
+        assert (h.rowids == o.search(qs[1], k=10, nprobe_min=12, nprobe_max=12)[0]).all()
+        assert ix.stats()["n_queries"] >= 40
+        ix.sync()
+        assert (r.rowids.numpy().view(np.uint64) == o.search(qs[0], k=10, nprobe_min=12, nprobe_max=12, refine_factor=8)[0]).all()

@@ -38,9 +38,27 @@ def test_sliced_work_items_return_the_unsliced_result(oracle, m, dim):
             _same(ix.search(q, **kw), o.search(q, **kw))
         st = ix.stats()
         pairs = nq * nprobe
-        slices = max(1, min(8, 256 // pairs)) if pairs * 2 <= 256 else 1
+        slices = max(1, min(8, 512 // pairs)) if pairs * 2 <= 256 else 1
         assert st["work_items"] == pairs * slices, (st["work_items"], pairs, slices)
     # a batch that fills the chip keeps whole partitions
     q = rng.normal(size=(64, dim)).astype(np.float32)
     _same(ix.search(q, k=10, nprobe_min=8, nprobe_max=8), o.search(q, k=10, nprobe_min=8, nprobe_max=8))
     assert ix.stats()["work_items"] == 64 * 8
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+@pytest.mark.parametrize("dim,m", [(128, 32), (50, 10)])
+def test_small_batches_take_the_fused_prep_and_coarse_launch(oracle, metric, dim, m):
+    """<= 8 queries: prep + coarse run as one launch of single-wave workgroups (k_coarse_small); the probe lists and
+    the results must be the oracle's for every metric, also for a dimension that is not a multiple of 4."""
+    rng = np.random.default_rng(dim)
+    s = train.synthetic_index(30000, dim, 48, m, seed=9, skew=0.8, empty_parts=1)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
+    for nq in (1, 2, 7, 8, 9):
+        q = (s["centroids"][rng.integers(0, 48, size=nq)] + rng.normal(0, 0.4, size=(nq, dim))).astype(np.float32)
+        _same(ix.search(q, k=10, nprobe_min=6, nprobe_max=6), o.search(q, k=10, nprobe_min=6, nprobe_max=6))
+        # maximum_nprobes expansion on top of the small path (the second pass runs behind a device-side mask)
+        ub = float(o.search(q, k=30, nprobe_min=20, nprobe_max=20)[1][0, 20])
+        kw = dict(k=25, nprobe_min=2, nprobe_max=20, upper_bound=ub)
+        _same(ix.search(q, **kw), o.search(q, **kw))

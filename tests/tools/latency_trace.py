@@ -1,0 +1,40 @@
+"""Dev: single-query (host I/O) searches on C3-shaped partitions, for a rocprofv3 --kernel-trace --stats run:
+per-kernel device times of the latency path next to the wall-clock p50 / p99."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import lancedb_amd  # noqa: E402
+from lancedb_amd import _abi  # noqa: E402
+
+n, dim, nlist, m = 25_000_000, 768, 1024, 96
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+cen = torch.randn((nlist, dim), generator=g, device=dev)
+cb = torch.randn((m, 256, dim // m), generator=g, device=dev) * 0.5
+rng = np.random.default_rng(1)
+w = np.exp(rng.normal(0.0, 0.5, size=nlist))
+lens = rng.multinomial(n, w / w.sum())
+po = np.zeros(nlist + 1, np.uint64)
+po[1:] = np.cumsum(lens)
+codes = torch.randint(0, 256, (n * m,), generator=g, device=dev, dtype=torch.uint8)
+torch.cuda.synchronize()
+ix = lancedb_amd.IvfPqIndex(cen, cb, po, codes, None, codes_layout=_abi.CODES_PART_TRANSPOSED)
+del codes
+q = (cen[torch.randint(0, nlist, (512,), generator=g, device=dev)] + 0.5 * torch.randn((512, dim), generator=g, device=dev)).cpu().numpy()
+kw = dict(k=10, nprobe_min=64, nprobe_max=64)
+ix.configure(profile=0, graph=False, coalesce=False)
+for i in range(10):
+    ix.search(q[i:i + 1], **kw)
+lat = []
+for i in range(300):
+    t0 = time.perf_counter()
+    ix.search(q[i:i + 1], **kw)
+    lat.append(time.perf_counter() - t0)
+lat = np.sort(np.array(lat)) * 1e6
+print(f"single query, host I/O: p50 {lat[150]:.1f} us  p99 {lat[296]:.1f} us  mean {lat.mean():.1f} us", flush=True)

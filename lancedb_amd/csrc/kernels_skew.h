@@ -45,6 +45,9 @@
 #include "kernels_ivfpq.h"
 #include "skew_chunks.inc"  // generated inner blocks; defines SK_ADDR_* / SK_SPLIT_*
 
+#ifndef SK_LUT_INFLIGHT
+#define SK_LUT_INFLIGHT 8  // 16-B codebook loads in flight per thread while the distance table is built
+#endif
 #ifndef SK_RING_FULL
 #define SK_RING_FULL 0  // dev knob: 1 = ring of a whole tile's chunks (prefetch distance CPT-1 chunks)
 #endif
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       auto lut_fast = [&](auto ds_tag) {
         constexpr int DS = decltype(ds_tag)::value;
         constexpr int V = DS / 4;    // 16-B pieces per codebook entry
-        constexpr int EPR = 8 / V;   // entries per thread per round
+        constexpr int EPR = (SK_LUT_INFLIGHT / V) > 0 ? (SK_LUT_INFLIGHT / V) : 1;  // entries per thread per round
         constexpr uint32_t TOTAL = 256u * M;
         for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
           float4 cv4[EPR][V];

@@ -144,7 +144,21 @@ def main():
     lens = rng.multinomial(n, w / w.sum())
     part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
     part_offsets[1:] = np.cumsum(lens)
-    owner = lancedb_amd.shard_plan(part_offsets, world)  # the plan mi355_index_open follows (host code)
+    def plan_owner(n_shards):
+        """Partition -> shard.  For more than one shard: balanced by the rows a shard SCANS — the probe histogram of a
+        calibration batch drawn from the query distribution (not one of the timed batches) weights the partitions
+        (mi355_shard_plan_weighted); every rank takes rank 0's histogram so that all ranks cut the same plan."""
+        if n_shards <= 1:
+            return lancedb_amd.shard_plan(part_offsets, n_shards)
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(SEED + 99)
+        qc = centroids[torch.randint(0, nlist, (4096,), generator=gc, device=dev)] + 0.5 * torch.randn((4096, dim), generator=gc, device=dev)
+        pr = torch.cdist(qc, centroids).topk(a.nprobe, largest=False).indices
+        hits = torch.bincount(pr.flatten(), minlength=nlist).to(torch.float32)
+        if sharded and world > 1:
+            dist.broadcast(hits, src=0)
+        return lancedb_amd.shard_plan(part_offsets, n_shards, weights=hits.cpu().numpy())
+    owner = plan_owner(world)  # handed to mi355_index_open as part_owner
     mine = np.nonzero(owner == rank)[0]
     rows_mine = int(lens[mine].sum())
     codes = torch.empty((rows_mine * m,), device=dev, dtype=torch.uint8)
@@ -170,7 +184,7 @@ def main():
     t_open = time.time()
     ix = lancedb_amd.IvfPqIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
                                 codes_layout=_abi.CODES_PART_TRANSPOSED, device=local_rank,
-                                shard_count=world, shard_rank=rank, local_arrays=True)
+                                shard_count=world, shard_rank=rank, local_arrays=True, part_owner=owner if world > 1 else None)
     t_open = time.time() - t_open
     rows_local, parts_local = ix.info()
     assert rows_local == rows_mine
@@ -289,6 +303,7 @@ def main():
             "rccl_ranks": cs["world"], "gathers_per_step": cs["n_gathers"], "bytes_gathered_per_step": cs["bytes_gathered"],
             "rows_scanned_per_rank_timed_steps": cs["rows_scanned"], "load_imbalance_max_over_mean": cs["imbalance"],
             "rows_on_rank": [int(lens[owner == r].sum()) for r in range(world)],
+            "shard_plan": "mi355_shard_plan_weighted over the probe histogram of a calibration batch",
             "stage_us_per_step_by_rank": per_rank,
         }
         if world == 1:  # --force-sharded-path: the exchange of a world of one must reproduce the plain search
@@ -318,7 +333,7 @@ def main():
         result["secondary"] = {}
         if keep_arrays:
             result["secondary"]["loopback_world%d" % a.loopback_world] = loopback_world(
-                a, torch, np, ix, centroids, codebook, part_offsets, codes, row_ids, qpool, params, dev)
+                a, torch, np, ix, centroids, codebook, part_offsets, codes, row_ids, qpool, params, dev, plan_owner(a.loopback_world))
             del codes, row_ids
             torch.cuda.empty_cache()
         result["secondary"]["latency_c3"] = latency_and_concurrency(a, np, ix, qpool)
@@ -480,7 +495,7 @@ def refine_operating_point(a, torch, ix, qpool, n_rows, dim, dev):
 
 
 
-def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, row_ids, qpool, params, dev):
+def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, row_ids, qpool, params, dev, owner):
     """The N-rank sharded search of the SAME index with every rank on this GPU (mi355_comm_create_loopback:
     one thread and one shard handle per rank, the gather = device copies into the slab layout ncclAllGather
     fills).  Three things a 1-GPU box can measure about an N-GPU step: (1) each rank's own stage times with
@@ -495,7 +510,7 @@ def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, r
     world, B, k, P = a.loopback_world, a.batch, a.k, len(qpool)
     t0 = time.perf_counter()
     shards = [lancedb_amd.IvfPqIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
-                                     codes_layout=_abi.CODES_PART_TRANSPOSED, shard_count=world, shard_rank=r)
+                                     codes_layout=_abi.CODES_PART_TRANSPOSED, shard_count=world, shard_rank=r, part_owner=owner)
               for r in range(world)]
     t_open = time.perf_counter() - t0
     comms = Comm.loopback(world)
@@ -503,7 +518,12 @@ def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, r
              torch.empty((B,), dtype=torch.int32, device=dev)) for _ in range(world)]
     steps = max(4, a.steps // 2)
     torch.cuda.synchronize()
-    # (1) one rank at a time: its stages with the GPU to itself
+    # (1) one rank at a time: its stages with the GPU to itself (after one untimed round over all ranks: the first
+    # handle measured otherwise also pays for cold caches and clocks)
+    for r in range(world):
+        for i in range(2):
+            shards[r].search(qpool[i % P], params, out=outs[r])
+        shards[r].sync()
     per_rank = []
     for r in range(world):
         # (the plain search of a shard handle = its local stages: replicated coarse / select / plan, the scan of
@@ -545,6 +565,8 @@ def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, r
                        "load_imbalance_max_over_mean": cs["imbalance"], "every_rank_equals_unsharded": same}
     stages = [p["ms_per_step_wall"] * 1e3 for p in per_rank]  # wall per step of one rank alone: its stages + planner + launch gaps
     res = {"world": world, "shard_open_s": round(t_open, 2), "steps": steps, "batch_queries": B,
+           "shard_plan": "mi355_shard_plan_weighted over the probe histogram of a calibration batch (rows held per rank: "
+                         + ", ".join(str(p["rows"]) for p in per_rank) + ")",
            "stage_us_per_step_by_rank_alone": per_rank, **modes,
            "step_model": {"slowest_rank_us": max(stages), "mean_rank_us": float(np.mean(stages)),
                           "overlapped_ms": max(stages) / 1e3, "qps_overlapped": B / (max(stages) * 1e-6),

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MI355_ANN_ABI_VERSION 4u
+#define MI355_ANN_ABI_VERSION 5u
 
 /* ---- status codes (rust/lancedb/src/error.rs:55-145) -------------------- */
 enum {
@@ -150,6 +150,10 @@ typedef struct mi355_index_desc {
   uint32_t shard_rank;
   uint32_t flags;               /* MI355_INDEX_* */
   uint32_t reserved;
+  /* optional [nlist] owner (shard id) of every partition, ALWAYS host memory: replaces the built-in plan,
+     e.g. with mi355_shard_plan_weighted over observed probe counts.  Every rank must pass the same array.
+     NULL = mi355_shard_plan(part_offsets, nlist, shard_count). */
+  const uint32_t *part_owner;
 } mi355_index_desc;
 
 /*
@@ -579,6 +583,14 @@ int32_t mi355_coarse_slice(uint32_t nlist, uint32_t world, uint32_t rank, uint32
    ties to the lower shard id).  out_owner is [nlist]. */
 int32_t mi355_shard_plan(const uint64_t *part_offsets, uint32_t nlist,
                          uint32_t shard_count, uint32_t *out_owner);
+/* The same greedy packing over cost[p] = rows(p) * weight[p] (ties: longer partition, then lower id): with
+   weight = how often partition p is probed (a histogram of mi355_coarse_topn over a sample of the query load)
+   the shards are balanced by the bytes they SCAN, not by the bytes they hold — equal rows owned still left
+   +- 8 % of scanned rows between eight shards of the C3 bench index, whose popular partitions are probed
+   several times as often as the others.  weight NULL = all 1 (= mi355_shard_plan).  Hand the result to every
+   rank's mi355_index_desc.part_owner. */
+int32_t mi355_shard_plan_weighted(const uint64_t *part_offsets, const float *weight, uint32_t nlist,
+                                  uint32_t shard_count, uint32_t *out_owner);
 
 #ifdef __cplusplus
 }

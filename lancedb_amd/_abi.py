@@ -6,7 +6,7 @@ exactly; `struct_size` guards against drift at run time.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 ERR_INVALID_INPUT = 1
@@ -90,6 +90,7 @@ class IndexDesc(C.Structure):
         ("shard_rank", C.c_uint32),
         ("flags", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("part_owner", C.c_void_p),
     ]
 
 
@@ -260,6 +261,7 @@ EXPORTED_SYMBOLS = (
     "mi355_ivfpq_encode", "mi355_kmeans_train", "mi355_ivf_residuals", "mi355_pq_train",
     "mi355_merge_topk",
     "mi355_shard_plan",
+    "mi355_shard_plan_weighted",
 )
 
 METRIC_NAMES = {"l2": METRIC_L2, "cosine": METRIC_COSINE, "dot": METRIC_DOT}

@@ -17,23 +17,33 @@ int32_t fail(int32_t code, const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------ shard plan ----
-void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::vector<uint32_t>& owner) {
+void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::vector<uint32_t>& owner, const float* weight) {
   owner.assign(nlist, 0);
   if (shards <= 1) return;
+  // cost of a partition: its rows, times how often it is probed when the caller knows
+  std::vector<double> cost(nlist);
+  for (uint32_t p = 0; p < nlist; ++p) {
+    const double w = weight ? (double)weight[p] : 1.0;
+    cost[p] = (double)(po[p + 1] - po[p]) * (w == w && w > 0.0 ? w : 0.0);
+  }
   std::vector<uint32_t> order(nlist);
   for (uint32_t p = 0; p < nlist; ++p) order[p] = p;
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    uint64_t la = po[a + 1] - po[a], lb = po[b + 1] - po[b];
+    if (cost[a] != cost[b]) return cost[a] > cost[b];
+    const uint64_t la = po[a + 1] - po[a], lb = po[b + 1] - po[b];
     if (la != lb) return la > lb;
     return a < b;
   });
-  std::vector<uint64_t> load(shards, 0);
+  // least loaded shard by cost; rows owned break ties (never-probed partitions still spread by size)
+  std::vector<double> load(shards, 0.0);
+  std::vector<uint64_t> rows(shards, 0);
   for (uint32_t i = 0; i < nlist; ++i) {
     uint32_t p = order[i], best = 0;
     for (uint32_t s = 1; s < shards; ++s)
-      if (load[s] < load[best]) best = s;
+      if (load[s] < load[best] || (load[s] == load[best] && rows[s] < rows[best])) best = s;
     owner[p] = best;
-    load[best] += po[p + 1] - po[p];
+    load[best] += cost[p];
+    rows[best] += po[p + 1] - po[p];
   }
 }
 
@@ -64,6 +74,16 @@ extern "C" int32_t mi355_shard_plan(const uint64_t* part_offsets, uint32_t nlist
     return fail(MI355_ERR_INVALID_INPUT, "mi355_shard_plan: bad arguments");
   std::vector<uint32_t> owner;
   shard_plan_host(part_offsets, nlist, shard_count, owner);
+  memcpy(out_owner, owner.data(), sizeof(uint32_t) * nlist);
+  return MI355_OK;
+}
+
+extern "C" int32_t mi355_shard_plan_weighted(const uint64_t* part_offsets, const float* weight, uint32_t nlist,
+                                             uint32_t shard_count, uint32_t* out_owner) {
+  if (!part_offsets || !out_owner || shard_count == 0 || nlist == 0)
+    return fail(MI355_ERR_INVALID_INPUT, "mi355_shard_plan_weighted: bad arguments");
+  std::vector<uint32_t> owner;
+  shard_plan_host(part_offsets, nlist, shard_count, owner, weight);
   memcpy(out_owner, owner.data(), sizeof(uint32_t) * nlist);
   return MI355_OK;
 }

@@ -191,6 +191,18 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ga.n_rtiles = n_rtiles;
     ga.omc = 1.f - f->c_err;
     ga.gm = f->g_gm.as<float>();
+    ga.vw = nullptr;
+    if (variant == MI355_FLAT_GEMM_8PHASE && metric != MI355_METRIC_L2) {
+      DevBuf& vw = metric == MI355_METRIC_COSINE ? f->vw_cos : f->vw_dot;
+      if (!vw.p) {  // once per column and metric
+        const uint64_t vv_rows = ((f->n_rows + 255) / 256) * 256;
+        ST_TRY(vw.ensure(sizeof(float) * vv_rows));
+        hipLaunchKernelGGL(k_flat_row_factor, dim3((uint32_t)((vv_rows + 255) / 256)), dim3(256), 0, st, f->vv.as<float>(), vv_rows,
+                           metric, vw.as<float>());
+        HIP_TRY(hipGetLastError());
+      }
+      ga.vw = vw.as<float>();
+    }
     uint32_t gemm_blocks = ((n_rtiles + 7) / 8) * 8 * ga.n_qtiles;  // one per (row tile, query tile)
     // persistent grid: one workgroup per CU slot walks its XCD's tiles and overlaps the next tile's
     // first stage with the current tile's last k-step and epilogue (grid_workgroups of
@@ -309,7 +321,7 @@ extern "C" int32_t mi355_flat_close(mi355_flat* f) {
   if (!f) return MI355_OK;
   (void)hipSetDevice(f->device);
   DevBuf* bufs[] = {&f->vectors, &f->row_ids, &f->w_q,  &f->w_cand, &f->w_ids,  &f->w_dist, &f->w_cnt,
-                    &f->shadow,  &f->vv,      &f->vmax, &f->g_qb,   &f->g_qa,   &f->g_qg,   &f->g_slack,
+                    &f->shadow,  &f->vv,      &f->vw_cos,  &f->vw_dot, &f->vmax, &f->g_qb,   &f->g_qa,   &f->g_qg,   &f->g_slack,
                     &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand, &f->w_filter, &f->w_sum, &f->w_fallback};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&f->ev_free, &f->ev_pending})

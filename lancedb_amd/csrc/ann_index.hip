@@ -134,6 +134,10 @@ static int32_t validate_index_desc(const mi355_index_desc* d) {
   if (d->shard_count > 1 && d->shard_rank >= d->shard_count)
     return fail(MI355_ERR_INVALID_INPUT, "shard_rank %u >= shard_count %u", d->shard_rank,
                 d->shard_count);
+  if (d->part_owner && d->shard_count > 1)
+    for (uint32_t p = 0; p < d->nlist; ++p)
+      if (d->part_owner[p] >= d->shard_count)
+        return fail(MI355_ERR_INVALID_INPUT, "part_owner[%u] = %u is not a shard of %u", p, d->part_owner[p], d->shard_count);
   // an 8-bit distance table larger than the LDS keeps its tail in global memory (k_scan_pair SPILL);
   // what cannot work is a residual + candidate lists that leave no room for any table
   if (scan_pair_m_lds(d->m, d->nbits, d->dim) == 0)
@@ -197,7 +201,10 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
 
   // -- ownership + local layout
   std::vector<uint32_t> owner;
-  shard_plan_host(d->part_offsets, nlist, ix->shard_count, owner);
+  if (d->part_owner && ix->shard_count > 1)
+    owner.assign(d->part_owner, d->part_owner + nlist);  // the caller's plan (validated: every id < shard_count)
+  else
+    shard_plan_host(d->part_offsets, nlist, ix->shard_count, owner);
   std::vector<uint32_t> plen(nlist), pstride(nlist), lrow0(nlist);
   std::vector<uint64_t> code_off(nlist), grow0(nlist);
   uint64_t rows = 0, bytes = 0;

@@ -94,7 +94,8 @@ static inline hipError_t copy_in(void* dst, const void* src, size_t bytes, uint3
 }
 
 int32_t need_device(int32_t device);
-void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::vector<uint32_t>& owner);
+void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::vector<uint32_t>& owner,
+                     const float* weight = nullptr);
 
 // Build-time dev knobs (-DMI355_DEV_KNOBS, scripts/build_variants.sh only): environment
 // overrides for kernel tuning experiments.  The product build reads no environment.
@@ -238,7 +239,7 @@ struct mi355_flat {
   bool shadowed = false;  // GEMM reads a bf16 shadow (column is f32/f16 or dim % 64 != 0)
   uint32_t dimp = 0;
   float c_err = 0.f, vv_max = 0.f;
-  DevBuf shadow, vv, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand, w_filter, w_sum, w_fallback;
+  DevBuf shadow, vv, vw_cos, vw_dot, vmax, g_qb, g_qa, g_qg, g_slack, g_tau, g_gm, g_seg, g_cnt, g_cand, w_filter, w_sum, w_fallback;
   uint32_t last_path = 0;  // 1 = MFMA filter, 2 = exact sweep (reported by mi355_flat_info)
   uint32_t gemm_variant = MI355_FLAT_GEMM_AUTO, grid_workgroups = 0, cfg_flags = 0;
   uint64_t checksum = 0, census[2] = {0, 0};

@@ -135,7 +135,18 @@ struct FlatGemmArgs {
   uint32_t n_rtiles;     // ceil(n_rows / 128)
   float omc;             // 1 - c_err (weight of |v|^2 in the L2 bound)
   float* gm;             // [n_rtiles * 4][nq_pad] group minima of lo
+  const float* vw;       // 8-phase kernel, cosine / dot: the per-row factor of the fast epilogue, 1 / sqrt(|v|^2) or
+                         // sqrt(|v|^2), computed once per column (k_flat_row_factor); padded like vv.  nullptr for L2
 };
+
+// the per-row factor of k_flat_gemm8's fast epilogue for cosine (1 / |v|) and dot (|v|): the same correctly rounded
+// sqrt / divide the epilogue used to run per tile — 32 quarter-rate operations per lane per tile
+static __global__ void k_flat_row_factor(const float* __restrict__ vv, uint64_t n, uint32_t metric, float* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = vv[i];
+  out[i] = metric == MI355_METRIC_COSINE ? 1.0f / sqrtf(v) : sqrtf(v);
+}
 
 __device__ __forceinline__ void fg_glds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,

@@ -181,8 +181,11 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
   // the previous group's stores — four serial round trips per tile with the matrix pipe idle.)
   auto stage_epi = [&](const TileRef& t) {
     if (FG_ABL(1) && abl_dma_off) return;
-    if (wid == 0)
-      fg_glds16(a.vv + t.row0 + (uint32_t)lane * 4u, smem + EPI_OFF);
+    if (wid == 0) {
+      // cosine / dot with the fast epilogue on a whole tile: the precomputed row factor instead of |v|^2
+      const float* rowv = (EPI == 1 && METRIC != MI355_METRIC_L2 && t.lim == (uint32_t)(BM - 1) && a.vw) ? a.vw : a.vv;
+      fg_glds16(rowv + t.row0 + (uint32_t)lane * 4u, smem + EPI_OFF);
+    }
     else if (wid == 1)
       fg_glds16(a.qa + t.q0 + (uint32_t)lane * 4u, smem + EPI_OFF + 1024);
     else if (wid == 2)
@@ -297,7 +300,9 @@ __global__ __launch_bounds__(512, 2) void k_flat_gemm8(FlatGemmArgs a) {
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const float vv = vvr[h][reg];
-            w[h][reg] = METRIC == MI355_METRIC_L2 ? a.omc * vv : METRIC == MI355_METRIC_COSINE ? 1.0f / sqrtf(vv) : sqrtf(vv);
+            w[h][reg] = METRIC == MI355_METRIC_L2 ? a.omc * vv
+                        : a.vw ? vv  // (the staged value IS the factor: k_flat_row_factor)
+                        : METRIC == MI355_METRIC_COSINE ? 1.0f / sqrtf(vv) : sqrtf(vv);
           }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {

@@ -902,7 +902,10 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
       oc[g] = e;
     }
   }
-  // `pos` travels through the selector as the candidate's slot index t (source = t / kk_in)
+  // With an owner output (gathered shard lists) `pos` travels through the selector as the candidate's slot index t
+  // (source = t / kk_in) and the record's own position is fetched when the row is emitted; otherwise the position
+  // itself travels: no dependent load per emitted row (ten serial round trips in a single query's merge)
+  const bool by_slot = a.out_owner != nullptr;
   auto gen = [&](WaveTopK<KPL>& top) {
     if (a.src_cnt && a.kk_in > 32u) {
       // long lists with counts: walk source by source and read only the filled part (with a query bound in
@@ -920,7 +923,7 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
             c = src[(size_t)sidx * a.src_stride + i];
             ok = c.pos != CAND_EMPTY_POS && c.d == c.d;
           }
-          top.offer(ok, c.d, sidx * a.kk_in + i, c.id, lane);
+          top.offer(ok, c.d, by_slot ? sidx * a.kk_in + i : c.pos, c.id, lane);
         }
       }
       return;
@@ -953,13 +956,16 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < G; ++u) {
-        if (t0 + u * MI355_WAVE < n) top.offer(ok[u], c[u].d, t0 + u * MI355_WAVE + lane, c[u].id, lane);
+        if (t0 + u * MI355_WAVE < n) top.offer(ok[u], c[u].d, by_slot ? t0 + u * MI355_WAVE + lane : c[u].pos, c[u].id, lane);
       }
     }
   };
   const uint32_t n_out = wave_select_sorted<KPL>(a.k_out, lane, gen, [&](uint32_t rk, float d, uint32_t t, uint64_t id) {
-    const uint32_t sidx = t / a.kk_in, i = t % a.kk_in;
-    const uint32_t pos = src[(size_t)sidx * a.src_stride + i].pos;
+    uint32_t sidx = 0, pos = t;
+    if (by_slot) {
+      sidx = t / a.kk_in;
+      pos = src[(size_t)sidx * a.src_stride + t % a.kk_in].pos;
+    }
     if (oi) oi[rk] = id;
     if (od) od[rk] = d;
     if (op) op[rk] = pos;

@@ -110,7 +110,7 @@ class IvfPqIndex(_Handle):
     def __init__(self, centroids, codebook, part_offsets, codes, row_ids=None, raw_vectors=None,
                  metric="l2", codes_layout=_abi.CODES_ROW_MAJOR, raw_dtype=_abi.DTYPE_F32,
                  device=0, shard_count=1, shard_rank=0, nbits=8, generic_scan=False, raw_host_mapped=False,
-                 local_arrays=False):
+                 local_arrays=False, part_owner=None):
         """nbits: 8, or 4 (codebook [m, 16, dim/m], codes [n, m/2] with sub-quantiser 2t in the low
         nibble of byte t; table/create_index.rs:96-101).  generic_scan: keep the generic code layout
         (k_scan_pair) for an m the production scan supports.  raw_host_mapped: `raw_vectors` (a host
@@ -149,6 +149,11 @@ class IvfPqIndex(_Handle):
         d.raw_dtype = raw_dtype
         d.device = device
         d.shard_count, d.shard_rank = shard_count, shard_rank
+        if part_owner is not None:  # [nlist] shard of every partition (shard_plan(..., weights=...)); host memory
+            self._owner = np.ascontiguousarray(part_owner, dtype=np.uint32)
+            if self._owner.shape != (int(d.nlist),):
+                raise ValueError("part_owner must be [nlist]")
+            d.part_owner = self._owner.ctypes.data_as(C.c_void_p)
         self.n_rows = d.n_rows
         self._keep = [cen, cb, po, cd, rid, raw]
         check(lib().mi355_index_open(C.byref(d), C.byref(self._h)))
@@ -316,10 +321,19 @@ def merge_topk(in_rowids, in_dist, in_counts, k, stream=0):
     return ids, dist, cnt
 
 
-def shard_plan(part_offsets, shard_count):
+def shard_plan(part_offsets, shard_count, weights=None):
+    """Partition -> shard assignment (greedy longest-first).  `weights` [nlist]: how often each partition is
+    probed (e.g. a histogram of `coarse_topn` over a sample of the query load) — the shards are then balanced by
+    the rows they scan instead of the rows they hold; pass the result as `IvfPqIndex(part_owner=...)` on every rank."""
     po = np.ascontiguousarray(part_offsets, dtype=np.uint64)
     out = np.empty(po.size - 1, dtype=np.uint32)
-    check(lib().mi355_shard_plan(_ptr(po), C.c_uint32(po.size - 1), C.c_uint32(shard_count), _ptr(out)))
+    if weights is None:
+        check(lib().mi355_shard_plan(_ptr(po), C.c_uint32(po.size - 1), C.c_uint32(shard_count), _ptr(out)))
+    else:
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        if w.shape != (po.size - 1,):
+            raise ValueError("weights must be [nlist]")
+        check(lib().mi355_shard_plan_weighted(_ptr(po), _ptr(w), C.c_uint32(po.size - 1), C.c_uint32(shard_count), _ptr(out)))
     return out
 
 

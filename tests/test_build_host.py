@@ -133,3 +133,26 @@ def test_four_bit_builder_shapes(oracle_backend):
     assert cb.shape == (8, 16, 4)
     assert oracle_backend[1][1] == (16 * 16, 32)  # PQ sample: sample_rate * 2^num_bits rows
     assert oracle_backend[2][2] == (8, 16, 4) and oracle_backend[2][5] == 4
+
+
+def test_weighted_shard_plan_balances_the_rows_that_are_scanned():
+    """mi355_shard_plan_weighted (host code): cost = rows x probe frequency.  Without weights it is mi355_shard_plan;
+    with a skewed probe histogram the heaviest shard's scanned rows drop to within a few percent of the mean."""
+    rng = np.random.default_rng(3)
+    nlist, shards = 4096, 8
+    lens = rng.multinomial(10_000_000, (lambda w: w / w.sum())(np.exp(rng.normal(0, 0.5, nlist))))
+    po = np.zeros(nlist + 1, np.uint64)
+    po[1:] = np.cumsum(lens)
+    plain = lancedb_amd.shard_plan(po, shards)
+    assert (lancedb_amd.shard_plan(po, shards, weights=np.ones(nlist)) == plain).all()
+    hits = rng.gamma(1.5, 20.0, nlist)  # popular and unpopular partitions, independent of their size
+    hits[rng.choice(nlist, 50, replace=False)] = 0.0  # never probed
+    weighted = lancedb_amd.shard_plan(po, shards, weights=hits)
+    assert weighted.max() < shards and len(np.unique(weighted)) == shards
+
+    def imbalance(owner):
+        cost = np.array([(lens[owner == r] * hits[owner == r]).sum() for r in range(shards)])
+        return cost.max() / cost.mean()
+    assert imbalance(weighted) < 1.01 < imbalance(plain)
+    rows = np.array([lens[weighted == r].sum() for r in range(shards)])
+    assert rows.max() / rows.mean() < 1.25  # rows held stay reasonable too

@@ -198,3 +198,32 @@ def test_shard_handle_and_communicator_must_agree(oracle):
     q = np.zeros((1, 32), np.float32)
     with pytest.raises(lancedb_amd.InvalidInput, match="shard 0 of 2"):
         ShardedSearcher(shards[0], comms[0]).search(q, _abi.make_params(k=5, nprobe_min=4, nprobe_max=4))
+
+
+def test_shards_cut_by_a_probe_weighted_plan_return_the_unsharded_result(oracle):
+    """mi355_index_desc.part_owner: ownership from mi355_shard_plan_weighted over observed probe counts (the plan
+    that balances the rows scanned, not the rows held) — results are the unsharded ones, whoever owns what."""
+    world, dim, m = 3, 128, 32
+    rng = np.random.default_rng(21)
+    s = train.synthetic_index(50000, dim, 64, m, seed=15, skew=0.9, empty_parts=2)
+    raw = rng.normal(size=(50000, dim)).astype(np.float32)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
+    q = (s["centroids"][rng.integers(0, 8, size=64)] + rng.normal(0, 0.3, size=(64, dim))).astype(np.float32)  # a skewed query load
+    probes = np.stack([o.select_probes(o.coarse(x), 8) for x in q])
+    hits = np.bincount(probes.ravel().astype(np.int64), minlength=64).astype(np.float32)
+    owner = lancedb_amd.shard_plan(s["part_offsets"], world, weights=hits)
+    assert (owner != lancedb_amd.shard_plan(s["part_offsets"], world)).any()
+    shards = [lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw,
+                                     shard_count=world, shard_rank=r, part_owner=owner) for r in range(world)]
+    assert sum(sh.info()[0] for sh in shards) == 50000
+    comms = Comm.loopback(world)
+    for kw in (dict(k=10, nprobe_min=8, nprobe_max=8), dict(k=10, nprobe_min=8, nprobe_max=8, refine_factor=5)):
+        exp = o.search(q, **kw)
+        got = run_ranks([lambda r=r: ShardedSearcher(shards[r], comms[r]).search(q, _abi.make_params(**kw)) for r in range(world)])
+        for r in range(world):
+            _same(got[r], exp, f"rank {r} {kw}")
+    st = comms[0].stats()
+    assert st["imbalance"] < 1.35  # the unweighted plan on this load: one shard scans most of the rows
+    with pytest.raises(lancedb_amd.InvalidInput, match="not a shard"):
+        lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], shard_count=world,
+                               shard_rank=0, part_owner=np.full(64, 7, np.uint32))

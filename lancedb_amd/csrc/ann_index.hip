@@ -807,11 +807,27 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
     } else {
     if (small_front) {
+      // lanes per centroid: the smallest split that gives the chip two waves per CU
+      int lpc = 1;
+      if ((ix->dim & 3u) == 0 && dev_knob("MI355_LAT_COARSE_SPLIT", 1))
+        while (lpc < 16 && (uint64_t)ix->nlist * lpc < 2ull * 64 * ix->n_cus) lpc = lpc == 1 ? 4 : lpc * 2;
+      if (lpc > 1) {
+        const size_t lds = coarse_split_lds(n, ix->dim, lpc);
+        auto go = [&](auto kern) -> int {
+          if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(kern, dim3((ix->nlist * lpc + 63) / 64), dim3(64), lds, st, q, n, ix->dim, ix->metric, view.centroids,
+                             view.cnorm, ix->nlist, ix->w_qp.as<float>(), ix->w_qq.as<float>(), ix->w_coarse.as<float>());
+          return MI355_OK;
+        };
+        const int rc = lpc == 4 ? go(k_coarse_split<4>) : lpc == 8 ? go(k_coarse_split<8>) : go(k_coarse_split<16>);
+        if (rc != MI355_OK) return rc;
+      } else {
       if (small_lds > 48u * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
       hipLaunchKernelGGL(k_coarse_small, dim3((ix->nlist + 63) / 64), dim3(64), small_lds, st, q, n, ix->dim, ix->metric,
                          view.centroids, view.cnorm, ix->nlist, ix->w_qp.as<float>(), ix->w_qq.as<float>(),
                          ix->w_coarse.as<float>());
+      }
     } else if (dev_knob("MI355_COARSE_VALU", 0))  // dev knob: the register-tiled VALU kernel (same bits)
       hipLaunchKernelGGL(k_coarse_tile, dim3((ix->nlist + CO_T - 1) / CO_T, (n + CO_T - 1) / CO_T),
                          dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,

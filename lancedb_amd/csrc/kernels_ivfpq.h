@@ -375,6 +375,129 @@ static __global__ __launch_bounds__(64) void k_coarse_small(const float* __restr
   }
 }
 
+// The same launch for centroid tables too small to give every CU a wave at 64 centroids per wave (nlist 4096 is
+// 64 waves on 256 CUs, each waiting for twelve dependent rounds of loads: 40 us): LPC lanes share a centroid.  They
+// load its row in 16-B pieces side by side (16 * LPC contiguous bytes per load instruction and centroid), stage a
+// round of PF * LPC pieces in LDS and each lane then walks the whole round in d order for ITS queries (query j is
+// lane j % LPC's), so every accumulator is still the one d-ascending chain.  LPC times the waves = LPC times the
+// bytes in flight; the chains themselves take what they took.
+template <int LPC>
+static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restrict__ q, uint32_t nq, uint32_t dim, uint32_t metric,
+                                                            const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist,
+                                                            float* __restrict__ qp, float* __restrict__ qq_out,
+                                                            float* __restrict__ out /*[nq, nlist]*/) {
+  constexpr int CPW = 64 / LPC;                      // centroids per wave
+  constexpr int PF = 16;                             // pieces in flight per lane
+  constexpr int RP = PF * LPC;                       // pieces of a row per round
+  constexpr int JPL = (CS_MAXQ + LPC - 1) / LPC;     // queries per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t dimq = dim + 4u;                    // dim % 4 == 0 here; the pad staggers the queries' banks
+  float* sq = (float*)smem;                          // [nq][dimq]
+  float* sqq = sq + (size_t)nq * dimq;               // [CS_MAXQ]
+  float4* stage = (float4*)(sqq + CS_MAXQ);          // [CPW][RP + 1]
+  const int lane = threadIdx.x;
+  for (uint32_t j = 0; j < nq; ++j)
+    for (uint32_t d = lane; d < dim; d += 64) sq[(size_t)j * dimq + d] = q[(size_t)j * dim + d];
+  __syncthreads();
+  auto chain_sq = [&](const float* v) -> float {
+    float acc = 0.f;
+    for (uint32_t d = 0; d < dim; d += 4) {
+      const float4 x = *(const float4*)(v + d);
+      acc = __fmaf_rn(x.x, x.x, acc);
+      acc = __fmaf_rn(x.y, x.y, acc);
+      acc = __fmaf_rn(x.z, x.z, acc);
+      acc = __fmaf_rn(x.w, x.w, acc);
+    }
+    return acc;
+  };
+  if ((uint32_t)lane < nq) sqq[lane] = chain_sq(sq + (size_t)lane * dimq);
+  __syncthreads();
+  if (metric == MI355_METRIC_COSINE) {
+    for (uint32_t j = 0; j < nq; ++j) {
+      const float nrm = ieee_sqrtf(sqq[j]);
+      for (uint32_t d = lane; d < dim; d += 64) sq[(size_t)j * dimq + d] = ieee_divf(sq[(size_t)j * dimq + d], nrm);
+    }
+    __syncthreads();
+    if ((uint32_t)lane < nq) sqq[lane] = chain_sq(sq + (size_t)lane * dimq);
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    for (uint32_t j = 0; j < nq; ++j)
+      for (uint32_t d = lane; d < dim; d += 64) qp[(size_t)j * dim + d] = sq[(size_t)j * dimq + d];
+    if ((uint32_t)lane < nq) qq_out[lane] = sqq[lane];
+  }
+  const uint32_t cl = (uint32_t)lane / LPC, sub = (uint32_t)lane % LPC;
+  const uint32_t c = blockIdx.x * CPW + cl;
+  const float4* row = (const float4*)(cen + (size_t)min(c, nlist - 1u) * dim);
+  float4* mine = stage + (size_t)cl * (RP + 1);
+  const uint32_t np = dim / 4u;
+  float acc[JPL];
+  const float* qv[JPL];
+  bool on[JPL];
+#pragma unroll
+  for (int i = 0; i < JPL; ++i) {
+    const uint32_t j = sub + (uint32_t)i * LPC;
+    acc[i] = 0.f;
+    on[i] = j < nq;
+    qv[i] = sq + (size_t)(on[i] ? j : 0u) * dimq;
+  }
+  for (uint32_t p0 = 0; p0 < np; p0 += RP) {
+    float4 r[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
+      if (pc < np) r[u] = row[pc];
+    }
+    __syncthreads();  // the previous round has been read
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
+      if (pc < np) mine[u * LPC + sub] = r[u];
+    }
+    __syncthreads();
+    const uint32_t lim = min((uint32_t)RP, np - p0);
+    if (on[0]) {
+      for (uint32_t pp = 0; pp < lim; pp += 4) {  // np % 4 need not be 0: the inner bound is checked
+        float4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (pp + e < lim) v[e] = mine[pp + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (pp + e >= lim) break;
+#pragma unroll
+          for (int i = 0; i < JPL; ++i) {
+            if (on[i]) {
+              const float4 x = *(const float4*)(qv[i] + 4u * (p0 + pp + e));
+              acc[i] = __fmaf_rn(x.x, v[e].x, acc[i]);
+              acc[i] = __fmaf_rn(x.y, v[e].y, acc[i]);
+              acc[i] = __fmaf_rn(x.z, v[e].z, acc[i]);
+              acc[i] = __fmaf_rn(x.w, v[e].w, acc[i]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (c >= nlist) return;
+  const float cnv = cn[c];
+#pragma unroll
+  for (int i = 0; i < JPL; ++i) {
+    if (on[i]) {
+      const uint32_t j = sub + (uint32_t)i * LPC;
+      float v;
+      if (metric == MI355_METRIC_DOT)
+        v = 1.0f - acc[i];
+      else
+        v = __fmaf_rn(-2.0f, acc[i], sqq[j] + cnv);
+      out[(size_t)j * nlist + c] = v;
+    }
+  }
+}
+static inline size_t coarse_split_lds(uint32_t nq, uint32_t dim, int lpc) {
+  return ((size_t)nq * (dim + 4u) + CS_MAXQ) * sizeof(float) + (size_t)(64 / lpc) * (16 * lpc + 1) * 16;
+}
+
 // ------------------------------------------------------------------ K1b ----
 // One 256-thread block per query: 4-pass byte radix select of the nprobe-th
 // smallest coarse key, then emit {key < T} (any order) followed by the
@@ -876,6 +999,7 @@ static inline MergeArgs merge_args_dense(const Cand* cand, uint32_t n_src, uint3
   return m;
 }
 
+#define MERGE_PRE_SRC 1024u
 template <int KPL>
 __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
   const int lane = threadIdx.x;
@@ -906,7 +1030,75 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
   // (source = t / kk_in) and the record's own position is fetched when the row is emitted; otherwise the position
   // itself travels: no dependent load per emitted row (ten serial round trips in a single query's merge)
   const bool by_slot = a.out_owner != nullptr;
+  // With counts and up to MERGE_PRE_SRC sources the filled slots are addressed directly: the counts are loaded
+  // together (one global round trip), their exclusive prefix goes to LDS, and filled slot t of the query is found
+  // by a binary search over it — a scan leaves a handful of rows in most work items once the query has a bound, so
+  // the sliced single query's 512 sources x 10 slots are one or two tiles of 64 instead of eighty, and the walk
+  // costs two round trips instead of two per eight sources.
+  __shared__ uint32_t s_pre[MERGE_PRE_SRC + 1];
+  const bool compact = a.src_cnt && a.n_src <= MERGE_PRE_SRC;
+  uint32_t n_filled = 0;
+  if (compact) {
+    constexpr int G = 8;
+    for (uint32_t s0 = 0; s0 < a.n_src; s0 += G * MI355_WAVE) {
+      uint32_t c[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t sidx = s0 + u * MI355_WAVE + lane;
+        c[u] = sidx < a.n_src ? min(a.src_cnt[(size_t)sidx * a.cnt_stride + (size_t)b * a.cnt_q_stride], a.kk_in) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (s0 + u * MI355_WAVE >= a.n_src) break;
+        uint32_t inc = c[u];
+#pragma unroll
+        for (int off = 1; off < MI355_WAVE; off <<= 1) {
+          const uint32_t o = __shfl_up(inc, off);
+          if (lane >= off) inc += o;
+        }
+        const uint32_t sidx = s0 + u * MI355_WAVE + lane;
+        if (sidx < a.n_src) s_pre[sidx] = n_filled + inc - c[u];
+        n_filled += __shfl(inc, MI355_WAVE - 1);
+      }
+    }
+    if (lane == 0) s_pre[a.n_src] = n_filled;
+    __syncthreads();
+  }
   auto gen = [&](WaveTopK<KPL>& top) {
+    if (compact) {
+      constexpr int G = 8;
+      for (uint32_t t0 = 0; t0 < n_filled; t0 += G * MI355_WAVE) {
+        Cand c[G];
+        bool ok[G];
+        uint32_t slot[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const uint32_t t = t0 + u * MI355_WAVE + lane;
+          c[u].d = 0.f;
+          c[u].pos = CAND_EMPTY_POS;
+          c[u].id = 0;
+          ok[u] = false;
+          slot[u] = 0;
+          if (t0 + u * MI355_WAVE >= n_filled) break;
+          uint32_t lo = 0, hi = a.n_src;  // the last source whose prefix is <= t holds slot t (empty sources share a prefix)
+          while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= t) lo = mid; else hi = mid;
+          }
+          if (t < n_filled) {
+            const uint32_t r = t - s_pre[lo];
+            slot[u] = lo * a.kk_in + r;
+            c[u] = src[(size_t)lo * a.src_stride + r];
+            ok[u] = c[u].pos != CAND_EMPTY_POS && c[u].d == c[u].d;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (t0 + u * MI355_WAVE < n_filled) top.offer(ok[u], c[u].d, by_slot ? slot[u] : c[u].pos, c[u].id, lane);
+        }
+      }
+      return;
+    }
     if (a.src_cnt && a.kk_in > 32u) {
       // long lists with counts: walk source by source and read only the filled part (with a query bound in
       // place most of a scan's work items return a handful of rows, or none, in their kk slots)

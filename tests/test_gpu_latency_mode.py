@@ -62,3 +62,19 @@ def test_small_batches_take_the_fused_prep_and_coarse_launch(oracle, metric, dim
         ub = float(o.search(q, k=30, nprobe_min=20, nprobe_max=20)[1][0, 20])
         kw = dict(k=25, nprobe_min=2, nprobe_max=20, upper_bound=ub)
         _same(ix.search(q, **kw), o.search(q, **kw))
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+@pytest.mark.parametrize("nlist,dim,m", [(5000, 768, 96), (9000, 96, 12), (2500, 200, 25)])
+def test_small_batches_split_centroid_rows_across_lanes(oracle, metric, nlist, dim, m):
+    """Centroid tables that would leave most CUs without a wave at one centroid per lane give 4 / 8 / 16 lanes to a
+    centroid (k_coarse_split): rows staged in rounds of 64 / 128 / 256 pieces, the last round partial, queries dealt
+    to the lanes of a centroid.  Probe lists and results are the oracle's."""
+    rng = np.random.default_rng(nlist)
+    s = train.synthetic_index(8 * nlist, dim, nlist, m, seed=5, skew=0.5, empty_parts=3)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
+    ix.configure(graph=False, coalesce=False)
+    for nq in (1, 3, 5, 8):
+        q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.4, size=(nq, dim))).astype(np.float32)
+        _same(ix.search(q, k=10, nprobe_min=24, nprobe_max=24), o.search(q, k=10, nprobe_min=24, nprobe_max=24))

@@ -876,9 +876,13 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       pa.act = act;
       const uint32_t pb = (pa.n_pairs + 255) / 256;
       // (qthr, the queries' running distance bounds, was reset by k_select_probes / k_take_probes)
-      hipLaunchKernelGGL(k_plan_count, dim3(pb), dim3(256), 0, st, pa);
-      hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, pa);
-      hipLaunchKernelGGL(k_plan_fill, dim3(pb), dim3(256), 0, st, pa);
+      if (pa.n_pairs <= PLAN_FUSED_MAX_PAIRS && dev_knob("MI355_PLAN_FUSED", 1)) {
+        hipLaunchKernelGGL(k_plan_fused, dim3(1), dim3(1024), 0, st, pa);
+      } else {
+        hipLaunchKernelGGL(k_plan_count, dim3(pb), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, pa);
+        hipLaunchKernelGGL(k_plan_fill, dim3(pb), dim3(256), 0, st, pa);
+      }
       HIP_TRY(hipGetLastError());
       SkewArgs ka;
       ka.ix = view;
@@ -924,6 +928,22 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     }
     if (prof) HIP_TRY(hipEventRecord(es.ev[3], st));
 
+    if (!ix->merge_block_tried) {  // the block reduction's lists take more LDS than a kernel gets by default
+      ix->merge_block_tried = true;
+      ix->merge_block_ok =
+          hipFuncSetAttribute((const void*)k_merge_cands<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MERGE_BLOCK_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_merge_cands<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MERGE_BLOCK_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_merge_cands<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MERGE_BLOCK_LDS) == hipSuccess;
+      if (!ix->merge_block_ok) (void)hipGetLastError();
+    }
+    // the reduction of the work items' candidate slots: one wave per query; a handful of queries (whose items all ran at
+    // once and all returned full lists) get a 16-wave block each, which cuts the slots to a short list first
+    auto launch_merge = [&](int kpl, uint32_t nq_, hipStream_t s_, const MergeArgs& m_) {
+      if (m_.src_cnt && nq_ <= (uint32_t)dev_knob("MI355_MERGE_BLOCK_MAX_NQ", 64) && ix->merge_block_ok)
+        launch_by_kpl(kpl, k_merge_cands<1, 16>, k_merge_cands<2, 16>, k_merge_cands<4, 16>, dim3(nq_), dim3(1024), MERGE_BLOCK_LDS, s_, m_);
+      else
+        launch_by_kpl(kpl, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(nq_), dim3(64), 0, s_, m_);
+    };
     MergeArgs ma = merge_args_dense(ix->w_cand.as<Cand>(), nprobe * n_slices, pl.kk, n, pl.k);
     ma.ctl = d_ctl;
     ma.act = act;
@@ -937,14 +957,14 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ma.k_out = pl.kk;
       ma.out_cand = pl.out_cand + (size_t)q0 * pl.kk;
       ma.out_cnt = d_cnt_ann + q0;
-      launch_by_kpl(kpl_kk, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
+      launch_merge(kpl_kk, n, st, ma);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
     } else if (!pl.refine) {
       ma.out_ids = d_ids + (size_t)q0 * pl.k;
       ma.out_dist = d_dist + (size_t)q0 * pl.k;
       ma.out_cnt = d_cnt + q0;
-      launch_by_kpl(kpl_k, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
+      launch_merge(kpl_k, n, st, ma);
       HIP_TRY(hipGetLastError());
       if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
     } else {
@@ -954,7 +974,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ma.k_out = pl.kk;
       ma.out_cand = ann;
       ma.out_cnt = d_cnt_ann + q0;
-      launch_by_kpl(kpl_kk, k_merge_cands<1>, k_merge_cands<2>, k_merge_cands<4>, dim3(n), dim3(64), 0, st, ma);
+      launch_merge(kpl_kk, n, st, ma);
       HIP_TRY(hipGetLastError());
       hipStream_t rs = st;
       if (defer) {  // the re-rank leaves the search stream: the next call's scan does not wait for it

@@ -190,6 +190,7 @@ struct mi355_index {
   // code layout: MI355_SCAN_PAIR = [mb][pstride] blocks, MI355_SCAN_SKEW = pre-skewed streams
   uint32_t layout = MI355_SCAN_PAIR;
   uint32_t n_cus = 256;
+  bool merge_block_tried = false, merge_block_ok = false;  // k_merge_cands<KPL, 16> may use MERGE_BLOCK_LDS bytes
   uint32_t wall_khz = 100000;  // rate of the constant device clock behind timeout_ms (wall_clock64)
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
   // workspace

@@ -1000,9 +1000,92 @@ static inline MergeArgs merge_args_dense(const Cand* cand, uint32_t n_src, uint3
 }
 
 #define MERGE_PRE_SRC 1024u
-template <int KPL>
-__global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
-  const int lane = threadIdx.x;
+#define MERGE_SHORT_CAP 8192u  // rows of the first short list (distance + slot, 8 B each in LDS)
+#define MERGE_FINAL_CAP 2048u  // rows ranked against each other at the end
+#define MERGE_BLOCK_LDS ((MERGE_SHORT_CAP * 2u + MERGE_FINAL_CAP * 5u + 256u + 8u) * 4u)
+// k-th smallest (1-based, k <= n) of the n keys get(0..n-1) by a byte-wise radix select over the whole block: four
+// passes of {256-bin LDS histogram, bin pick by wave 0}.  hist[256], st[2] (prefix, need) are LDS; every thread of
+// the NT-thread block calls it.
+template <int NT, typename Get>
+__device__ __forceinline__ uint32_t block_kth_smallest_key(Get get, uint32_t n, uint32_t k, uint32_t* hist, uint32_t* st) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  if (tid == 0) {
+    st[0] = 0;
+    st[1] = k;
+  }
+  uint32_t mask = 0;
+  for (int byte = 3; byte >= 0; --byte) {
+    if (tid < 256u) hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = st[0], need = st[1];
+    for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+      const uint32_t i = i0 + tid;
+      const uint32_t key = i < n ? get(i) : 0u;
+      bool mine = i < n && (key & mask) == prefix;
+      const uint32_t bin = (key >> (8 * byte)) & 255u;
+      // distances of one query share their leading bits: a wave's keys fall into one or two bins in the first
+      // passes, so the two most common bins are counted once per wave, the rest lane by lane
+      uint64_t rem = __ballot(mine);
+      for (int round = 0; round < 2 && rem; ++round) {
+        const int leader = __ffsll((unsigned long long)rem) - 1;
+        const uint32_t lb = __shfl(bin, leader);
+        const uint64_t same = __ballot(mine && bin == lb);
+        if ((int)lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll((unsigned long long)same));
+        if (bin == lb) mine = false;
+        rem &= ~same;
+      }
+      if (mine) atomicAdd(&hist[bin], 1u);
+    }
+    __syncthreads();
+    if (tid < 64u) {  // lane l owns bins 4l .. 4l+3
+      const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const uint32_t sum = h0 + h1 + h2 + h3;
+      uint32_t inc = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += o;
+      }
+      const uint32_t exc = inc - sum;
+      if (exc < need && need <= inc) {  // exactly one lane
+        uint32_t bin = 4 * lane, before = exc;
+        if (need > before + h0) {
+          before += h0;
+          ++bin;
+          if (need > before + h1) {
+            before += h1;
+            ++bin;
+            if (need > before + h2) {
+              before += h2;
+              ++bin;
+            }
+          }
+        }
+        st[0] = prefix | (bin << (8 * byte));
+        st[1] = need - before;
+      }
+    }
+    mask |= 255u << (8 * byte);
+    __syncthreads();
+  }
+  return st[0];
+}
+
+// NW > 1 (a batch too small to fill the chip with single waves — the sliced single query's 512 work items all run at
+// once, without a query bound, and every one returns its own kk best: 5120 .. 128 000 filled slots for ONE wave, whose
+// selector pays ~1 us per row it admits).  The block of NW waves selects by keys instead (f32 sort key of the distance):
+//   1. bound: when the query has more than MERGE_SHORT_CAP filled slots, the k_out-th smallest key of a sample of
+//      64 * NW of them (the first rows of every source: the lists are sorted) — at least k_out slots lie at or below it;
+//   2. sweep: all slots, independent loads; the ones at or below the bound go to a short list in LDS (distance, slot);
+//   3. the exact k_out-th smallest key of the short list (radix select in LDS) cuts it to the final list: k_out rows
+//      plus the ties of the last one;
+//   4. the final list is ranked by counting in (distance, rowid) order — ids are unique, they are fetched where two
+//      distances are equal — and the rows ranked below k_out are written where they belong.
+// A list that overflows (more than MERGE_SHORT_CAP rows under the bound, more than MERGE_FINAL_CAP with the ties) or
+// k_out > 64 * NW: wave 0 walks everything as the one-wave kernel does.
+template <int KPL, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t b = blockIdx.x;
   if (a.ctl && a.ctl->timed_out) return;
   if (!a.act.on(b)) return;
@@ -1013,7 +1096,7 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
   uint32_t* op = a.out_pos ? a.out_pos + (size_t)b * a.k_out : nullptr;
   uint32_t* oo = a.out_owner ? a.out_owner + (size_t)b * a.k_out : nullptr;
   Cand* oc = a.out_cand ? a.out_cand + (size_t)b * a.k_out : nullptr;
-  for (uint32_t g = lane; g < a.k_out; g += MI355_WAVE) {
+  for (uint32_t g = tid; g < a.k_out; g += MI355_WAVE * NW) {
     if (oi) oi[g] = ~0ull;
     if (od) od[g] = __builtin_huge_valf();
     if (op) op[g] = CAND_EMPTY_POS;
@@ -1030,12 +1113,158 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
   // (source = t / kk_in) and the record's own position is fetched when the row is emitted; otherwise the position
   // itself travels: no dependent load per emitted row (ten serial round trips in a single query's merge)
   const bool by_slot = a.out_owner != nullptr;
+  auto emit_row = [&](uint32_t rk, float d, uint32_t t, uint64_t id) {
+    uint32_t sidx = 0, pos = t;
+    if (by_slot) {
+      sidx = t / a.kk_in;
+      pos = src[(size_t)sidx * a.src_stride + t % a.kk_in].pos;
+    }
+    if (oi) oi[rk] = id;
+    if (od) od[rk] = d;
+    if (op) op[rk] = pos;
+    if (oo) oo[rk] = sidx;
+    if (oc) {
+      Cand e;
+      e.d = d;
+      e.pos = pos;
+      e.id = id;
+      oc[rk] = e;
+    }
+  };
+  __shared__ uint32_t s_pre[MERGE_PRE_SRC + 1];
+  if constexpr (NW > 1) {
+    constexpr uint32_t NT = MI355_WAVE * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char merge_lds[];
+    float* sl_d = (float*)merge_lds;                      // [MERGE_SHORT_CAP] (the sample's keys before the sweep)
+    uint32_t* sl_t = (uint32_t*)(sl_d + MERGE_SHORT_CAP);  // [MERGE_SHORT_CAP] slot index
+    uint32_t* fl = sl_t + MERGE_SHORT_CAP;                // [MERGE_FINAL_CAP] indices into the short list
+    uint64_t* f_id = (uint64_t*)(fl + MERGE_FINAL_CAP);   // [MERGE_FINAL_CAP] the final list: row ids,
+    float* f_d = (float*)(f_id + MERGE_FINAL_CAP);        // [MERGE_FINAL_CAP] distances (-0 as +0),
+    uint32_t* f_t = (uint32_t*)(f_d + MERGE_FINAL_CAP);   // [MERGE_FINAL_CAP] slots
+    uint32_t* hist = f_t + MERGE_FINAL_CAP;               // [256]
+    uint32_t* st = hist + 256;                            // [0..1] radix state, [2] short-list rows, [3] final rows
+    if (a.src_cnt && a.n_src <= MERGE_PRE_SRC && a.k_out <= NT) {  // block-uniform
+      uint32_t filled = 0;
+      for (uint32_t sidx = tid; sidx < a.n_src; sidx += NT) {
+        const uint32_t c = min(a.src_cnt[(size_t)sidx * a.cnt_stride + (size_t)b * a.cnt_q_stride], a.kk_in);
+        s_pre[sidx] = c;
+        filled += c;
+      }
+      if (tid == 0) st[2] = st[3] = st[4] = 0;
+      __syncthreads();
+      if (filled) atomicAdd(&st[4], filled);
+      __syncthreads();
+      const uint32_t n_filled = st[4];
+      auto key_of = [&](const Cand& c) -> uint32_t {  // 0xFFFFFFFF: not a candidate; -0 orders as +0, like the compare
+        return (c.pos != CAND_EMPTY_POS && c.d == c.d) ? f32_sort_key(c.d) : 0xFFFFFFFFu;
+      };
+      uint32_t tau = 0xFFFFFFFFu;
+      if (n_filled > MERGE_SHORT_CAP) {
+        const uint32_t sidx = (uint32_t)tid % a.n_src, r = (uint32_t)tid / a.n_src;
+        uint32_t key = 0xFFFFFFFFu;
+        if (r < s_pre[sidx]) key = key_of(src[(size_t)sidx * a.src_stride + r]);
+        uint32_t* s_keys = (uint32_t*)sl_d;
+        s_keys[tid] = key;
+        __syncthreads();
+        tau = block_kth_smallest_key<NT>([&](uint32_t i) { return s_keys[i]; }, NT, a.k_out, hist, st);
+        __syncthreads();  // the keys are dead: the sweep reuses their space
+      }
+      constexpr int G = 4;
+      for (uint32_t t0 = 0; t0 < n; t0 += G * NT) {
+        Cand c[G];
+        bool in[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const uint32_t t = t0 + (uint32_t)u * NT + tid;
+          in[u] = t < n && t % a.kk_in < s_pre[t / a.kk_in];
+          if (in[u]) c[u] = src[(size_t)(t / a.kk_in) * a.src_stride + t % a.kk_in];
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const uint32_t t = t0 + (uint32_t)u * NT + tid;
+          const uint32_t key = in[u] ? key_of(c[u]) : 0xFFFFFFFFu;
+          const bool take = key != 0xFFFFFFFFu && key <= tau;
+          const uint64_t m = __ballot(take);
+          if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&st[2], (uint32_t)__popcll((unsigned long long)m));
+            base = __shfl(base, 0);
+            const uint32_t at = base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+            if (take && at < MERGE_SHORT_CAP) {
+              sl_d[at] = c[u].d + 0.0f;
+              sl_t[at] = t;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t n_short = st[2];
+      bool done = false;
+      if (n_short <= MERGE_SHORT_CAP) {
+        uint32_t tau2 = 0xFFFFFFFFu;
+        if (n_short > a.k_out)
+          tau2 = block_kth_smallest_key<NT>([&](uint32_t i) { return f32_sort_key(sl_d[i]); }, n_short, a.k_out, hist, st);
+        for (uint32_t i0 = 0; i0 < n_short; i0 += NT) {
+          const uint32_t i = i0 + tid;
+          const bool take = i < n_short && f32_sort_key(sl_d[i]) <= tau2;
+          const uint64_t m = __ballot(take);
+          if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&st[3], (uint32_t)__popcll((unsigned long long)m));
+            base = __shfl(base, 0);
+            const uint32_t at = base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+            if (take && at < MERGE_FINAL_CAP) fl[at] = i;
+          }
+        }
+        __syncthreads();
+        const uint32_t n_fin = st[3];
+#ifdef MI355_DEV_COUNTERS  // dev[5] (the scan's redone passes, 0 up to kk 128) doubles as: short rows + 1e5 * final rows
+        if (tid == 0 && a.ctl) atomicAdd(const_cast<uint32_t*>(&a.ctl->dev[5]), n_short + 100000u * min(n_fin, 9999u));
+#endif
+        if (n_fin <= MERGE_FINAL_CAP) {
+          for (uint32_t i = tid; i < n_fin; i += NT) {
+            const uint32_t me = fl[i], t = sl_t[me];
+            f_d[i] = sl_d[me];
+            f_t[i] = t;
+            f_id[i] = src[(size_t)(t / a.kk_in) * a.src_stride + t % a.kk_in].id;
+          }
+          __syncthreads();
+          for (uint32_t i = tid; i < n_fin; i += NT) {
+            const float d = f_d[i];
+            const uint64_t id = f_id[i];
+            uint32_t rank = 0;
+            for (uint32_t j0 = 0; j0 < n_fin; j0 += 4) {  // broadcast reads, four distances at a time
+              const float4 dj = *(const float4*)&f_d[j0];
+              const float dv[4] = {dj.x, dj.y, dj.z, dj.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (j0 + e >= n_fin) break;
+                bool lt = dv[e] < d;
+                if (dv[e] == d) lt = f_id[j0 + e] < id;  // a tie on the distance: the row ids decide (ids are unique)
+                rank += lt ? 1u : 0u;
+              }
+            }
+            if (rank < a.k_out) {
+              const uint32_t t = f_t[i];
+              const Cand c = src[(size_t)(t / a.kk_in) * a.src_stride + t % a.kk_in];
+              emit_row(rank, c.d, by_slot ? t : c.pos, c.id);
+            }
+          }
+          if (tid == 0) a.out_cnt[b] = min(n_fin, a.k_out);
+          done = true;
+        }
+      }
+#ifdef MI355_DEV_COUNTERS
+      if (!done && tid == 0 && a.ctl) atomicAdd(const_cast<uint32_t*>(&a.ctl->dev[5]), 1000000000u);
+#endif
+      if (done) return;
+    }
+    if (wid != 0) return;
+  }
   // With counts and up to MERGE_PRE_SRC sources the filled slots are addressed directly: the counts are loaded
   // together (one global round trip), their exclusive prefix goes to LDS, and filled slot t of the query is found
   // by a binary search over it — a scan leaves a handful of rows in most work items once the query has a bound, so
-  // the sliced single query's 512 sources x 10 slots are one or two tiles of 64 instead of eighty, and the walk
-  // costs two round trips instead of two per eight sources.
-  __shared__ uint32_t s_pre[MERGE_PRE_SRC + 1];
+  // a walk over the filled slots only costs two round trips plus a tile of 64 per 64 rows actually there.
   const bool compact = a.src_cnt && a.n_src <= MERGE_PRE_SRC;
   uint32_t n_filled = 0;
   if (compact) {
@@ -1152,24 +1381,7 @@ __global__ __launch_bounds__(64) void k_merge_cands(MergeArgs a) {
       }
     }
   };
-  const uint32_t n_out = wave_select_sorted<KPL>(a.k_out, lane, gen, [&](uint32_t rk, float d, uint32_t t, uint64_t id) {
-    uint32_t sidx = 0, pos = t;
-    if (by_slot) {
-      sidx = t / a.kk_in;
-      pos = src[(size_t)sidx * a.src_stride + t % a.kk_in].pos;
-    }
-    if (oi) oi[rk] = id;
-    if (od) od[rk] = d;
-    if (op) op[rk] = pos;
-    if (oo) oo[rk] = sidx;
-    if (oc) {
-      Cand e;
-      e.d = d;
-      e.pos = pos;
-      e.id = id;
-      oc[rk] = e;
-    }
-  });
+  const uint32_t n_out = wave_select_sorted<KPL>(a.k_out, lane, gen, emit_row);
   if (lane == 0) a.out_cnt[b] = n_out;
 }
 

@@ -257,9 +257,7 @@ __device__ __forceinline__ uint32_t plan_class(const PlanArgs& a, uint32_t i) {
   return (a.best_first && (i % a.nprobe) == 0u) ? 1u : 0u;
 }
 
-static __global__ void k_plan_count(PlanArgs a) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n_pairs) return;
+__device__ __forceinline__ void plan_count_pair(const PlanArgs& a, uint32_t i) {
   if (!a.act.on(i / a.nprobe)) return;
   const uint32_t p = a.probes[i];
   // ids outside the index (mi355_search_probes), empty and not-owned partitions make no work item; a
@@ -267,13 +265,15 @@ static __global__ void k_plan_count(PlanArgs a) {
   for (uint32_t sl = 0; sl < a.n_slices; ++sl) a.cand_cnt[(size_t)i * a.n_slices + sl] = 0u;
   if (p < a.nlist && a.plen[p]) atomicAdd(&a.cnt[p + plan_class(a, i) * a.nlist], a.n_slices);
 }
+static __global__ void k_plan_count(PlanArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n_pairs) plan_count_pair(a, i);
+}
 
 // one 1024-thread block: exclusive scan of the item counts in queue order.  The virtual sequence is,
 // queue by queue, [class-1 counts of the queue's partitions (best_first only)] [class-0 counts of the
 // same partitions], partitions in the index's static `order`.
-static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
-  __shared__ uint32_t s_part[1024];
-  __shared__ uint32_t s_xf[9];
+__device__ __forceinline__ void plan_scan_block(const PlanArgs& a, uint32_t* s_part /*[1024]*/, uint32_t* s_xf /*[9]*/) {
   const uint32_t tid = threadIdx.x;
   const uint32_t ncls = a.best_first ? 2u : 1u;
   const uint32_t nv = ncls * a.nlist;
@@ -319,10 +319,13 @@ static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
   }
   if (tid < 8) a.heads[tid * SK_HEAD_STRIDE] = 0;
 }
+static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
+  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_xf[9];
+  plan_scan_block(a, s_part, s_xf);
+}
 
-static __global__ void k_plan_fill(PlanArgs a) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n_pairs) return;
+__device__ __forceinline__ void plan_fill_pair(const PlanArgs& a, uint32_t i) {
   if (!a.act.on(i / a.nprobe)) return;
   const uint32_t p = a.probes[i];
   const uint32_t len = p < a.nlist ? a.plen[p] : 0u;
@@ -340,6 +343,26 @@ static __global__ void k_plan_fill(PlanArgs a) {
     it.pair = a.n_slices > 1u ? (i | (sl << 24)) : i;
     a.items[at + sl] = it;
   }
+}
+static __global__ void k_plan_fill(PlanArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n_pairs) plan_fill_pair(a, i);
+}
+// The three steps as ONE workgroup for the batches of a few queries (a launch boundary costs more than the steps): the
+// counts, offsets and fill cursors are only touched by this workgroup's own atomics / stores between its barriers
+// (device-scope atomics execute at L2, stores write through, and the barrier waits for both), and no line of them
+// was read earlier in the kernel.
+#define PLAN_FUSED_MAX_PAIRS 4096u
+static __global__ __launch_bounds__(1024) void k_plan_fused(PlanArgs a) {
+  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_xf[9];
+  for (uint32_t i = threadIdx.x; i < a.n_pairs; i += 1024u) plan_count_pair(a, i);
+  __threadfence();
+  __syncthreads();
+  plan_scan_block(a, s_part, s_xf);
+  __threadfence();
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < a.n_pairs; i += 1024u) plan_fill_pair(a, i);
 }
 
 // ------------------------------------------------------------------- scan ----

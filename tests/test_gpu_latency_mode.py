@@ -78,3 +78,26 @@ def test_small_batches_split_centroid_rows_across_lanes(oracle, metric, nlist, d
     for nq in (1, 3, 5, 8):
         q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.4, size=(nq, dim))).astype(np.float32)
         _same(ix.search(q, k=10, nprobe_min=24, nprobe_max=24), o.search(q, k=10, nprobe_min=24, nprobe_max=24))
+
+
+@pytest.mark.parametrize("dup", [3000, 40, 1])
+def test_block_merge_short_list_with_ties_and_overflow(oracle, dup):
+    """A handful of queries reduce their work items' slots with a 16-wave block that first cuts them to a short list
+    under a bound (k_merge_cands<KPL, 16>).  Rows that share a code vector tie exactly: `dup` = 3000 makes every slot
+    of every slice tie with thousands of others (the short list overflows and one wave walks all slots), 40 ties the
+    winners across slices at the bound, 1 is the plain case.  Any k up to 1024 takes the block; results are the
+    oracle's (ties by row id)."""
+    rng = np.random.default_rng(dup)
+    n, dim, m, nlist = 400_000, 64, 16, 24
+    s = train.synthetic_index(n, dim, nlist, m, seed=11, skew=0.6, empty_parts=1)
+    if dup > 1:
+        base = rng.integers(0, 256, size=((n + dup - 1) // dup, m), dtype=np.uint8)
+        s["codes"] = np.ascontiguousarray(base[rng.integers(0, base.shape[0], size=n)])
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    ix.configure(graph=False, coalesce=False)
+    for nq, nprobe in ((1, 8), (2, 20), (1, 24)):
+        q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.5, size=(nq, dim))).astype(np.float32)
+        for k in (1, 10, 64, 100, 250, 1000, 1500):
+            kw = dict(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
+            _same(ix.search(q, **kw), o.search(q, **kw))

@@ -379,14 +379,16 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
       order.insert(order.end(), queue[x].begin(), queue[x].end());
     }
     xcd_first[8] = nlist;
-    ST_TRY(ix->order.ensure(sizeof(uint32_t) * nlist));
+    order.resize(2 * (size_t)nlist);  // second half: the inverse permutation (k_plan_sparse)
+    for (uint32_t at = 0; at < nlist; ++at) order[nlist + order[at]] = at;
+    ST_TRY(ix->order.ensure(sizeof(uint32_t) * 2 * nlist));
     ST_TRY(ix->xcd_first.ensure(sizeof(uint32_t) * 9));
     ST_TRY(ix->p_cnt.ensure(sizeof(uint32_t) * 2 * nlist));  // two item classes per partition (PlanArgs::best_first)
     ST_TRY(ix->p_off.ensure(sizeof(uint32_t) * 2 * nlist));
     ST_TRY(ix->p_fill.ensure(sizeof(uint32_t) * 2 * nlist));
     ST_TRY(ix->q_start.ensure(sizeof(uint32_t) * 16));
     ST_TRY(ix->heads.ensure(sizeof(uint32_t) * 8 * SK_HEAD_STRIDE));
-    HIP_TRY(hipMemcpyAsync(ix->order.p, order.data(), sizeof(uint32_t) * nlist, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ix->order.p, order.data(), sizeof(uint32_t) * 2 * nlist, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ix->xcd_first.p, xcd_first.data(), sizeof(uint32_t) * 9, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(ix->p_cnt.p, 0, sizeof(uint32_t) * 2 * nlist, st));
     HIP_TRY(hipStreamSynchronize(st));  // host vectors above go out of scope
@@ -854,6 +856,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       pa.nlist = ix->nlist;
       pa.plen = view.plen;
       pa.order = ix->order.as<uint32_t>();
+      pa.opos = ix->order.as<uint32_t>() + ix->nlist;
       pa.xcd_first = ix->xcd_first.as<uint32_t>();
       pa.cnt = ix->p_cnt.as<uint32_t>();
       pa.off = ix->p_off.as<uint32_t>();
@@ -876,7 +879,9 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       pa.act = act;
       const uint32_t pb = (pa.n_pairs + 255) / 256;
       // (qthr, the queries' running distance bounds, was reset by k_select_probes / k_take_probes)
-      if (pa.n_pairs <= PLAN_FUSED_MAX_PAIRS && dev_knob("MI355_PLAN_FUSED", 1)) {
+      if (pa.n_pairs <= PLAN_SPARSE_MAX_PAIRS && dev_knob("MI355_PLAN_SPARSE", 1)) {
+        hipLaunchKernelGGL(k_plan_sparse, dim3(1), dim3(PLAN_SPARSE_MAX_PAIRS), 0, st, pa);
+      } else if (pa.n_pairs <= PLAN_FUSED_MAX_PAIRS && dev_knob("MI355_PLAN_FUSED", 1)) {
         hipLaunchKernelGGL(k_plan_fused, dim3(1), dim3(1024), 0, st, pa);
       } else {
         hipLaunchKernelGGL(k_plan_count, dim3(pb), dim3(256), 0, st, pa);

@@ -508,7 +508,7 @@ static __global__ __launch_bounds__(256) void k_select_probes(
     const uint32_t* __restrict__ plen, uint32_t* __restrict__ probes /*[nq, nprobe]*/,
     unsigned long long* __restrict__ stat_rows, ActiveMask act = ActiveMask(), uint32_t* __restrict__ qthr = nullptr) {
   __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_need, s_less, s_wave_cnt[4], s_running, s_best_at;
+  __shared__ uint32_t s_prefix, s_need, s_less, s_wave_cnt[4], s_running, s_best_at, s_eq_all;
   __shared__ unsigned long long s_rows, s_best;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t b = blockIdx.x;
@@ -524,6 +524,7 @@ static __global__ __launch_bounds__(256) void k_select_probes(
     s_rows = 0;
     s_best = ~0ull;
     s_best_at = 0;
+    s_eq_all = 0;
   }
   uint32_t mask = 0;
   for (int byte = 3; byte >= 0; --byte) {
@@ -555,6 +556,7 @@ static __global__ __launch_bounds__(256) void k_select_probes(
       if (inc >= need && inc - h < need) {  // exactly one thread
         s_need = need - (inc - h);
         s_prefix = prefix | ((uint32_t)tid << (8 * byte));
+        if (byte == 0) s_eq_all = (h == need - (inc - h)) ? 1u : 0u;  // every key equal to the threshold is taken
       }
     }
     mask |= 255u << (8 * byte);
@@ -564,7 +566,17 @@ static __global__ __launch_bounds__(256) void k_select_probes(
   const uint32_t need_eq = s_need;           // rows with key == T to take (>= 1)
   const uint32_t n_less = nprobe - need_eq;  // rows with key < T
   unsigned long long rows = 0;
-  for (uint32_t p0 = 0; p0 < nlist; p0 += 256) {
+  // no tie is cut at the threshold (the usual case): the list is every key <= T in any order, no ranks to agree on
+  const bool unordered = s_eq_all != 0u;
+  for (uint32_t p = tid; unordered && p < nlist; p += 256) {
+    const uint32_t key = f32_sort_key(src[p]);
+    if (key <= T) {
+      out[atomicAdd(&s_less, 1u)] = p;
+      rows += plen[p];
+      atomicMin(&s_best, ((unsigned long long)key << 32) | p);
+    }
+  }
+  for (uint32_t p0 = 0; !unordered && p0 < nlist; p0 += 256) {
     uint32_t p = p0 + tid;
     uint32_t key = p < nlist ? f32_sort_key(src[p]) : 0xFFFFFFFFu;
     bool less = p < nlist && key < T;

@@ -228,6 +228,7 @@ struct PlanArgs {
   uint32_t nlist;
   const uint32_t* plen;     // [nlist]
   const uint32_t* order;    // [nlist] static partition order
+  const uint32_t* opos;     // [nlist] its inverse: position of partition p in `order`
   const uint32_t* xcd_first;  // [9] index into order where queue x starts
   uint32_t* cnt;            // [2 * nlist] (zeroed by k_plan_scan for the next batch); second half: class "nearest"
   uint32_t* off;            // [2 * nlist]
@@ -363,6 +364,66 @@ static __global__ __launch_bounds__(1024) void k_plan_fused(PlanArgs a) {
   __threadfence();
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < a.n_pairs; i += 1024u) plan_fill_pair(a, i);
+}
+
+// A few queries (<= PLAN_SPARSE_MAX_PAIRS pairs): the same work list without walking the 2 * nlist counters — every
+// pair computes its place in the virtual sequence directly (queue of its partition, class, position in `order`), the
+// pairs are ranked by counting over (place, pair index), and the queue boundaries are counts of the places below them.
+// Items of one partition and class land in pair-index order (the counting planner leaves that order to its atomics;
+// placement affects speed only).  cnt / off / fill are not touched (cnt stays zeroed for the counting planner).
+#define PLAN_SPARSE_MAX_PAIRS 512u
+static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(PlanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ uint32_t s_xf[9], s_q[9];
+  const uint32_t i = threadIdx.x, lane = i & 63u;
+  const uint32_t ncls = a.best_first ? 2u : 1u;
+  if (i < 9) {
+    s_xf[i] = a.xcd_first[i];
+    s_q[i] = 0;
+  }
+  __syncthreads();
+  uint32_t key = 0xFFFFFFFFu, p = 0xFFFFFFFFu, len = 0;
+  if (i < a.n_pairs && a.act.on(i / a.nprobe)) {
+    for (uint32_t sl = 0; sl < a.n_slices; ++sl) a.cand_cnt[(size_t)i * a.n_slices + sl] = 0u;
+    p = a.probes[i];
+    len = p < a.nlist ? a.plen[p] : 0u;
+    if (len) {
+      const uint32_t at = a.opos[p];
+      uint32_t x = 0;
+      for (uint32_t y = 1; y < 8; ++y) x += (at >= s_xf[y]) ? 1u : 0u;  // queue of the partition (empty queues are skipped over)
+      const uint32_t qlen = s_xf[x + 1] - s_xf[x], idx = at - s_xf[x];
+      key = ncls * s_xf[x] + ((ncls == 2u && plan_class(a, i) == 0u) ? qlen : 0u) + idx;
+    }
+  }
+  s_key[i] = key;
+  // queue x starts behind the items whose place is below its first virtual index
+#pragma unroll
+  for (uint32_t x = 0; x < 9; ++x) {
+    const uint64_t m = __ballot(key != 0xFFFFFFFFu && key < ncls * s_xf[x]);
+    if (lane == 0 && m) atomicAdd(&s_q[x], (uint32_t)__popcll((unsigned long long)m));
+  }
+  __syncthreads();
+  if (key != 0xFFFFFFFFu) {
+    uint32_t rank = 0;
+    for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {  // (s_key beyond n_pairs holds 0xFFFFFFFF: never below a real key)
+      const uint4 kj = *(const uint4*)&s_key[j0];
+      const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rank += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? 1u : 0u;
+    }
+    SkewItem it;
+    it.part = p;
+    it.len = len;
+    it.lrow0 = a.lrow0[p];
+    it.grow0 = a.grow0[p];
+    it.code_off = a.code_off[p];
+    for (uint32_t sl = 0; sl < a.n_slices; ++sl) {
+      it.pair = a.n_slices > 1u ? (i | (sl << 24)) : i;
+      a.items[(size_t)rank * a.n_slices + sl] = it;
+    }
+  }
+  if (i < 9) a.q_start[i] = s_q[i] * a.n_slices;
+  if (i < 8) a.heads[i * SK_HEAD_STRIDE] = 0;
 }
 
 // ------------------------------------------------------------------- scan ----

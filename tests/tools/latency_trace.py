@@ -11,7 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import lancedb_amd  # noqa: E402
 from lancedb_amd import _abi  # noqa: E402
 
-n, dim, nlist, m = 25_000_000, 768, 1024, 96
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000  # 100000000 4096: the C3 shape
+nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+dim, m = 768, 96
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(1)
@@ -22,7 +24,10 @@ w = np.exp(rng.normal(0.0, 0.5, size=nlist))
 lens = rng.multinomial(n, w / w.sum())
 po = np.zeros(nlist + 1, np.uint64)
 po[1:] = np.cumsum(lens)
-codes = torch.randint(0, 256, (n * m,), generator=g, device=dev, dtype=torch.uint8)
+codes = torch.empty((n * m,), device=dev, dtype=torch.uint8)
+for c0 in range(0, n * m, 1 << 30):  # in pieces: one randint call over 9.6e9 elements (the C3 shape) left the GPU faulting
+    c1 = min(n * m, c0 + (1 << 30))
+    torch.randint(0, 256, (c1 - c0,), generator=g, device=dev, dtype=torch.uint8, out=codes[c0:c1])
 torch.cuda.synchronize()
 ix = lancedb_amd.IvfPqIndex(cen, cb, po, codes, None, codes_layout=_abi.CODES_PART_TRANSPOSED)
 del codes

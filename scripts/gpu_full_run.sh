@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 3, final: whole GPU suite + the default bench line end to end (wall time printed) + rocprofv3 kernel stats
-O=gpurun_out/r3fin2
+# On an MI355X box (gpurun -- 'bash scripts/gpu_full_run.sh [outdir]'): the whole GPU suite, the default bench line end to end
+# (wall time printed), rocprofv3 kernel statistics of the C3 and flat commands, smoke(), the single-query tool with the
+# planner A/B.  The summaries a round keeps are copied from the out directory into profiles/ by hand.
+O=${1:-gpurun_out/full_run}
 mkdir -p $O
 export PYTHONFAULTHANDLER=1
 S=$(date +%s)
@@ -20,8 +22,8 @@ find $O -name "*kernel_trace.csv" -size +20M -delete
 find $O -name "*_kernel_stats.csv"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 python - <<'PY'
-import json
-d = json.load(open("gpurun_out/r3fin2/bench_default.json"))
+import glob, json
+d = json.load(open(glob.glob("gpurun_out/*/bench_default.json")[-1]))
 print("C3", round(d["value"]), "ms", round(d["ms_per_step"], 3), "frac", round(d["roofline"]["frac"], 3))
 s = d["secondary"]
 print("latency", s["latency_c3"]["single_query_us_eager"], s["latency_c3"]["single_query_stage_us"], s["latency_c3"].get("qps_64_threads_coalesced"))

@@ -517,6 +517,31 @@ struct WaveList {
     cnt = keep;
   }
 
+  // Drop every entry above `thr` from a list in ANY order (the survivors keep their relative order).
+  __device__ __forceinline__ void filter(float thr, int lane) {
+    ListEnt mine[R];
+    bool k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t slot = (uint32_t)(r * MI355_WAVE + lane);
+      k[r] = slot < cnt;
+      mine[r].d = 0.f;
+      mine[r].pos = CAND_EMPTY_POS;
+      if (k[r]) mine[r] = list[slot];
+      k[r] = k[r] && mine[r].d <= thr;
+    }
+    __threadfence_block();  // every entry is in registers before any slot is rewritten
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t m = __ballot(k[r]);
+      if (k[r]) list[base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)))] = mine[r];
+      base += (uint32_t)__popcll((unsigned long long)m);
+    }
+    cnt = base;
+    __threadfence_block();
+  }
+
   // Every lane offers at most one row.  `thr` is the caller's current
   // admission threshold (updated when a compaction tightens it).
   template <typename IdOf>

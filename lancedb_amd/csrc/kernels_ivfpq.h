@@ -1087,7 +1087,8 @@ __device__ __forceinline__ uint32_t block_kth_smallest_key(Get get, uint32_t n, 
 // once, without a query bound, and every one returns its own kk best: 5120 .. 128 000 filled slots for ONE wave, whose
 // selector pays ~1 us per row it admits).  The block of NW waves selects by keys instead (f32 sort key of the distance):
 //   1. bound: when the query has more than MERGE_SHORT_CAP filled slots, the k_out-th smallest key of a sample of
-//      64 * NW of them (the first rows of every source: the lists are sorted) — at least k_out slots lie at or below it;
+//      64 * NW of them — at least k_out slots lie at or below it (two samples, the tighter bound wins: the first rows of
+//      every source, and every (filled / 1024)-th filled slot);
 //   2. sweep: all slots, independent loads; the ones at or below the bound go to a short list in LDS (distance, slot);
 //   3. the exact k_out-th smallest key of the short list (radix select in LDS) cuts it to the final list: k_out rows
 //      plus the ties of the last one;
@@ -1145,6 +1146,7 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
   };
   __shared__ uint32_t s_pre[MERGE_PRE_SRC + 1];
   if constexpr (NW > 1) {
+    __shared__ uint32_t s_pfx[MERGE_PRE_SRC + 1], s_wt[NW];
     constexpr uint32_t NT = MI355_WAVE * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char merge_lds[];
     float* sl_d = (float*)merge_lds;                      // [MERGE_SHORT_CAP] (the sample's keys before the sweep)
@@ -1172,13 +1174,48 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
       };
       uint32_t tau = 0xFFFFFFFFu;
       if (n_filled > MERGE_SHORT_CAP) {
-        const uint32_t sidx = (uint32_t)tid % a.n_src, r = (uint32_t)tid / a.n_src;
-        uint32_t key = 0xFFFFFFFFu;
-        if (r < s_pre[sidx]) key = key_of(src[(size_t)sidx * a.src_stride + r]);
+        // Two samples of NT distinct filled slots, the smaller k_out-th key wins.  (A) the first rows of every source:
+        // tight when the sources are long sorted lists whose heads hold the winners — but short of k_out keys when
+        // most work items returned nothing (a bound shared early); (B) every (n_filled / NT)-th filled slot: its
+        // k_out-th key sits near rank k_out * n_filled / NT of all slots — enough exactly when the lists are short.
         uint32_t* s_keys = (uint32_t*)sl_d;
-        s_keys[tid] = key;
+        {
+          const uint32_t sidx = (uint32_t)tid % a.n_src, r = (uint32_t)tid / a.n_src;
+          uint32_t key = 0xFFFFFFFFu;
+          if (r < s_pre[sidx]) key = key_of(src[(size_t)sidx * a.src_stride + r]);
+          s_keys[tid] = key;
+        }
+        // exclusive prefix of the counts (n_src <= NT: one source per thread)
+        {
+          const uint32_t c = (uint32_t)tid < a.n_src ? s_pre[tid] : 0u;
+          uint32_t inc = c;
+#pragma unroll
+          for (int off = 1; off < MI355_WAVE; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+          }
+          if (lane == MI355_WAVE - 1) s_wt[wid] = inc;
+          __syncthreads();
+          uint32_t base = 0;
+          for (int w = 0; w < wid; ++w) base += s_wt[w];
+          if ((uint32_t)tid < a.n_src) s_pfx[tid] = base + inc - c;
+          if (tid == 0) s_pfx[a.n_src] = n_filled;
+        }
         __syncthreads();
-        tau = block_kth_smallest_key<NT>([&](uint32_t i) { return s_keys[i]; }, NT, a.k_out, hist, st);
+        const uint32_t tau_a = block_kth_smallest_key<NT>([&](uint32_t i) { return s_keys[i]; }, NT, a.k_out, hist, st);
+        __syncthreads();
+        {
+          const uint32_t f = (uint32_t)(((uint64_t)tid * n_filled) / NT);  // distinct: n_filled > NT
+          uint32_t lo = 0, hi = a.n_src;  // the last source whose prefix is <= f holds filled slot f
+          while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pfx[mid] <= f) lo = mid; else hi = mid;
+          }
+          s_keys[tid] = key_of(src[(size_t)lo * a.src_stride + (f - s_pfx[lo])]);
+        }
+        __syncthreads();
+        const uint32_t tau_b = block_kth_smallest_key<NT>([&](uint32_t i) { return s_keys[i]; }, NT, a.k_out, hist, st);
+        tau = min(tau_a, tau_b);
         __syncthreads();  // the keys are dead: the sweep reuses their space
       }
       constexpr int G = 4;

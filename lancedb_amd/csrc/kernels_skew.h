@@ -736,6 +736,8 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     }
     SK_DEV(const unsigned long long dv_p0 = wall_clock64();)
     WaveList<LR, QSHARE> wl;
+    const bool whole_kk = pass_base + kk_pass >= a.kk;  // this pass completes the item's kk rows
+    uint32_t pub_g = 0xFFFFFFFFu;                        // the tightest bound this lane sent to the query's global word
     const uint32_t q_share = (kk_pass + NW - 1) / NW;
     wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass, q_share);
     float pub_q = __builtin_huge_valf();
@@ -798,7 +800,16 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
 #pragma unroll
             for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
             v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-            if (v != 0xFFFFFFFFu && lane == 0) atomicMin(s_thr, v);
+            if (v != 0xFFFFFFFFu && lane == 0) {
+              atomicMin(s_thr, v);
+              // kk rows of the QUERY lie at or below it when this pass completes the item's kk (pass_base rows below
+              // the floor + NW * q >= kk_pass above it): the other work items of the query — all running at the same
+              // time when a single query is cut into slices — pick it up before they merge
+              if (whole_kk && v < pub_g) {
+                pub_g = v;
+                atomicMin(a.qthr + b, v);
+              }
+            }
           }
         }
       }
@@ -939,6 +950,11 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       s_rec[slot ^ 1u] = nxt;
     };
     if (last_known && !tail_popped && tid == 0 && (!nxt_valid || !rec_stored)) next_item_fallback();
+    // what the query's other work items learnt meanwhile (a bound on its kk-th best distance: valid for any pass)
+    if (tid == 0) {
+      const uint32_t g = __hip_atomic_load(a.qthr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g != 0xFFFFFFFFu) atomicMin(s_thr, g);
+    }
     __syncthreads();
     SK_DEV(const unsigned long long dv_p1 = wall_clock64(); dv_scan += dv_p1 - dv_p0;  // every wave is done
            )
@@ -965,6 +981,17 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     if (last_known) {
       if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
       tail_done = true;
+    }
+    {
+      // The lists were filled under the bounds known when their rows arrived; the bound the workgroup holds now — its
+      // own or one of the query's other work items' — cuts them before they are ranked.  (A single query's 512 slices
+      // run at the same time without any bound: each would rank, and hand the final merge, its own kk best rows.)
+      const uint32_t tk0 = *s_thr;  // workgroup-uniform: nothing writes it between the barrier above and this read
+      if (tk0 != 0xFFFFFFFFu) {
+        wl.filter(f32_from_sort_key(tk0), lane);
+        if (lane == 0) s_cnt[wid] = wl.cnt;
+        __syncthreads();
+      }
     }
     // Exact (distance, rowid) ranks of the lists' rows, one row per WAVE at a time, the 64 lanes
     // comparing it with 64 rows of the concatenated lists per step: every step is an independent
@@ -995,7 +1022,10 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
             uint32_t v = lane < NW ? s_part[lane] : 0u;
 #pragma unroll
             for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
-            if (lane == 0 && v != 0xFFFFFFFFu) atomicMin(s_thr, v);
+            if (lane == 0 && v != 0xFFFFFFFFu) {
+              atomicMin(s_thr, v);
+              if (whole_kk) atomicMin(a.qthr + b, v);
+            }
           }
           __syncthreads();
         }

@@ -1289,7 +1289,10 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
               for (int e = 0; e < 4; ++e) {
                 if (j0 + e >= n_fin) break;
                 bool lt = dv[e] < d;
-                if (dv[e] == d) lt = f_id[j0 + e] < id;  // a tie on the distance: the row ids decide (ids are unique)
+                if (dv[e] == d) {  // a tie on the distance: the row ids decide; the same row twice: its place in the list
+                  const uint64_t idj = f_id[j0 + e];
+                  lt = idj < id || (idj == id && j0 + e < i);
+                }
                 rank += lt ? 1u : 0u;
               }
             }

@@ -249,6 +249,46 @@ class VectorQuery:
 
     to_arrays = execute
 
+    # ---- the Python binding's collected forms (python/python/lancedb/query.py:986-1117, :1771-1790) ----------
+    def to_batches(self, batch_size=None, *, timeout=None):
+        """-> pyarrow.RecordBatchReader over the stream (query.py:1077-1101, :1824): at most `batch_size` rows per
+        batch (None = the execution options' default, 1024), `timeout` a timedelta or seconds."""
+        import pyarrow as pa
+        opts = QueryExecutionOptions()
+        if batch_size is not None:
+            if int(batch_size) <= 0:
+                raise InvalidInput(1, "batch_size must be positive")
+            opts.max_batch_length = int(batch_size)
+        if timeout is not None:
+            opts.timeout = timeout.total_seconds() if hasattr(timeout, "total_seconds") else float(timeout)
+        types = {"_rowid": pa.uint64(), "_distance": pa.float32(), "query_index": pa.int32()}
+        names = self.create_plan(opts).output_columns()
+        schema = pa.schema([(n, types[n]) for n in names])
+        stream = self.execute_with_options(opts)
+
+        def gen():
+            for b in stream:
+                yield pa.record_batch([pa.array(b[n], type=types[n]) for n in names], schema=schema)
+
+        return pa.RecordBatchReader.from_batches(schema, gen())
+
+    def to_arrow(self, *, timeout=None):
+        """-> pyarrow.Table (query.py:1771-1790: `to_batches(timeout=...).read_all()`)."""
+        return self.to_batches(timeout=timeout).read_all()
+
+    def to_list(self, *, timeout=None):
+        """-> list of row dicts (query.py:1103-1117)."""
+        return self.to_arrow(timeout=timeout).to_pylist()
+
+    def to_pandas(self, *, timeout=None):
+        """-> pandas.DataFrame (query.py:997-1057; the flatten / blob options act on user columns, which this path
+        does not produce)."""
+        return self.to_arrow(timeout=timeout).to_pandas()
+
+    def to_df(self):
+        """Deprecated spelling of to_pandas (query.py:986-995)."""
+        return self.to_pandas()
+
 
 class VectorTable:
     """The slice of `BaseTable` this path needs (table.rs:549-576): holds the

@@ -267,3 +267,36 @@ def test_reference_python_query_tests_on_the_mirror():
     q2 = t.vector_search([0, 0, 0, 0]).limit(2)
     assert [len(b["_rowid"]) for b in q2.execute_with_options(QueryExecutionOptions(max_batch_length=1))] == [1, 1]
     assert [len(b["_rowid"]) for b in q2.execute_with_options(QueryExecutionOptions(max_batch_length=2))] == [2]
+
+
+def test_collected_forms_of_the_python_binding():
+    """to_batches / to_arrow / to_list / to_pandas (python/python/lancedb/query.py:986-1117, :1771-1790; the
+    schema test python/python/tests/test_query.py:1798-1800: `_distance` is float32)."""
+    import datetime
+    import pyarrow as pa
+    t = VectorTable(index=_ArrayIndex(5000))
+    q = t.vector_search([0, 0, 0, 0]).limit(2500)
+    rd = q.to_batches()
+    assert isinstance(rd, pa.RecordBatchReader)
+    assert rd.schema == pa.schema([("_rowid", pa.uint64()), ("_distance", pa.float32())])
+    assert [b.num_rows for b in rd] == [1024, 1024, 452]
+    assert [b.num_rows for b in q.to_batches(1000)] == [1000, 1000, 500]
+    with pytest.raises(lancedb_amd.InvalidInput, match="batch_size"):
+        q.to_batches(0)
+    tab = q.to_arrow()
+    assert tab.num_rows == 2500 and tab.column("_rowid").to_pylist()[:3] == [0, 1, 2]
+    assert tab.schema.field("_distance").type == pa.float32()
+    rows = t.vector_search([0, 0, 0, 0]).limit(3).to_list()
+    assert rows == [{"_rowid": 0, "_distance": 0.0}, {"_rowid": 1, "_distance": 1.0}, {"_rowid": 2, "_distance": 2.0}]
+    df = t.vector_search([0, 0, 0, 0]).limit(4).select(["_distance"]).to_pandas()
+    assert list(df.columns) == ["_distance"] and df["_distance"].tolist() == [0.0, 1.0, 2.0, 3.0]
+    assert t.vector_search([0, 0, 0, 0]).limit(4).to_df().shape == (4, 2)
+    # several query vectors add query_index (table/query.rs:334-381)
+    mq = t.vector_search([0, 0, 0, 0]).add_query_vector([1, 1, 1, 1]).limit(2).to_arrow()
+    assert mq.schema.names == ["_rowid", "_distance", "query_index"] and mq.column("query_index").to_pylist() == [0, 0, 1, 1]
+    assert mq.schema.field("query_index").type == pa.int32()
+    # the timeout (a timedelta in the binding) reaches the engine as its deadline
+    t.vector_search([0, 0, 0, 0]).limit(2).to_arrow(timeout=datetime.timedelta(seconds=1.5))
+    assert t.index.params.timeout_ms == 1500
+    with pytest.raises(lancedb_amd.QueryTimeout, match="Query timeout"):
+        t.vector_search([0, 0, 0, 0]).limit(2).to_list(timeout=datetime.timedelta(0))

@@ -249,6 +249,21 @@ class VectorQuery:
 
     to_arrays = execute
 
+    def metric(self, metric):
+        """Alias of distance_type (python/python/lancedb/query.py:1596-1612)."""
+        return self.distance_type(metric)
+
+    def to_query_object(self):
+        """The request this builder stands for, detached (python/python/lancedb/query.py:1790-1822: "can be used to
+        serialize a query" — `wire.request_to_json` is that serialisation)."""
+        return copy.deepcopy(self.request)
+
+    def output_schema(self):
+        """pyarrow schema of the result without running the query (python/python/lancedb/query.py:1763-1769)."""
+        import pyarrow as pa
+        types = {"_rowid": pa.uint64(), "_distance": pa.float32(), "query_index": pa.int32()}
+        return pa.schema([(n, types[n]) for n in self.create_plan().output_columns()])
+
     # ---- the Python binding's collected forms (python/python/lancedb/query.py:986-1117, :1771-1790) ----------
     def to_batches(self, batch_size=None, *, timeout=None):
         """-> pyarrow.RecordBatchReader over the stream (query.py:1077-1101, :1824): at most `batch_size` rows per

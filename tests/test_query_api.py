@@ -300,3 +300,22 @@ def test_collected_forms_of_the_python_binding():
     assert t.index.params.timeout_ms == 1500
     with pytest.raises(lancedb_amd.QueryTimeout, match="Query timeout"):
         t.vector_search([0, 0, 0, 0]).limit(2).to_list(timeout=datetime.timedelta(0))
+
+
+def test_builder_conveniences_of_the_python_binding():
+    """metric() alias, output_schema() without execution, to_query_object() (python/python/lancedb/query.py:1596-1612,
+    :1763-1769, :1790-1822)."""
+    import pyarrow as pa
+    t = VectorTable(index=_ArrayIndex(10))
+    q = t.vector_search([0, 0, 0, 0]).metric("cosine").limit(3)
+    assert q.request.distance_type == "cosine"
+    with pytest.raises(lancedb_amd.InvalidInput):
+        t.vector_search([0, 0, 0, 0]).metric("manhattan")
+    assert q.output_schema() == pa.schema([("_rowid", pa.uint64()), ("_distance", pa.float32())])
+    assert t.index.params is None  # nothing ran
+    assert q.select(["_distance"]).output_schema().names == ["_distance"]
+    obj = q.to_query_object()
+    assert obj is not q.request and obj.limit == 3 and obj.distance_type == "cosine"
+    assert np.array_equal(obj.query_vector[0], q.request.query_vector[0]) and obj.query_vector[0] is not q.request.query_vector[0]
+    obj.limit = 99
+    assert q.request.limit == 3

@@ -31,6 +31,6 @@ for k in ("c3_refine10", "c3_refine25", "c5_refine10", "flat_c2_l2", "flat_c2_co
     if k in s: print(k, round(s[k]["value"]), s[k].get("roofline", {}).get("frac"))
 print("loopback", {k: v for k, v in s.get("loopback_world8", {}).get("step_model", {}).items() if k != "note"})
 PY
-for kn in "" "MI355_PLAN_SPARSE=0"; do
-  echo "== knobs [$kn]"; env $kn MI355_ANN_LIB=$PWD/lancedb_amd/variants/lib_knobs.so timeout 120 python tests/tools/latency_trace.py 2>&1 | grep "single query"
-done
+timeout 120 python tests/tools/latency_trace.py 2>&1 | grep "single query"
+# planner A/B, if a knob build was shipped along (scripts/build_variants.sh knobs:-DMI355_DEV_KNOBS)
+[ -e lancedb_amd/variants/lib_knobs.so ] && bash scripts/ab_variants.sh tests/tools/latency_trace.py knobs knobs:MI355_PLAN_SPARSE=0 | grep "variant\|single query"

@@ -157,7 +157,8 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->cbT,       &ix->order,  &ix->xcd_first, &ix->p_cnt,  &ix->p_off,
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
-                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt};
+                    &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt,
+                    &ix->w_partial};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -196,7 +197,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   const uint32_t nlist = d->nlist, m = d->m, mb = ix->mb, cb_entries = 1u << d->nbits;
   for (DevBuf* b : {&ix->w_q, &ix->w_qp, &ix->w_qq, &ix->w_coarse, &ix->w_probes, &ix->w_cand, &ix->w_ids, &ix->w_dist,
                     &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr, &ix->w_ccnt,
-                    &ix->w_filter, &ix->w_probes64, &ix->w_spill})
+                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial})
     b->gen = &ix->ws_gen;  // a re-allocation of any of these invalidates the cached hipGraphs
 
   // -- ownership + local layout
@@ -211,11 +212,21 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   uint32_t owned = 0, max_len = 0;
   {
     const bool force_pair = (d->flags & MI355_INDEX_GENERIC_SCAN) != 0;
-    // the skewed layout needs the 256 x P-dword table + residual + lists in 160 KiB of LDS
-    const size_t lds_skew = (size_t)SK_TABLE_BYTES + (size_t)d->dim * 4 + 25 * 1024;
-    ix->layout = (!force_pair && d->nbits == 8 && sk_supported_m(m) && d->dim <= 2048 && lds_skew <= 160u * 1024)
-                     ? MI355_SCAN_SKEW
-                     : MI355_SCAN_PAIR;
+    // The production scan takes every 8-bit m (SkewShape: padded to a kernel width, or cut into slabs of <= 96
+    // columns) whose work item fits the LDS: the 256 x 128-dword table + one slab's residual (the whole row's when
+    // there is one slab) + the candidate lists of eight waves; a thread stages at most four residual elements.
+    SkewShape shp{};
+    ix->layout = MI355_SCAN_PAIR;
+    if (!force_pair && d->nbits == 8 && sk_shape(m, &shp)) {
+      const uint32_t res_floats = shp.n_slabs > 1 ? shp.M * ix->dsub : d->dim;
+      if (res_floats <= 2048 && sk_scan_lds(res_floats, 8, 5) <= 160u * 1024) {
+        ix->layout = MI355_SCAN_SKEW;
+        ix->sk_M = shp.M;
+        ix->sk_slabs = shp.n_slabs;
+        ix->sk_slabbed = shp.slabbed;
+        ix->sk_res_floats = res_floats;
+      }
+    }
   }
   const bool skew = ix->layout == MI355_SCAN_SKEW;
   const bool local_arrays = (d->flags & MI355_INDEX_LOCAL_ARRAYS) != 0;
@@ -228,7 +239,8 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     grow0[p] = d->part_offsets[p];
     code_off[p] = bytes;
     rows += plen[p];
-    bytes += skew ? sk_part_chunks((plen[p] + SK_TILE - 1) / SK_TILE, m / 16) * 1024u : (uint64_t)mb * pstride[p];
+    bytes += skew ? (uint64_t)ix->sk_slabs * sk_part_chunks((plen[p] + SK_TILE - 1) / SK_TILE, ix->sk_M / 16) * 1024u
+                  : (uint64_t)mb * pstride[p];
     if (plen[p]) {
       ++owned;
       max_len = std::max(max_len, plen[p]);
@@ -292,7 +304,8 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
       sp.dst = ra.dst;
       sp.code_off = ra.code_off;
       sp.plen = ra.plen;
-      sp.m = m;
+      sp.m = ix->sk_M;
+      sp.m_src = m;
       sp.transposed = ra.transposed;
       // grid.y is limited to 65535: split very wide batches
       for (size_t y0 = 0; y0 < pids.size(); y0 += 32768) {
@@ -301,8 +314,8 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
           SkewPackArgs sb = sp;
           sb.src_off += y0;
           sb.part_ids += y0;
-          hipLaunchKernelGGL(k_pack_skew, dim3(sk_pack_slots(batch_max_stride), ny), dim3(256),
-                             2 * 64 * (m + 1), st, sb);
+          hipLaunchKernelGGL(k_pack_skew, dim3(sk_pack_slots(batch_max_stride), ny, ix->sk_slabs), dim3(256),
+                             2 * 64 * (ix->sk_M + 1), st, sb);
         } else {
           RepackArgs rb = ra;
           rb.src_off += y0;
@@ -713,7 +726,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   uint32_t nt = dev_knob("MI355_SCAN_THREADS", 0), vpt = dev_knob("MI355_SCAN_VPT", 0);
   if (!nt) nt = pl.kk > 64 ? 256 : ix->max_len >= 8192 ? 1024 : ix->max_len >= 2048 ? 512 : 256;
   // an 8-bit distance table larger than the LDS keeps its tail in global memory (long lists, 256 threads)
-  const uint32_t m_lds = skew ? ix->m : scan_pair_m_lds(ix->m, ix->nbits, ix->dim);
+  const uint32_t m_lds = skew ? ix->m : scan_pair_m_lds(ix->m, ix->nbits, ix->dim);  // (the production scan never spills: it walks slabs)
   if (m_lds < ix->m) nt = 256;
   if (!vpt) vpt = ix->max_len >= 4 * nt * 4 ? 16 : 4;
   // Generic kernel: one work item per (query, partition) whenever the batch
@@ -910,8 +923,23 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       // a handle whose re-rank runs beside its scans (deferred refine over a host column) keeps a few CUs free for it:
       // a scan workgroup takes a whole CU (128 VGPRs x 16 waves), so nothing can share one with it
       const uint32_t scan_cus = (pl.defer_refine && ix->n_cus > 4 * MI355_REFINE_SIDE_CUS) ? ix->n_cus - MI355_REFINE_SIDE_CUS : ix->n_cus;
-      const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(scan_cus, (uint64_t)n * nprobe * n_slices);
-      ST_TRY(launch_scan_skew(ka, ix->m, std::max(n_blocks, 1u), ix->dim, pl.kk, st));
+      uint32_t n_blocks = std::max(1u, (uint32_t)std::min<uint64_t>(scan_cus, (uint64_t)n * nprobe * n_slices));
+      ka.n_slabs = ix->sk_slabs;
+      ka.res_floats = ix->sk_res_floats;
+      ka.partial = nullptr;
+      ka.partial_stride = 0;
+      if (ix->sk_slabs > 1) {
+        // partial row sums between the slabs of a work item: 8 B per (tile position, unit, lane) of the longest partition,
+        // per workgroup (persistent: one work item at a time)
+        const uint64_t n_tiles = ((uint64_t)ix->max_len + SK_TILE - 1) / SK_TILE;
+        const uint64_t stride = ((n_tiles + SK_STREAMS - 1) / SK_STREAMS + 1) * SK_UNITS * MI355_WAVE;
+        if (stride >= (1ull << 31)) return fail(MI355_ERR_NOT_SUPPORTED, "a partition of %u rows is too long for the multi-slab scan", ix->max_len);
+        while (n_blocks > 8 && stride * 8 * n_blocks > (2ull << 30)) n_blocks /= 2;  // (very long partitions: fewer workgroups)
+        ST_TRY(ix->w_partial.ensure((size_t)stride * 8 * n_blocks));
+        ka.partial = ix->w_partial.as<float2>();
+        ka.partial_stride = (uint32_t)stride;
+      }
+      ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, pl.kk, st));
     } else {
       ScanArgs sa;
       sa.ix = view;

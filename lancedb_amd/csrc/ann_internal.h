@@ -193,6 +193,9 @@ struct mi355_index {
   bool merge_block_tried = false, merge_block_ok = false;  // k_merge_cands<KPL, 16> may use MERGE_BLOCK_LDS bytes
   uint32_t wall_khz = 100000;  // rate of the constant device clock behind timeout_ms (wall_clock64)
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
+  // SkewShape of the packed codes (MI355_SCAN_SKEW): columns per slab, slabs per row, generalised kernel or not
+  uint32_t sk_M = 0, sk_slabs = 1, sk_slabbed = 0, sk_res_floats = 0;
+  DevBuf w_partial;  // per-workgroup partial row sums between the slabs of a work item (sk_slabs > 1)
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2, w_dist2, w_cnt2, w_ctl,
       w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann, w_spill, w_srows, w_ccnt;
@@ -280,7 +283,7 @@ struct SkewArgs;
 int32_t launch_scan_pair(const ScanArgs& sa, dim3 grid, hipStream_t st, uint32_t vpt, uint32_t nt);
 size_t scan_pair_lds(uint32_t m, uint32_t nbits, uint32_t dim, uint32_t lr, uint32_t nt);
 uint32_t scan_pair_m_lds(uint32_t m, uint32_t nbits, uint32_t dim);
-int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint32_t dim, uint32_t kk, hipStream_t st);
+int32_t launch_scan_skew(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint32_t n_blocks, uint32_t kk, hipStream_t st);
 
 struct IndexView;
 int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,

@@ -1,51 +1,19 @@
 // ann_scan_skew.hip — launcher of the production ADC scan kernel (k_scan_skew: pre-skewed code
 // streams, conflict-free [code][column] table, persistent workgroups on per-XCD queues).
 // Its own translation unit so that the kernel families compile in parallel.
-#include "ann_internal.h"
-#include "kernels_ivfpq.h"
-#include "kernels_skew.h"
+#include "ann_scan_skew_impl.h"
 
-template <int M>
-static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_t dim, uint32_t kk,
-                                  hipStream_t st) {
-  auto lds_of = [&](int nw, int lr) {
-    return (size_t)SK_TABLE_BYTES + (((size_t)dim * 4 + 15) & ~(size_t)15) +
-           (size_t)nw * lr * 64 * 8 + (size_t)(2 * nw + 11) * 4 + 128;
-  };
-#define LAUNCH_SK(LR, NT, MULTI, OPT)                                                           \
-  {                                                                                             \
-    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT>;                                             \
-    const size_t lds = lds_of(NT / 64, LR);                                                     \
-    if (lds > 160u * 1024)                                                                      \
-      return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds));                                                     \
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(NT), lds, st, sa);                            \
+int32_t launch_scan_skew_slab(const SkewArgs& sa, uint32_t M, uint32_t n_blocks, uint32_t kk, hipStream_t st);
+
+// M = columns per slab (SkewShape::M); slabbed: the padded / multi-slab kernel family (ann_scan_skew_slab.hip)
+int32_t launch_scan_skew(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint32_t n_blocks, uint32_t kk, hipStream_t st) {
+  if (slabbed) return launch_scan_skew_slab(sa, M, n_blocks, kk, st);
+  switch (M) {
+    case 32: return launch_scan_skew_m<32, false>(sa, n_blocks, kk, st);
+    case 48: return launch_scan_skew_m<48, false>(sa, n_blocks, kk, st);
+    case 64: return launch_scan_skew_m<64, false>(sa, n_blocks, kk, st);
+    case 80: return launch_scan_skew_m<80, false>(sa, n_blocks, kk, st);
+    case 96: return launch_scan_skew_m<96, false>(sa, n_blocks, kk, st);
   }
-  // kk <= 128: sixteen waves with lists of 128 / 192 rows; beyond: sixteen waves with 192-row
-  // lists and optimistic passes of SCAN_PASS_ROWS rows (k_scan_skew OPT) when that fits the LDS,
-  // else eight waves with 320-row lists
-  const bool opt_fits = lds_of(16, 3) <= 160u * 1024;
-  if (kk <= 64) LAUNCH_SK(2, 1024, false, false)
-  else if (kk <= 128 && opt_fits) LAUNCH_SK(3, 1024, false, false)
-  else if (kk <= 128) LAUNCH_SK(3, 512, false, false)  // dim close to 2048: the lists of 16 waves do not fit
-  else if (opt_fits) LAUNCH_SK(3, 1024, true, true)
-  else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
-  else LAUNCH_SK(5, 512, true, false)
-#undef LAUNCH_SK
-  HIP_TRY(hipGetLastError());
-  return MI355_OK;
+  return fail(MI355_ERR_NOT_SUPPORTED, "no skewed scan kernel for a table of %u columns", M);
 }
-
-int32_t launch_scan_skew(const SkewArgs& sa, uint32_t m, uint32_t n_blocks, uint32_t dim,
-                                uint32_t kk, hipStream_t st) {
-  switch (m) {
-    case 32: return launch_scan_skew_m<32>(sa, n_blocks, dim, kk, st);
-    case 48: return launch_scan_skew_m<48>(sa, n_blocks, dim, kk, st);
-    case 64: return launch_scan_skew_m<64>(sa, n_blocks, dim, kk, st);
-    case 80: return launch_scan_skew_m<80>(sa, n_blocks, dim, kk, st);
-    case 96: return launch_scan_skew_m<96>(sa, n_blocks, dim, kk, st);
-  }
-  return fail(MI355_ERR_NOT_SUPPORTED, "no skewed scan kernel for m = %u", m);
-}
-

@@ -1,0 +1,35 @@
+// ann_scan_skew_impl.h — launcher template shared by the two translation units that instantiate k_scan_skew
+// (ann_scan_skew.hip: the plain widths; ann_scan_skew_slab.hip: the padded / multi-slab form), so that the two
+// kernel families compile in parallel.
+#pragma once
+#include "ann_internal.h"
+#include "kernels_ivfpq.h"
+#include "kernels_skew.h"
+
+template <int M, bool SLABBED>
+static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_t kk, hipStream_t st) {
+  auto lds_of = [&](int nw, int lr) { return sk_scan_lds(sa.res_floats, nw, lr); };
+#define LAUNCH_SK(LR, NT, MULTI, OPT)                                                           \
+  {                                                                                             \
+    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT, SLABBED>;                                    \
+    const size_t lds = lds_of(NT / 64, LR);                                                     \
+    if (lds > 160u * 1024)                                                                      \
+      return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                (int)lds));                                                     \
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(NT), lds, st, sa);                            \
+  }
+  // kk <= 128: sixteen waves with lists of 128 / 192 rows; beyond: sixteen waves with 192-row
+  // lists and optimistic passes of SCAN_PASS_ROWS rows (k_scan_skew OPT) when that fits the LDS,
+  // else eight waves with 320-row lists
+  const bool opt_fits = lds_of(16, 3) <= 160u * 1024;
+  if (kk <= 64) LAUNCH_SK(2, 1024, false, false)
+  else if (kk <= 128 && opt_fits) LAUNCH_SK(3, 1024, false, false)
+  else if (kk <= 128) LAUNCH_SK(3, 512, false, false)  // a long residual: the lists of 16 waves do not fit
+  else if (opt_fits) LAUNCH_SK(3, 1024, true, true)
+  else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
+  else LAUNCH_SK(5, 512, true, false)
+#undef LAUNCH_SK
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}

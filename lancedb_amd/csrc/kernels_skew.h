@@ -118,8 +118,37 @@ __host__ __device__ __forceinline__ uint32_t sk_pack_slots(uint32_t max_rows) {
 #else
 #define SK_TABLE_BYTES 131072u
 #endif
-__host__ __device__ __forceinline__ bool sk_supported_m(uint32_t m) {
+// Table widths the kernel is instantiated for (LUT columns per slab): the table holds M + 32 <= 128 columns.
+__host__ __device__ __forceinline__ bool sk_kernel_m(uint32_t m) {
   return m == 32 || m == 48 || m == 64 || m == 80 || m == 96;
+}
+// Every 8-bit m the reference's builder produces (index/vector.rs:306-319: dim / 16, dim / 8 or 1) runs this kernel:
+//  * m <= 96 that is not a kernel width is PADDED to the next one with code 0 and an all-zero table column — the
+//    row sum stays the contract's j-ascending chain followed by `+ 0.0f` terms, which are exact;
+//  * m > 96 is cut into n_slabs slabs of M columns (the last one padded): a work item builds slab s's table, scans
+//    slab s's code streams starting every row's accumulator from the row's partial sum of slabs 0..s-1 (parked in a
+//    per-workgroup scratch, 4 B per row against M code bytes) and selects in the last slab — still j-ascending.
+struct SkewShape {
+  uint32_t M;        // columns per slab = template width of k_scan_skew
+  uint32_t n_slabs;  // slabs per row
+  uint32_t slabbed;  // 1: the generalised kernel (padding and / or several slabs); 0: m == M, one slab
+};
+#define SK_MAX_SLABS 8u
+__host__ __device__ __forceinline__ bool sk_shape(uint32_t m, SkewShape* out) {
+  if (m == 0 || m > 96u * SK_MAX_SLABS) return false;
+  const uint32_t n_slabs = (m + 95u) / 96u;
+  const uint32_t per = (m + n_slabs - 1) / n_slabs;
+  uint32_t M = (per + 15u) & ~15u;
+  if (M < 32u) M = 32u;  // a tile is at least the 32 skew steps
+  out->M = M;
+  out->n_slabs = n_slabs;
+  out->slabbed = (n_slabs > 1u || M != m) ? 1u : 0u;
+  return true;
+}
+// dynamic LDS of a scan workgroup: table + residual (res_floats f32) + nw lists of lr * 64 entries + small words
+__host__ __device__ __forceinline__ size_t sk_scan_lds(uint32_t res_floats, int nw, int lr) {
+  return (size_t)SK_TABLE_BYTES + (((size_t)res_floats * 4 + 15) & ~(size_t)15) + (size_t)nw * lr * 64 * 8 +
+         (size_t)(2 * nw + 11) * 4 + 128;
 }
 // LUT pitch in dwords: >= m + 32 columns and a power of two, so that the address
 // is (code << 9) | column bytes (three 2-cycle VOP2 ops, scripts/gen_skew_chunks.py)
@@ -139,10 +168,13 @@ struct SkewPackArgs {
   uint8_t* dst;
   const uint64_t* code_off;   // [nlist] byte offset of the partition block in dst
   const uint32_t* plen;
-  uint32_t m;
-  uint32_t transposed;        // source layout: 1 = [m][len] per partition, 0 = [len][m]
+  uint32_t m;                 // columns per slab (SkewShape::M): the packed row width
+  uint32_t m_src;             // code bytes per source row (the index's m); slab z packs columns z*m .. of it, zero-padded
+  uint32_t transposed;        // source layout: 1 = [m_src][len] per partition, 0 = [len][m_src]
 };
 
+// grid = (slots, partitions of the batch, slabs); a partition block holds its slabs one after the other, each laid
+// out as a partition of m-byte rows
 static __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];  // [2][64][m+1]
   const uint32_t p = a.part_ids[blockIdx.y];
@@ -155,6 +187,7 @@ static __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
   const uint32_t nt_w = sk_unit_tiles(n_tiles, w);
   if (nt_w == 0 || n > nt_w) return;
   const uint32_t m = a.m, pitch = m + 1, cpt = m / 16;
+  const uint32_t j0 = blockIdx.z * m;  // first source column of this slab
   const bool tail = n == nt_w;
   const uint8_t* src = a.src + a.src_off[blockIdx.y];
   // stage tile position n (slot 0) and n-1 (slot 1) of this chain's stream; positions past
@@ -175,13 +208,15 @@ static __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
         j = e % m;
       }
       uint32_t v = 0;
-      if (r0 + i < len) v = a.transposed ? src[(size_t)j * len + r0 + i] : src[(size_t)(r0 + i) * m + j];
+      if (r0 + i < len && j0 + j < a.m_src)
+        v = a.transposed ? src[(size_t)(j0 + j) * len + r0 + i] : src[(size_t)(r0 + i) * a.m_src + j0 + j];
       t[i * pitch + j] = (unsigned char)v;
     }
   }
   __syncthreads();
   const uint32_t n_chunks = tail ? SK_TAIL_CHUNKS : cpt;
-  uint8_t* dst = a.dst + a.code_off[p] + (size_t)sk_unit_chunk0(n_tiles, w, cpt) * 1024u;
+  uint8_t* dst = a.dst + a.code_off[p] + (size_t)blockIdx.z * sk_part_chunks(n_tiles, cpt) * 1024u +
+                 (size_t)sk_unit_chunk0(n_tiles, w, cpt) * 1024u;
   for (uint32_t e = threadIdx.x; e < n_chunks * 64u; e += 256) {
     const uint32_t cc = e / 64u, l = e % 64u, lm = sk_phase(l);
     uint32_t wds[4];
@@ -448,6 +483,11 @@ struct SkewArgs {
   uint32_t n_slices;
   uint32_t dbg;
   DevCtl* ctl;              // deadline / counters of the call
+  // SLABBED kernels (SkewShape): ix.m columns per row are scanned as n_slabs slabs of M columns (the template width)
+  uint32_t n_slabs;
+  uint32_t res_floats;      // LDS floats of the residual: dim, or one slab's M * dsub (SLABBED)
+  float2* partial;          // [grid][partial_stride]: per-workgroup partial row sums between slabs (n_slabs > 1)
+  uint32_t partial_stride;  // float2 elements per workgroup: (tile positions of the longest unit) * 16 units * 64 lanes
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -505,7 +545,12 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
 #else
 #define SK_DEV(...)
 #endif
-template <int M, int LR, int NT, bool MULTI, bool OPT = false>
+// SLABBED: the generalised form for the widths the plain kernel is not instantiated for (SkewShape): table column j of
+// slab s is sub-quantiser s * M + j of the index (an all-zero column past ix.m), the residual in LDS is one slab's,
+// and with n_slabs > 1 a work item walks the slabs: build table s, scan code slab s with every row's accumulator
+// starting from the row's partial sum of slabs < s (`partial`, written and read back by the same lane), select in the
+// last slab.  Every row sum is still LUT[0] + LUT[1] + ... in j order followed by exact `+ 0.0f` terms.
+template <int M, int LR, int NT, bool MULTI, bool OPT = false, bool SLABBED = false>
 __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   static_assert(!OPT || (MULTI && LR * 64 >= (int)SK_SAFE_PASS), "OPT rides on the pass machinery");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -520,8 +565,9 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lm = sk_phase(lane);
   float* lut = (float*)smem;                                  // [256][P] (dual: two slabs)
-  float* res = (float*)(smem + SK_TABLE_BYTES);               // [dim]
-  ListEnt* lists = (ListEnt*)(smem + SK_TABLE_BYTES + (((size_t)ix.dim * 4 + 15) & ~(size_t)15));
+  float* res = (float*)(smem + SK_TABLE_BYTES);               // [dim] (SLABBED: [M * dsub], the current slab's)
+  const uint32_t res_n = SLABBED ? a.res_floats : ix.dim;     // residual elements of the first (only) slab
+  ListEnt* lists = (ListEnt*)(smem + SK_TABLE_BYTES + (((size_t)res_n * 4 + 15) & ~(size_t)15));
   uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);  // [NW]
   uint32_t* s_part = s_cnt + NW;                              // [NW] every wave's q-th best (sort key), QSHARE
   uint32_t* s_ovf = s_part + NW;                              // [1] OPT: a list overflowed in the optimistic pass
@@ -569,7 +615,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       const uint32_t d = tid + u * NT;
       pre_q[u] = 0.f;
       pre_c[u] = 0.f;
-      if (d < ix.dim) {
+      if (d < res_n && d < ix.dim) {
         pre_q[u] = q[d];
         if (ix.metric != MI355_METRIC_DOT) pre_c[u] = c[d];
       }
@@ -609,18 +655,21 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t d = tid + u * NT;
-      if (d < ix.dim) res[d] = pre_q[u] - pre_c[u];  // dot: pre_c == 0, q - 0 == q exactly
+      if (d < res_n) res[d] = pre_q[u] - pre_c[u];  // dot: pre_c == 0, q - 0 == q exactly
     }
     if (tid == 0) *s_thr = __hip_atomic_load(a.qthr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
     if (OPT && tid == 0) *s_ovf = 0u;
     __syncthreads();
-    if (!(a.dbg & 1u)) {
+    // distance table of slab `slab` (the whole row's when !SLABBED): columns = sub-quantisers slab * M .. of the index
+    auto build_lut = [&](uint32_t slab) {
       const uint32_t dsub = ix.dsub;
       const bool dotm = ix.metric == MI355_METRIC_DOT;
-      auto put = [&](uint32_t e, float acc) {
+      const uint32_t jbase = SLABBED ? slab * (uint32_t)M : 0u;
+      auto put = [&](uint32_t e, float acc, bool valid) {
         const uint32_t c = e / (uint32_t)M, j = e % (uint32_t)M;
         if (dotm) acc = 1.0f - acc;
+        if (SLABBED && !valid) acc = 0.f;  // a padding column: `+ 0.0f` is exact
 #ifdef SK_DUAL
         // two slabs of 256-B rows; byte address slab*65536 + c*256 + 4u (u >= 64 spills one row on)
         const uint32_t u = j + 32;
@@ -631,6 +680,17 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         if (j >= (uint32_t)(M - 31)) lut[c * P + j - (M - 32)] = acc;
 #endif
       };
+      // entry e = (code c, column j) -> its codebook vector [256][ix.m][dsub] and whether the column exists
+      auto cb_of = [&](uint32_t e, bool& valid) -> size_t {
+        if constexpr (SLABBED) {
+          const uint32_t c = e / (uint32_t)M, jg = jbase + e % (uint32_t)M;
+          valid = jg < ix.m;
+          return (size_t)c * ix.m + jg;
+        } else {
+          valid = true;
+          return e;
+        }
+      };
       // sub-vector lengths 4 / 8 / 16 (dim / m of the reference's defaults, index/vector.rs:306-310: 768 / 96,
       // 1536 / 96): whole entries as 16-B loads, 8 of them in flight per thread, the chain in element order
       auto lut_fast = [&](auto ds_tag) {
@@ -640,12 +700,20 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         constexpr uint32_t TOTAL = 256u * M;
         for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
           float4 cv4[EPR][V];
+          bool ok[EPR];
 #pragma unroll
           for (int u = 0; u < EPR; ++u) {
             const uint32_t e = e0 + u * NT;
+            ok[u] = false;
             if (e < TOTAL) {
+              const size_t at = cb_of(e, ok[u]);
+              if (ok[u]) {
 #pragma unroll
-              for (int v = 0; v < V; ++v) cv4[u][v] = *(const float4*)(a.cbT + (size_t)e * DS + 4 * v);
+                for (int v = 0; v < V; ++v) cv4[u][v] = *(const float4*)(a.cbT + at * DS + 4 * v);
+              } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) cv4[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+              }
             }
           }
 #pragma unroll
@@ -654,24 +722,26 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
             if (e < TOTAL) {
               const float* rj = res + (e % (uint32_t)M) * DS;
               float acc = 0.f;
+              if (!SLABBED || ok[u]) {
 #pragma unroll
-              for (int v = 0; v < V; ++v) {
-                const float4 r = *(const float4*)(rj + 4 * v);
-                const float4 c = cv4[u][v];
-                if (dotm) {
-                  acc = __fmaf_rn(r.x, c.x, acc);
-                  acc = __fmaf_rn(r.y, c.y, acc);
-                  acc = __fmaf_rn(r.z, c.z, acc);
-                  acc = __fmaf_rn(r.w, c.w, acc);
-                } else {
-                  const float d0 = r.x - c.x, d1 = r.y - c.y, d2 = r.z - c.z, d3 = r.w - c.w;
-                  acc = __fmaf_rn(d0, d0, acc);
-                  acc = __fmaf_rn(d1, d1, acc);
-                  acc = __fmaf_rn(d2, d2, acc);
-                  acc = __fmaf_rn(d3, d3, acc);
+                for (int v = 0; v < V; ++v) {
+                  const float4 r = *(const float4*)(rj + 4 * v);
+                  const float4 c = cv4[u][v];
+                  if (dotm) {
+                    acc = __fmaf_rn(r.x, c.x, acc);
+                    acc = __fmaf_rn(r.y, c.y, acc);
+                    acc = __fmaf_rn(r.z, c.z, acc);
+                    acc = __fmaf_rn(r.w, c.w, acc);
+                  } else {
+                    const float d0 = r.x - c.x, d1 = r.y - c.y, d2 = r.z - c.z, d3 = r.w - c.w;
+                    acc = __fmaf_rn(d0, d0, acc);
+                    acc = __fmaf_rn(d1, d1, acc);
+                    acc = __fmaf_rn(d2, d2, acc);
+                    acc = __fmaf_rn(d3, d3, acc);
+                  }
                 }
               }
-              put(e, acc);
+              put(e, acc, ok[u]);
             }
           }
         }
@@ -684,21 +754,26 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         lut_fast(std::integral_constant<int, 4>{});
       } else {
         for (uint32_t e = tid; e < 256u * M; e += NT) {
-          const float* cb = a.cbT + (size_t)e * dsub;
-          const float* rj = res + (e % (uint32_t)M) * dsub;
+          bool valid;
+          const size_t at = cb_of(e, valid);
           float acc = 0.f;
-          if (dotm) {
-            for (uint32_t t = 0; t < dsub; ++t) acc = __fmaf_rn(rj[t], cb[t], acc);
-          } else {
-            for (uint32_t t = 0; t < dsub; ++t) {
-              float df = rj[t] - cb[t];
-              acc = __fmaf_rn(df, df, acc);
+          if (valid) {
+            const float* cb = a.cbT + at * dsub;
+            const float* rj = res + (e % (uint32_t)M) * dsub;
+            if (dotm) {
+              for (uint32_t t = 0; t < dsub; ++t) acc = __fmaf_rn(rj[t], cb[t], acc);
+            } else {
+              for (uint32_t t = 0; t < dsub; ++t) {
+                float df = rj[t] - cb[t];
+                acc = __fmaf_rn(df, df, acc);
+              }
             }
           }
-          put(e, acc);
+          put(e, acc, valid);
         }
       }
-    }
+    };
+    if (!(a.dbg & 1u)) build_lut(0);
     // the next item's record: one dependent load, lands during the scan
     SkewItem nxt;
     nxt.pair = SK_NONE;
@@ -714,7 +789,9 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
                          })
     // ---- K3 + K4: skewed ADC scan, one stream per wave ----------------------
     auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
-    const uint8_t* pcodes = ix.codes + code_off;
+    const uint32_t n_slabs = SLABBED ? a.n_slabs : 1u;
+    const size_t slab_bytes = (size_t)sk_part_chunks(n_tiles, CPT) * 1024u;  // one slab of this partition's block
+    uint32_t cur_slab = 0;  // the slab whose table (and residual) is in LDS
     const uint32_t thr0_key = *s_thr;  // the query's bound when this item started (valid for every pass)
     uint32_t pass_rows = SCAN_PASS_ROWS;  // (OPT: optimistic passes of SCAN_PASS_ROWS rows, SK_SAFE_PASS after an overflow)
     bool optimistic = OPT;
@@ -816,6 +893,27 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     };
 
 #ifdef SK_DUAL
+    for (uint32_t slab = 0; slab < n_slabs; ++slab) {
+    const bool first_slab = !SLABBED || slab == 0, last_slab = !SLABBED || slab + 1 == n_slabs;
+    if constexpr (SLABBED) {
+      if (cur_slab != slab) {  // (workgroup-uniform) the table of another slab: also a later pass coming back to slab 0
+        __syncthreads();       // every wave is done with the old table and residual
+        for (uint32_t dl = tid; dl < a.res_floats; dl += NT) {
+          const uint32_t dg = slab * a.res_floats + dl;  // res_floats = M * dsub whenever there are several slabs
+          float v = 0.f;
+          if (dg < ix.dim) {
+            v = a.qp[(size_t)b * ix.dim + dg];
+            if (ix.metric != MI355_METRIC_DOT) v -= ix.centroids[(size_t)uni32(rec->part) * ix.dim + dg];
+          }
+          res[dl] = v;
+        }
+        __syncthreads();
+        if (!(a.dbg & 1u)) build_lut(slab);
+        __syncthreads();
+        cur_slab = slab;
+      }
+    }
+    const uint8_t* pcodes = ix.codes + code_off + (SLABBED ? slab * slab_bytes : (size_t)0);
     // two streams (chains A = 2u, B = 2u + 1) per wave; codes arrive chunk by chunk through a
     // ring of RING register slots per chain (prefetch distance RING - 1 chunks)
     for (uint32_t u = wid; u < SK_UNITS && !(a.dbg & 2u); u += NW) {
@@ -835,6 +933,20 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       // hold the tails of tile n1 - 1 (their tile-n1 bytes go to a dummy accumulator)
       const uint32_t n0 = (uint32_t)((uint64_t)nt * slice / a.n_slices), n1 = (uint32_t)((uint64_t)nt * (slice + 1u) / a.n_slices);
       if (n0 == n1) continue;
+      // partial row sums of the slabs before this one: [tile position][unit][lane] float2 (chains A, B), parked by this
+      // very lane in the previous slab.  The load of position n + 1 is issued at the top of position n — before that
+      // position's CPT >= RING - 1 ring fetches, so the counted wait that opens position n + 1 has retired it
+      // (vmcnt retires in order) — and x starts from it.
+      sk_f32x2 px = {0.f, 0.f};
+      float2* ppart = nullptr;
+      if constexpr (SLABBED) {
+        if (n_slabs > 1u) ppart = a.partial + (size_t)blockIdx.x * a.partial_stride + (size_t)u * MI355_WAVE + lane;
+        if (!first_slab)
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(px) : "v"(ppart + (size_t)n0 * (SK_UNITS * MI355_WAVE)) : "memory");
+      }
+      auto park = [&](const sk_f32x2& v, uint32_t tp) {  // (not the last slab) this lane's two rows of position tp
+        ppart[(size_t)tp * (SK_UNITS * MI355_WAVE)] = make_float2(v.x, v.y);
+      };
 #pragma unroll
       for (int g = 0; g < RING; ++g) fetch(g, n0 * CPT + g);
       sk_f32x2 x = {0.f, 0.f}, y = {0.f, 0.f};
@@ -842,6 +954,14 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       const uint32_t sa = u * SK_CHAINS, sb = sa + 1;
       for (uint32_t n = n0; n < n1; ++n) {
         const uint32_t c0 = n * CPT;
+        if constexpr (SLABBED) {
+          if (!first_slab) {
+            asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(px) : "i"(2 * (RING - 1)) : "memory");
+            x = px;
+            const uint32_t nn = sk_min_u32(n + 1u, n1 - 1u);  // (clamped: one load per position, like the ring's)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(px) : "v"(ppart + (size_t)nn * (SK_UNITS * MI355_WAVE)) : "memory");
+          }
+        }
         auto chunks = [&](auto self, auto gtag) -> void {
           constexpr int G = decltype(gtag)::value;
           if constexpr (G < CPT) {
@@ -850,8 +970,12 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
             fetch(G % RING, c0 + G + RING);
             if constexpr (G == 1) {
               if (n > n0) {  // rows of tile position n-1 are complete on every lane after step 30
-                consume(y.x, sa, n - 1);
-                consume(y.y, sb, n - 1);
+                if (last_slab) {
+                  consume(y.x, sa, n - 1);
+                  consume(y.y, sb, n - 1);
+                } else {
+                  park(y, n - 1);
+                }
               }
               if (n == n0 && tid == 0 && nxt_valid) {
                 s_rec[slot ^ 1u] = nxt;
@@ -871,13 +995,20 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         sk_f32x2 dummy = {0.f, 0.f};
         sk_wait_codes<0>(ra[0], rb[0]);  // also drains the clamped prefetches: the ring registers die here
         sk_wait_codes<0>(ra[1 % RING], rb[1 % RING]);
+        if constexpr (SLABBED) asm volatile("" : "+v"(px));  // (its last, clamped load has landed too: vmcnt(0) above)
         skew_dchunk<0>(ra[0], rb[0], r, r2, slab_bit, dummy, y);
         skew_dchunk<1>(ra[1 % RING], rb[1 % RING], r, r2, slab_bit, dummy, y);
-        consume(y.x, sa, n1 - 1);
-        consume(y.y, sb, n1 - 1);
+        if (last_slab) {
+          consume(y.x, sa, n1 - 1);
+          consume(y.y, sb, n1 - 1);
+        } else {
+          park(y, n1 - 1);
+        }
       }
     }
+    }  // slabs
 #else
+    static_assert(!SLABBED, "slabs ride on the two-rows-per-lane blocks");
     for (uint32_t w = wid; w < SK_STREAMS && !(a.dbg & 2u); w += NW) {
       const uint32_t nt = sk_unit_tiles(n_tiles, w);
       if (!nt) continue;

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       if constexpr (SLABBED) {
         if (n_slabs > 1u) ppart = a.partial + (size_t)blockIdx.x * a.partial_stride + (size_t)u * MI355_WAVE + lane;
         if (!first_slab)
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(px) : "v"(ppart + (size_t)n0 * (SK_UNITS * MI355_WAVE)) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(px) : "v"(ppart + (size_t)n0 * (SK_UNITS * MI355_WAVE)) : "memory");
       }
       auto park = [&](const sk_f32x2& v, uint32_t tp) {  // (not the last slab) this lane's two rows of position tp
         ppart[(size_t)tp * (SK_UNITS * MI355_WAVE)] = make_float2(v.x, v.y);
@@ -956,10 +956,14 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         const uint32_t c0 = n * CPT;
         if constexpr (SLABBED) {
           if (!first_slab) {
-            asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(px) : "i"(2 * (RING - 1)) : "memory");
-            x = px;
-            const uint32_t nn = sk_min_u32(n + 1u, n1 - 1u);  // (clamped: one load per position, like the ring's)
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(px) : "v"(ppart + (size_t)nn * (SK_UNITS * MI355_WAVE)) : "memory");
+            // ONE statement: wait for this position's partial sums, start x from them, request the next position's into
+            // the same register (clamped: one load per position, like the ring's).  px is never read by compiler-made code
+            // while a load into it is in flight; scripts/check_inflight_regs.py checks the generated code for copies.
+            const uint32_t nn = sk_min_u32(n + 1u, n1 - 1u);
+            asm volatile("s_waitcnt vmcnt(%c3)\n\tv_mov_b64 %0, %1\n\tglobal_load_dwordx2 %1, %2, off"
+                         : "=&v"(x), "+v"(px)
+                         : "v"(ppart + (size_t)nn * (SK_UNITS * MI355_WAVE)), "i"(2 * (RING - 1))
+                         : "memory");
           }
         }
         auto chunks = [&](auto self, auto gtag) -> void {

@@ -72,9 +72,11 @@ def parse():
     ap.add_argument("--recall2-queries", type=int, default=2_000)
     ap.add_argument("--recall-iters", type=int, default=25, help="Lloyd iterations of the IVF and PQ trainers")
     ap.add_argument("--secondary", type=int, default=1, help="0 = skip the secondary lines (refine operating point, flat C2)")
-    ap.add_argument("--workload", default="ivfpq", choices=["ivfpq", "flat"],
+    ap.add_argument("--workload", default="ivfpq", choices=["ivfpq", "flat", "c4"],
                     help="ivfpq = C3, the configuration BASELINE.json's metric is quoted on (default); "
-                         "flat = C2 (10 M x 768 bf16, 1024 queries), a secondary line for the MFMA path")
+                         "flat = C2 (10 M x 768 bf16, 1024 queries), a secondary line for the MFMA path; "
+                         "c4 = BASELINE.json configs[3] (1 B x 768, nlist 65536, m 96, nprobe 128): with --gpus 8 the sharded run "
+                         "(implies --shard-coarse), with --gpus 1 the single-GPU leg of the default line alone")
     ap.add_argument("--flat-rows", type=int, default=10_000_000)
     ap.add_argument("--flat-batch", type=int, default=1024)
     ap.add_argument("--flat-metric", default="l2", choices=["l2", "cosine", "dot"])
@@ -92,6 +94,15 @@ def parse():
                          "with the unsharded search (0 / 1 = skip)")
     ap.add_argument("--c5-rows", type=int, default=100_000_000,
                     help="rows of the C5 line (BASELINE.json configs[4]: 100 M x 1536 cosine, refine_factor 10); 0 = skip")
+    ap.add_argument("--c4-rows", type=int, default=1_000_000_000,
+                    help="rows of the C4 leg (BASELINE.json configs[3]: 1 B x 768, nlist 65536, m 96, nprobe 128) on one GPU; 0 = skip")
+    ap.add_argument("--shard-coarse", action="store_true",
+                    help="N > 1: shard the coarse quantiser too (MI355_SHARD_COARSE: each rank scores nlist / N centroids; one extra "
+                         "gather of nprobe (partition, distance) pairs per query per rank) — the C4 mode")
+    ap.add_argument("--batch-per-gpu", type=int, default=0,
+                    help="N > 1: queries per step = this x N (the batch grows with the ranks) instead of --batch")
+    ap.add_argument("--widths", type=int, default=1, help="secondary lines at the reference's default PQ widths m = dim / 16 (384-d, 3072-d); 0 = skip")
+    ap.add_argument("--gist-rows", type=int, default=1_000_000, help="rows of the GIST1M-shaped recall@1 / latency line; 0 = skip")
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--slice-rows", type=int, default=0)
     return ap.parse_args()
@@ -114,8 +125,18 @@ def main():
     import torch
     import torch.distributed as dist
 
+    import bench_legs as legs
     import lancedb_amd
     from lancedb_amd import _abi
+    if a.workload == "c4":
+        if a.gpus == 1 and not a.force_sharded_path:  # the single-GPU C4 leg of the default line, alone
+            torch.cuda.set_device(0)
+            res = legs.c4_leg(a, torch, np, torch.device("cuda", 0), n_rows=a.c4_rows, world=a.loopback_world)
+            res.update({"n_gpus": 1, "warmup": 2, "higher_is_better": True, "scaling": "strong", "vs_baseline": None})
+            print(json.dumps(res), flush=True)
+            return
+        # the sharded run of configs[3]: same code path as the C3 scaling run, C4's shape, sharded coarse stage
+        a.n_rows, a.nlist, a.m, a.nprobe, a.shard_coarse = a.c4_rows, 65536, 96, 128, True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,19 +152,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n, dim, nlist, m = a.n_rows, a.dim, a.nlist, a.m
-    dsub = dim // m
+    if a.batch_per_gpu and world > 1:
+        a.batch = a.batch_per_gpu * world
     # ---- synthetic index: small tables identical on every rank (same seed); the O(rows) arrays are
     # generated PER PARTITION (seed = f(SEED, partition)) for the partitions this rank owns only, so a
-    # rank never materialises the others' data and the index is the same for every N
-    g = torch.Generator(device=dev)
-    g.manual_seed(SEED)
-    centroids = torch.randn((nlist, dim), generator=g, device=dev, dtype=torch.float32)
-    codebook = torch.randn((m, 256, dsub), generator=g, device=dev, dtype=torch.float32) * 0.5
-    rng = np.random.default_rng(SEED)
-    w = np.exp(rng.normal(0.0, a.skew, size=nlist))
-    lens = rng.multinomial(n, w / w.sum())
-    part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
-    part_offsets[1:] = np.cumsum(lens)
+    # rank never materialises the others' data and the index is the same for every N (bench_legs.synth_*)
+    tables = legs.synth_tables(torch, np, dev, n, dim, nlist, m, a.skew, seed=SEED)
+    g, centroids, codebook, lens, part_offsets = (tables[k2] for k2 in ("gen", "centroids", "codebook", "lens", "part_offsets"))
     def plan_owner(n_shards):
         """Partition -> shard.  For more than one shard: balanced by the rows a shard SCANS — the probe histogram of a
         calibration batch drawn from the query distribution (not one of the timed batches) weights the partitions
@@ -159,27 +174,8 @@ def main():
             dist.broadcast(hits, src=0)
         return lancedb_amd.shard_plan(part_offsets, n_shards, weights=hits.cpu().numpy())
     owner = plan_owner(world)  # handed to mi355_index_open as part_owner
-    mine = np.nonzero(owner == rank)[0]
-    rows_mine = int(lens[mine].sum())
-    codes = torch.empty((rows_mine * m,), device=dev, dtype=torch.uint8)
-    pos = torch.empty((rows_mine,), device=dev, dtype=torch.int64)  # global index position of every local row
-    gp = torch.Generator(device=dev)
-    off = 0
-    for p in mine:
-        ln = int(lens[p])
-        if ln:
-            gp.manual_seed(SEED * 1_000_003 + int(p))
-            # the uniform code bytes of partition p, declared to be lance's transposed [m, len_p] block
-            torch.randint(0, 256, (ln * m,), generator=gp, device=dev, dtype=torch.uint8, out=codes[off * m:(off + ln) * m])
-            torch.arange(int(part_offsets[p]), int(part_offsets[p + 1]), device=dev, out=pos[off:off + ln])
-            off += ln
-    # _rowid of global position i: an affine permutation of 0..n (no n-sized table on any rank)
-    mult = 982_451_653
-    while np.gcd(mult, n) != 1:
-        mult += 2
-    row_ids = (pos * mult + 12_345) % n
-    del pos
-    torch.cuda.synchronize()
+    legs.synth_rows(torch, np, dev, tables, owner if world > 1 else None, rank)
+    codes, row_ids, rows_mine = tables.pop("codes"), tables.pop("row_ids"), tables["rows"]
 
     t_open = time.time()
     ix = lancedb_amd.IvfPqIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
@@ -223,7 +219,7 @@ def main():
         uid = [unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = Comm(uid[0], rank, world, device=local_rank)
-        searcher = ShardedSearcher(ix, comm, overlap=not a.no_overlap)
+        searcher = ShardedSearcher(ix, comm, shard_coarse=a.shard_coarse, overlap=not a.no_overlap)
 
     def step(i):
         r = searcher.search(qpool[i % P], params, out=out) if searcher else ix.search(qpool[i % P], params, out=out)
@@ -264,7 +260,8 @@ def main():
     traffic = traffic_from_profiles(workload, a.batch) if not sharded else None
 
     result = {
-        "metric": "queries/sec @ recall@10, 100M×768 IVF-PQ nprobe=64 k=10",
+        "metric": ("queries/sec @ recall@10, 100M×768 IVF-PQ nprobe=64 k=10" if a.workload != "c4" else
+                   "queries/sec, IVF-PQ 1B×768 nlist=65536 m=96 nprobe=128 k=10, partitions sharded (BASELINE.json configs[3])"),
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
@@ -304,8 +301,18 @@ def main():
             "rows_scanned_per_rank_timed_steps": cs["rows_scanned"], "load_imbalance_max_over_mean": cs["imbalance"],
             "rows_on_rank": [int(lens[owner == r].sum()) for r in range(world)],
             "shard_plan": "mi355_shard_plan_weighted over the probe histogram of a calibration batch",
+            "coarse": "sharded (MI355_SHARD_COARSE)" if a.shard_coarse else "replicated",
+            "batch_queries": a.batch, "batch_per_gpu_mode": bool(a.batch_per_gpu),
             "stage_us_per_step_by_rank": per_rank,
         }
+        # a scaling run checks itself: the communicator really spans the ranks torch.distributed launched, and every
+        # rank returned the same answers (the merge runs on every rank: compare a checksum of the last step's row ids)
+        assert cs["world"] == world, f"RCCL communicator spans {cs['world']} ranks, launched {world}"
+        chk = torch.stack([last[0].to(torch.int64).sum(), (last[1] * 1e3).to(torch.int64).sum(), last[2].to(torch.int64).sum()])
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        result["multi_gpu"]["all_ranks_returned_the_same_results"] = bool((lo_ == hi_).all().item())
         if world == 1:  # --force-sharded-path: the exchange of a world of one must reproduce the plain search
             plain = ix.search(qpool[(a.steps - 1) % P], params)
             torch.cuda.synchronize()
@@ -337,6 +344,8 @@ def main():
             del codes, row_ids
             torch.cuda.empty_cache()
         result["secondary"]["latency_c3"] = latency_and_concurrency(a, np, ix, qpool)
+        result["secondary"]["qps_vs_batch"] = legs.qps_vs_batch(a, torch, np, ix, centroids, dev)
+        ix.set_stream(stream)
         result["secondary"].update(refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev))
         if a.c5_rows > 0:
             result["secondary"]["c5_refine10"] = c5_refine10(a, torch, np, dev)
@@ -348,6 +357,13 @@ def main():
         ix.close()
         del ix
         torch.cuda.empty_cache()
+        torch.cuda.empty_cache()
+        if a.c4_rows > 0:
+            result["secondary"]["c4"] = legs.c4_leg(a, torch, np, dev, n_rows=a.c4_rows, world=a.loopback_world)
+        if a.widths:
+            result["secondary"].update(legs.width_lines(a, torch, np, dev))
+        if a.gist_rows > 0:
+            result["secondary"]["gist_like"] = legs.gist_like(a, torch, np, dev, n=a.gist_rows)
         for metric in ("l2", "cosine"):
             result["secondary"]["flat_c2_" + metric] = flat_c2(a, metric, cpu_queries=32 if metric == "l2" else 16)
     if rank == 0 and "secondary" in result and "recall_at_10" in result:
@@ -357,6 +373,7 @@ def main():
             {"refine_factor": 10, "queries_per_s": sec.get("c3_refine10", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine10")},
             {"refine_factor": 25, "queries_per_s": sec.get("c3_refine25", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine25")}]
     if rank == 0:
+        result["summary"] = legs.summary_of(result)  # LAST key: the driver keeps only the tail of the line
         print(json.dumps(result), flush=True)
     if sharded:
         # tear down in dependency order: the communicator before the index whose stream it used
@@ -689,15 +706,19 @@ def c5_refine10(a, torch, np, dev):
            torch.empty((B,), dtype=torch.int32, device=dev))
     stream = torch.cuda.current_stream().cuda_stream
     ix.set_stream(stream)
-    ix.configure(profile=0)
+    # the re-rank of step i (a PCIe gather) runs beside the scan of step i + 1: opt-in (MI355_CFG_DEFER_REFINE), results
+    # complete at sync()
+    ix.configure(profile=0, defer_refine=host_mapped)
     for i in range(2):
         ix.search(qpool[i % P], params, out=out)
+    ix.sync()
     torch.cuda.synchronize()
     ix.configure(profile=2)
     steps = max(6, a.steps)  # (the re-rank of step i runs beside the scan of step i + 1: the last one drains inside the timed region)
     t0 = time.perf_counter()
     for i in range(steps):
         last = ix.search(qpool[i % P], params, out=out)
+    ix.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = ix.stats()
@@ -725,7 +746,9 @@ def c5_refine10(a, torch, np, dev):
     if a.cpu_seconds > 0:
         from oracle import oracle as orc
         orc.build()
-        cores = os.cpu_count() or 1
+        import bench_legs as legs
+        hc = legs.host_cores()
+        cores = hc["usable"]
         nq = min(B, cores)
         h_raw = raw if host_mapped else col.cpu().numpy().view(np.uint16)
         ox = orc.OracleIndex(centroids.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
@@ -733,11 +756,12 @@ def c5_refine10(a, torch, np, dev):
                              metric="cosine", codes_layout=1, borrow=True)
         hq = qpool[(steps - 1) % P][:nq].cpu().numpy()
         t1 = time.perf_counter()
-        ids, dist, cnt, _ = ox.search(hq, params)
+        ids, dist, cnt, _ = ox.search(hq, params, nthreads=cores)
         t_cpu = time.perf_counter() - t1
         g_ids = last.rowids[:nq].cpu().numpy().astype(np.uint64)
         g_dist = last.distances[:nq].cpu().numpy()
-        res["cpu_baseline"] = {"value": nq / t_cpu, "unit": "queries/s", "cores": cores, "kind": "port",
+        res["cpu_baseline"] = {"value": nq / t_cpu, "unit": "queries/s", "cores": cores, "host_cores": hc, "kind": "port",
+                               "stage_cpu_seconds": ox.last_stage_seconds,
                                "sample": f"{nq} queries of the last timed batch, one per thread, {t_cpu:.1f} s; C restatement "
                                          "(oracle/ann_oracle.c), not the reference binary",
                                "parity": {"queries": nq, "rowids_bit_exact": bool((g_ids == ids).all()),
@@ -814,7 +838,9 @@ def flat_c2(a, metric, cpu_queries):
     if a.cpu_seconds > 0 and cpu_queries:
         from oracle import oracle as orc
         orc.build()
-        cores = os.cpu_count() or 1
+        import bench_legs as legs
+        hc = legs.host_cores()
+        cores = hc["usable"]
         nq = min(B, cpu_queries)  # every query sweeps the whole column on the host
         hv = col.view(torch.int16).cpu().numpy().view(np.uint16)
         hq = qpool[(steps - 1) % P][:nq].cpu().numpy()
@@ -824,8 +850,8 @@ def flat_c2(a, metric, cpu_queries):
         g_ids = last.rowids[:nq].cpu().numpy().astype(np.uint64)
         g_dist = last.distances[:nq].cpu().numpy()
         res["cpu_baseline"] = {
-            "value": nq / dt, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"{nq} queries of the last timed batch, one per thread, {dt:.1f} s on {cores} host cores; "
+            "value": nq / dt, "unit": "queries/s", "cores": min(cores, nq), "host_cores": hc, "kind": "port",
+            "sample": f"{nq} queries of the last timed batch, one per thread, {dt:.1f} s on {min(cores, nq)} of {cores} usable host cores; "
                       "C restatement (oracle/ann_oracle.c), not the reference binary",
             "parity": {"queries": nq, "rowids_bit_exact": bool((g_ids == ids).all()),
                        "distances_equal": bool((g_dist == dist).all())}}
@@ -917,14 +943,19 @@ def recall_at_10(a, np, dim, m):
         orc.build()
         ox = orc.OracleIndex(cen.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
                              order.cpu().numpy().astype(np.uint64), raw_vectors=xs.cpu().numpy())
+    # the oracle answers the first `n_or` queries of every operating point (row for row against the engine; its recall is
+    # over those queries) — all 10 k on the host were 110 s of a 190 s bench run
+    n_or = min(nq, 2048)
+    out["cpu_oracle_queries"] = n_or
     for nprobe, rf in ((64, 0), (64, 10), (64, 25), (64, 50), (16, 0)):
         key = f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")
         got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf).rowids
         out[key] = rec(got)
         if ox is not None:
-            o_ids, _, _, _ = ox.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
-            out[key + "_cpu_oracle"] = rec(o_ids)
-            out[key + "_rowids_bit_exact"] = bool((o_ids == got).all())
+            o_ids, _, _, _ = ox.search(hq[:n_or], k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+            out[key + "_cpu_oracle"] = round(float(np.mean([len(set(truth[i].tolist()) & set(o_ids[i].tolist())) / 10.0 for i in range(n_or)])), 4)
+            out[key + "_engine_same_queries"] = round(float(np.mean([len(set(truth[i].tolist()) & set(got[i].tolist())) / 10.0 for i in range(n_or)])), 4)
+            out[key + "_rowids_bit_exact"] = bool((o_ids == got[:n_or]).all())
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 
@@ -1042,34 +1073,49 @@ def traffic_from_profiles(workload, batch):
 
 
 def cpu_baseline(a, np, centroids, codebook, part_offsets, codes, row_ids, d_queries, last, params):
-    """The C oracle (a restatement, kind = "port") on this box's host cores over a
-    bounded sample of the last batch; doubles as the full-size parity check."""
+    """The C oracle (a restatement, kind = "port") on this box's host cores over a bounded sample of the last batch;
+    doubles as the full-size parity check.  `cores` = the threads it ran on: the process's affinity mask capped by the
+    cgroup's CPU quota (bench_legs.host_cores — os.cpu_count() is the box, not what the container may use); the
+    per-stage CPU seconds (summed over the threads) say where the oracle's time goes."""
+    import bench_legs as legs
     from oracle import oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    hc = legs.host_cores()
+    cores = hc["usable"]
     ox = orc.OracleIndex(centroids, codebook, part_offsets, codes, row_ids, metric="l2",
                          codes_layout=1, borrow=True)
     q = d_queries.cpu().numpy()
+    n0 = min(len(q), cores)
     t0 = time.perf_counter()
-    ids0, dist0, cnt0, st = ox.search(q[:cores], params)
+    ids0, dist0, cnt0, st = ox.search(q[:n0], params, nthreads=cores)
     t_probe = time.perf_counter() - t0
-    n_more = int(max(0, min(len(q) - cores, (a.cpu_seconds - t_probe) / max(t_probe, 1e-3) * cores)))
+    stage = dict(ox.last_stage_seconds)
+    n_more = int(max(0, min(len(q) - n0, (a.cpu_seconds - t_probe) / max(t_probe, 1e-3) * cores)))
     n_more -= n_more % cores
     t1 = time.perf_counter()
     if n_more:
-        ids1, dist1, cnt1, _ = ox.search(q[cores:cores + n_more], params)
+        ids1, dist1, cnt1, _ = ox.search(q[n0:n0 + n_more], params, nthreads=cores)
+        for k2, v2 in ox.last_stage_seconds.items():
+            stage[k2] += v2
     t_more = time.perf_counter() - t1
-    nq = cores + n_more
+    nq = n0 + n_more
     ids = np.concatenate([ids0, ids1]) if n_more else ids0
     dst = np.concatenate([dist0, dist1]) if n_more else dist0
     g_ids = last[0][:nq].cpu().numpy().astype(np.uint64)
     g_dist = last[1][:nq].cpu().numpy()
     rel = float(np.max(np.abs(g_dist - dst) / np.maximum(np.abs(dst), 1e-30)))
+    wall = t_probe + t_more
+    busy = sum(stage.values())
     return {
-        "value": nq / (t_probe + t_more), "unit": "queries/s", "cores": cores, "kind": "port",
-        "sample": f"{nq} queries of the last timed batch, one query per thread (OpenMP), "
-                  f"{t_probe + t_more:.1f} s of wall time on {cores} host cores; C restatement of the "
-                  "lance-index IVF-PQ path (oracle/ann_oracle.c, -O3 -mavx2 -mfma), not the reference binary",
+        "value": nq / wall, "unit": "queries/s", "cores": cores, "host_cores": hc, "kind": "port",
+        "queries_per_s_per_core": nq / wall / cores,
+        "stage_cpu_seconds": {k2: round(v2, 3) for k2, v2 in stage.items()},
+        "cpu_seconds_per_query": busy / max(nq, 1),
+        "thread_utilisation": busy / max(wall * cores, 1e-9),
+        "sample": f"{nq} queries of the last timed batch, one query per thread (OpenMP, {cores} threads = affinity {hc['affinity']}, "
+                  f"cgroup CPU quota {hc['cgroup_cpu_quota']}, box {hc['box']}), {wall:.1f} s of wall time; C restatement of the "
+                  "lance-index IVF-PQ path (oracle/ann_oracle.c, -O3 -mavx2 -mfma; coarse stage 8 centroids per AVX2 register, "
+                  "ADC 8 sub-quantisers per sweep — same chains, same bits), not the reference binary",
         "parity": {"queries": nq, "rowids_bit_exact": bool((g_ids == ids).all()), "max_rel_distance_error": rel},
     }
 

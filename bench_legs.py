@@ -1,0 +1,539 @@
+"""Secondary legs of bench.py (round 4): BASELINE.json configs[3] (C4) at full size on one MI355X, the reference's
+default PQ widths on the production scan, throughput against batch size, and a GIST1M-shaped recall / latency line.
+The timed region of the driver's metric stays in bench.py; everything here is reported under `secondary`.
+
+PyTorch is used for device memory and the RNG only; every timed kernel is the engine's own HIP code behind the C ABI.
+"""
+import os
+import time
+
+SEED = 0x1A2CE
+HBM_PEAK_GBS = 8000.0
+F32_MFMA_PEAK_TF = 157.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+
+
+# --------------------------------------------------------------------------------------- host cores ----
+def host_cores():
+    """What the CPU legs may use, and what they are printed with: the affinity mask of this process capped by the
+    cgroup's CPU quota (cpu.max, v2; cfs quota, v1) — os.cpu_count() is the box, not the container."""
+    n_box = os.cpu_count() or 1
+    try:
+        n_aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n_aff = n_box
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = n_aff if quota is None else max(1, min(n_aff, int(quota + 0.5)))
+    return {"usable": int(usable), "affinity": int(n_aff), "cgroup_cpu_quota": quota, "box": int(n_box)}
+
+
+# --------------------------------------------------------------------------------- synthetic indexes ----
+def synth_tables(torch, np, dev, n, dim, nlist, m, skew, seed=SEED, cen_scale=1.0, cb_scale=0.5):
+    """The small tables of a throughput dataset, identical on every rank: centroids ~ N(0,1),
+    codebook ~ N(0,0.25), log-normally skewed partition lengths.  `gen` is the device generator, positioned behind
+    the tables (the query batches are drawn from it next)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centroids = torch.randn((nlist, dim), generator=g, device=dev, dtype=torch.float32) * cen_scale
+    codebook = torch.randn((m, 256, dim // m), generator=g, device=dev, dtype=torch.float32) * cb_scale
+    rng = np.random.default_rng(seed)
+    w = np.exp(rng.normal(0.0, skew, size=nlist))
+    lens = rng.multinomial(n, w / w.sum())
+    part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
+    part_offsets[1:] = np.cumsum(lens)
+    return {"centroids": centroids, "codebook": codebook, "part_offsets": part_offsets, "lens": lens, "gen": g, "n": n, "m": m,
+            "seed": seed}
+
+
+def synth_rows(torch, np, dev, t, owner=None, rank=0):
+    """The O(rows) arrays of `t` = synth_tables(...): uniform u8 codes in lance's per-partition transposed blocks and row
+    ids = an affine permutation of the global index position, generated PER PARTITION (seed = f(seed, partition)) for the
+    partitions of `owner == rank` only (all when owner is None) — a rank never materialises another rank's rows and the
+    index is the same for every world size."""
+    n, m, seed, lens, part_offsets = t["n"], t["m"], t["seed"], t["lens"], t["part_offsets"]
+    nlist = len(lens)
+    mine = np.arange(nlist) if owner is None else np.nonzero(owner == rank)[0]
+    lm = lens[mine].astype(np.int64)
+    rows_mine = int(lm.sum())
+    codes = torch.empty((rows_mine * m,), device=dev, dtype=torch.uint8)
+    gp = torch.Generator(device=dev)
+    off = 0
+    for p, ln in zip(mine.tolist(), lm.tolist()):
+        if ln:
+            gp.manual_seed(seed * 1_000_003 + p)
+            torch.randint(0, 256, (ln * m,), generator=gp, device=dev, dtype=torch.uint8, out=codes[off * m:(off + ln) * m])
+            off += ln
+    # global index position of every local row, then _rowid = an affine permutation of 0..n (no n-sized table anywhere)
+    local_start = np.cumsum(lm) - lm
+    delta = torch.from_numpy(part_offsets[mine].astype(np.int64) - local_start).to(dev)
+    pos = torch.arange(rows_mine, device=dev, dtype=torch.int64)
+    if rows_mine:
+        pos += torch.repeat_interleave(delta, torch.from_numpy(lm).to(dev), output_size=rows_mine)
+    mult = 982_451_653
+    while np.gcd(mult, n) != 1:
+        mult += 2
+    row_ids = (pos * mult + 12_345) % n
+    del pos
+    torch.cuda.synchronize()
+    t.update({"codes": codes, "row_ids": row_ids, "rows": rows_mine, "mine": mine})
+    return t
+
+
+def synth_ivfpq(torch, np, dev, n, dim, nlist, m, skew, seed=SEED, owner=None, rank=0):
+    return synth_rows(torch, np, dev, synth_tables(torch, np, dev, n, dim, nlist, m, skew, seed), owner, rank)
+
+
+def query_pool(torch, s, nlist, dim, batch, n_batches, noise=0.5):
+    out = []
+    for _ in range(n_batches):
+        pick = torch.randint(0, nlist, (batch,), generator=s["gen"], device=s["centroids"].device)
+        out.append((s["centroids"][pick] + noise * torch.randn((batch, dim), generator=s["gen"], device=s["centroids"].device)).contiguous())
+    return out
+
+
+def out_buffers(torch, dev, B, k):
+    return (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+            torch.empty((B,), dtype=torch.int32, device=dev))
+
+
+def timed_steps(torch, ix, qpool, params, out, steps, warmup=2, searcher=None):
+    """-> (seconds per step, stats of the timed steps, last result)."""
+    run = (lambda q: searcher.search(q, params, out=out)) if searcher else (lambda q: ix.search(q, params, out=out))
+    ix.configure(profile=0)
+    for i in range(warmup):
+        run(qpool[i % len(qpool)])
+    ix.sync()
+    torch.cuda.synchronize()
+    ix.configure(profile=2)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = run(qpool[i % len(qpool)])
+    ix.sync()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = ix.stats()
+    ix.configure(profile=0)
+    return dt, st, last
+
+
+def scan_line(st, steps, B, dt, n_cus=256):
+    """The section-8d numbers of a run: algorithmic code bytes (m bytes per scanned row) over the scan kernel's own time."""
+    us = st["us_scan"] / max(steps, 1)
+    by = st["code_bytes_scanned"] / max(steps, 1)
+    gbs = by / max(us, 1e-9) / 1e3
+    return {"value": B / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge")},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": by, "us_per_launch": us,
+                         "lds_gather_frac": by / max(us * 1e-6, 1e-12) / (n_cus * 32 * 2.4e9),
+                         "frac_definition": "no-reuse algorithmic code bytes / scan-kernel time / 8 TB/s (SURVEY.md section 8d)"},
+            "scan_variant": st["scan_variant"]}
+
+
+# ------------------------------------------------------------------------------------------------ C4 ----
+def _reduced_host_index(torch, np, s, parts, m):
+    """Host copy of an index in which only `parts` keep their rows (every other partition is empty): what the CPU
+    oracle needs to answer queries that probe only those partitions, without 96 GB of codes crossing PCIe."""
+    po = s["part_offsets"].astype(np.int64)
+    keep = np.zeros(len(po) - 1, dtype=bool)
+    keep[parts] = True
+    lens = np.where(keep, np.diff(po), 0)
+    red_po = np.zeros(len(po), dtype=np.uint64)
+    red_po[1:] = np.cumsum(lens)
+    idx = np.nonzero(keep)[0]
+    code_chunks = [s["codes"][int(po[p]) * m:int(po[p + 1]) * m] for p in idx]
+    id_chunks = [s["row_ids"][int(po[p]):int(po[p + 1])] for p in idx]
+    h_codes = torch.cat(code_chunks).cpu().numpy() if code_chunks else np.zeros(0, np.uint8)
+    h_ids = torch.cat(id_chunks).cpu().numpy().astype(np.uint64) if id_chunks else np.zeros(0, np.uint64)
+    return red_po, h_codes, h_ids
+
+
+def c4_leg(a, torch, np, dev, n_rows=1_000_000_000, world=8, parity_queries=64):
+    """BASELINE.json configs[3] / SURVEY.md section 8e: IVF-PQ 1 B x 768, nlist 65536, m = 96 x 8 bit, nprobe 128, k 10
+    (nprobes semantics: rust/lancedb/src/query.rs:1216-1280; builder shape: index/vector.rs:266-304) on ONE MI355X:
+    96 GB of codes + 8 GB of row ids + 201 MB of centroids fit its 288 GB.
+      (a) the unsharded handle: QPS, stage times, the section-8d roofline of the scan (187.5 MB of codes per query ->
+          42.7 k QPS at 8 TB/s on one GPU), and the coarse quantiser at nlist 65536 as its own line (100.7 MFLOP per
+          query against the f32 matrix peak);
+      (b) a CPU-oracle parity sample of `parity_queries` queries of the last timed batch, on a host copy of the index
+          in which the partitions those queries probe keep their rows (the oracle ranks all 65536 centroids itself; the
+          rows it scans must add up to the engine's count for the same queries, so a probe outside the copied set shows);
+      (c) `world` loopback ranks with the sharded coarse stage (MI355_SHARD_COARSE) and the probe-weighted shard plan:
+          every rank == the unsharded result at full size, each rank's own stage times, and the N-GPU step model against
+          the aggregate roofline (341 k QPS at 8 x 8 TB/s)."""
+    import lancedb_amd
+    from lancedb_amd import _abi
+    from lancedb_amd.distributed import Comm, ShardedSearcher, coarse_slice, run_ranks
+    n, dim, nlist, m, nprobe, k, B = n_rows, 768, 65536, 96, 128, a.k, a.batch
+    free, _ = torch.cuda.mem_get_info(dev)
+    need = n * (m + 8) * 2 + (12 << 30)
+    if free < need:
+        scale = (free - (12 << 30)) / (n * (m + 8) * 2)
+        n = int(n * scale) // 10_000_000 * 10_000_000
+        if n < 100_000_000:
+            return {"skipped": f"{free / 1e9:.0f} GB of HBM free: not enough for a C4-sized index"}
+    t0 = time.perf_counter()
+    s = synth_ivfpq(torch, np, dev, n, dim, nlist, m, a.skew, seed=SEED + 4)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric="l2",
+                                codes_layout=_abi.CODES_PART_TRANSPOSED)
+    t_open = time.perf_counter() - t0
+    P = 3
+    qpool = query_pool(torch, s, nlist, dim, B, P)
+    params = _abi.make_params(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
+    out = out_buffers(torch, dev, B, k)
+    ix.set_stream(torch.cuda.current_stream().cuda_stream)
+    steps = max(4, a.steps // 2)
+    dt, st, last = timed_steps(torch, ix, qpool, params, out, steps)
+    line = scan_line(st, steps, B, dt, torch.cuda.get_device_properties(dev).multi_processor_count)
+    coarse_us = st["us_coarse"] / steps
+    res = {
+        "metric": "queries/sec, IVF-PQ 1B×768 nlist=65536 m=96 nprobe=128 k=10 (BASELINE.json configs[3]), one MI355X",
+        **line, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{nprobe}_k{k}_l2", "n_rows": n, "rows_asked": n_rows,
+                   "batch_queries": B, "nlist": nlist, "m": m, "nprobe": nprobe, "k": k, "partition_skew_sigma": a.skew,
+                   "generate_s": round(t_gen, 1), "index_open_s": round(t_open, 1),
+                   "hbm_gb": {"codes_packed": round(n * m * 1.014 / 1e9, 1), "row_ids": round(n * 8 / 1e9, 1)}},
+        "roofline_qps_at_8tbs_one_gpu": HBM_PEAK_GBS * 1e9 / (st["code_bytes_scanned"] / max(st["n_queries"], 1)),
+        "coarse_nlist65536": {"us_per_step": coarse_us, "flops_per_query": 2.0 * nlist * dim,
+                              "tflops": 2.0 * B * nlist * dim / max(coarse_us, 1e-9) / 1e6,
+                              "frac_of_f32_mfma_peak": 2.0 * B * nlist * dim / max(coarse_us, 1e-9) / 1e6 / F32_MFMA_PEAK_TF,
+                              "centroid_bytes": nlist * dim * 4, "share_of_step": coarse_us / (dt * 1e6)},
+    }
+    res["config"]["bytes_per_query_algorithmic"] = st["code_bytes_scanned"] / max(st["n_queries"], 1)
+    # the unsharded answers of the batch the loopback ranks are compared on, and its probe list (sharded-coarse check)
+    ref = ix.search(qpool[(steps - 1) % P], params)
+    torch.cuda.synchronize()
+    ref_ids, ref_dist = ref.rowids.clone(), ref.distances.clone()
+    # ---- (b) CPU-oracle parity sample
+    if a.cpu_seconds > 0 and parity_queries:
+        from oracle import oracle as orc
+        orc.build()
+        nq = min(parity_queries, B)
+        q_dev = qpool[(steps - 1) % P][:nq].contiguous()
+        pr, _, _ = ix.coarse_topn(q_dev, nprobe)
+        parts = np.unique(pr.cpu().numpy().astype(np.int64).reshape(-1))
+        parts = parts[(parts >= 0) & (parts < nlist)]
+        t1 = time.perf_counter()
+        red_po, h_codes, h_ids = _reduced_host_index(torch, np, s, parts, m)
+        t_copy = time.perf_counter() - t1
+        ox = orc.OracleIndex(s["centroids"].cpu().numpy(), s["codebook"].cpu().numpy(), red_po, h_codes, h_ids, metric="l2",
+                             codes_layout=1, borrow=True)
+        t1 = time.perf_counter()
+        o_ids, o_dist, o_cnt, _ = ox.search(q_dev.cpu().numpy(), params)
+        t_cpu = time.perf_counter() - t1
+        ix.configure(profile=0)
+        got = ix.search(q_dev, params)
+        torch.cuda.synchronize()
+        eng_rows = ix.stats()["vectors_scanned"]
+        cores = host_cores()
+        res["cpu_baseline"] = {
+            "value": nq / t_cpu, "unit": "queries/s", "cores": cores["usable"], "kind": "port",
+            "sample": f"{nq} queries of the last timed batch, one per thread, {t_cpu:.1f} s; the oracle ranks all {nlist} centroids and "
+                      f"scans a host copy holding the {len(parts)} partitions these queries probe ({h_codes.nbytes / 1e9:.1f} GB, copied in "
+                      f"{t_copy:.1f} s); C restatement (oracle/ann_oracle.c), not the reference binary",
+            "parity": {"queries": nq, "rowids_bit_exact": bool((got.rowids.cpu().numpy().astype(np.uint64) == o_ids).all()),
+                       "distances_equal": bool((got.distances.cpu().numpy() == o_dist).all()),
+                       "counts_equal": bool((got.counts.cpu().numpy().astype(np.uint32) == o_cnt).all()),
+                       "rows_scanned_engine": int(eng_rows), "rows_scanned_oracle": int(ox.last_vectors_scanned),
+                       "oracle_probed_only_copied_partitions": bool(int(eng_rows) == int(ox.last_vectors_scanned))}}
+        ox.close()
+        del h_codes, h_ids
+    # ---- (c) `world` loopback ranks, sharded coarse, probe-weighted plan
+    if world > 1:
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(SEED + 99)
+        qc = s["centroids"][torch.randint(0, nlist, (2048,), generator=gc, device=dev)] + 0.5 * torch.randn((2048, dim), generator=gc, device=dev)
+        prc, _, _ = ix.coarse_topn(qc.contiguous(), nprobe)  # calibration batch (not one of the timed ones)
+        hits = torch.bincount(prc.flatten().clamp(0, nlist - 1), minlength=nlist).to(torch.float32).cpu().numpy()
+        owner = lancedb_amd.shard_plan(s["part_offsets"], world, weights=hits)
+        probes_ref, _, _ = ix.coarse_topn(qpool[0], nprobe)  # what a rank's scan stage is timed on when it runs alone
+        torch.cuda.synchronize()
+        ix.close()
+        del ix
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        shards = [lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric="l2",
+                                         codes_layout=_abi.CODES_PART_TRANSPOSED, shard_count=world, shard_rank=r, part_owner=owner)
+                  for r in range(world)]
+        t_sh = time.perf_counter() - t0
+        del s["codes"], s["row_ids"]
+        torch.cuda.empty_cache()
+        comms = Comm.loopback(world)
+        outs = [out_buffers(torch, dev, B, k) for _ in range(world)]
+        st2 = max(3, steps // 2)
+        per_rank = []
+        for r in range(world):
+            lo, hi = coarse_slice(nlist, world, r)
+            for _ in range(2):
+                shards[r].coarse_topn(qpool[0], nprobe, lo, hi)
+                shards[r].search_probes(qpool[0], probes_ref, params, out=outs[r])
+            shards[r].sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(st2):
+                shards[r].coarse_topn(qpool[0], nprobe, lo, hi)
+            shards[r].sync()
+            torch.cuda.synchronize()
+            t_co = (time.perf_counter() - t1) / st2
+            shards[r].configure(profile=2)
+            t1 = time.perf_counter()
+            for _ in range(st2):
+                shards[r].search_probes(qpool[0], probes_ref, params, out=outs[r])
+            shards[r].sync()
+            torch.cuda.synchronize()
+            t_sc = (time.perf_counter() - t1) / st2
+            sst = shards[r].stats()
+            shards[r].configure(profile=0)
+            per_rank.append({"rows": shards[r].info()[0], "coarse_slice_us": t_co * 1e6, "probe_take_plan_scan_merge_us": t_sc * 1e6,
+                             "scan_us": sst["us_scan"] / st2, "merge_us": sst["us_merge"] / st2, "step_us": (t_co + t_sc) * 1e6})
+
+        def rank_fn(r):
+            sh = ShardedSearcher(shards[r], comms[r], shard_coarse=True, overlap=True)
+            sh.search(qpool[0], params, out=outs[r])
+            shards[r].sync()
+            t2 = time.perf_counter()
+            for i in range(st2):
+                sh.search(qpool[(steps - 1 - (st2 - 1 - i)) % P], params, out=outs[r])  # (ends on the reference batch)
+            shards[r].sync()
+            return (time.perf_counter() - t2) / st2, comms[r].stats()
+        got = run_ranks([lambda r=r: rank_fn(r) for r in range(world)])
+        torch.cuda.synchronize()
+        same = all(bool((outs[r][0] == ref_ids).all().item() and (outs[r][1] == ref_dist).all().item()) for r in range(world))
+        cs = got[0][1]
+        slow = max(p["step_us"] for p in per_rank)
+        mean = float(np.mean([p["step_us"] for p in per_rank]))
+        res["loopback_world%d" % world] = {
+            "coarse": "sharded (MI355_SHARD_COARSE): each rank scores nlist / world centroids, one extra gather of nprobe (partition, distance) pairs",
+            "shard_plan": "mi355_shard_plan_weighted over the probe histogram of a calibration batch",
+            "shard_open_s": round(t_sh, 1), "every_rank_equals_unsharded": same,
+            "all_ranks_on_one_gpu_ms_per_step": max(g_[0] for g_ in got) * 1e3,
+            "gathers_per_step": cs["n_gathers"], "bytes_gathered_per_step": cs["bytes_gathered"],
+            "rows_scanned_by_rank": cs["rows_scanned"], "load_imbalance_max_over_mean": cs["imbalance"],
+            "stage_us_per_step_by_rank_alone": per_rank,
+            "step_model": {"slowest_rank_us": slow, "mean_rank_us": mean, "qps_overlapped": B / (slow * 1e-6),
+                           "qps_if_ranks_were_balanced": B / (mean * 1e-6),
+                           "aggregate_roofline_qps_at_8x8tbs": world * res["roofline_qps_at_8tbs_one_gpu"],
+                           "frac_of_aggregate_roofline": B / (slow * 1e-6) / (world * res["roofline_qps_at_8tbs_one_gpu"]),
+                           "note": "each rank's own step with the GPU to itself: its slice of the coarse quantiser + the scan of the probed "
+                                   "partitions it owns (external probe list = the merged global one) + its local merge; the exchange runs on "
+                                   "the communicator's stream under the next step's scan.  A model from measured terms, not a measurement of "
+                                   "N GPUs"}}
+        for c in comms:
+            c.close()
+        for sh in shards:
+            sh.close()
+    else:
+        ix.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+# -------------------------------------------------------------------- the reference's default PQ widths ----
+def width_lines(a, torch, np, dev, shapes=((384, 24), (3072, 192)), n_rows=100_000_000):
+    """`suggested_num_sub_vectors` (rust/lancedb/src/index/vector.rs:306-319) gives m = dim / 16: 24 for 384-d, 192 for
+    3072-d — neither is a kernel width of the production scan.  Round 4 runs them on it anyway (padding / slabs,
+    csrc/kernels_skew.h SkewShape); these lines are the C3 workload at those shapes with the section-8d fraction of each
+    (algorithmic bytes = the REAL m bytes per scanned row: padding bytes are not credited)."""
+    import lancedb_amd
+    from lancedb_amd import _abi
+    out = {}
+    nlist, nprobe, k, B = a.nlist, a.nprobe, a.k, a.batch
+    for dim, m in shapes:
+        free, _ = torch.cuda.mem_get_info(dev)
+        n = n_rows
+        while n * (m + 8) * 2.2 + (8 << 30) > free and n > 10_000_000:
+            n //= 2
+        s = synth_ivfpq(torch, np, dev, n, dim, nlist, m, a.skew, seed=SEED + dim)
+        ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric="l2",
+                                    codes_layout=_abi.CODES_PART_TRANSPOSED)
+        del s["codes"], s["row_ids"]
+        torch.cuda.empty_cache()
+        qpool = query_pool(torch, s, nlist, dim, B, 2)
+        params = _abi.make_params(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
+        outb = out_buffers(torch, dev, B, k)
+        ix.set_stream(torch.cuda.current_stream().cuda_stream)
+        steps = max(3, a.steps // 3)
+        dt, st, _ = timed_steps(torch, ix, qpool, params, outb, steps, warmup=1)
+        line = scan_line(st, steps, B, dt, torch.cuda.get_device_properties(dev).multi_processor_count)
+        line["config"] = {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{nprobe}_k{k}_l2", "n_rows": n, "dim": dim, "m": m,
+                          "batch_queries": B, "table": "padded to 32 columns" if m < 32 else f"{(m + 95) // 96} slabs of {((-(-m // ((m + 95) // 96))) + 15) // 16 * 16} columns"}
+        out[f"c3_shape_dim{dim}_m{m}"] = line
+        ix.close()
+        del ix, s
+        torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------- throughput vs batch ----
+def qps_vs_batch(a, torch, np, ix, centroids, dev, batches=(1, 8, 64, 256, 512, 1024, 2048)):
+    """The reference's callers are concurrent single queries (python/src/runtime.rs:31-37; one plan per query vector,
+    table/query.rs:334-381); the headline is quoted at a batch of 2048.  The same C3 index, device I/O, at smaller
+    batches: QPS, scan microseconds and the section-8d fraction per point."""
+    from lancedb_amd import _abi
+    nlist, dim = centroids.shape
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 31)
+    params = _abi.make_params(k=a.k, nprobe_min=a.nprobe, nprobe_max=a.nprobe)
+    pts = []
+    for B in batches:
+        pool = []
+        for _ in range(3):
+            pick = torch.randint(0, nlist, (B,), generator=g, device=dev)
+            pool.append((centroids[pick] + 0.5 * torch.randn((B, dim), generator=g, device=dev)).contiguous())
+        outb = out_buffers(torch, dev, B, a.k)
+        steps = 30 if B <= 64 else 12 if B <= 512 else 6
+        dt, st, _ = timed_steps(torch, ix, pool, params, outb, steps, warmup=2)
+        us = st["us_scan"] / steps
+        by = st["code_bytes_scanned"] / steps
+        pts.append({"batch": B, "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "scan_us": us,
+                    "frac_of_8tbs": by / max(us, 1e-9) / 1e3 / HBM_PEAK_GBS,
+                    "work_items_per_step": st["work_items"] / steps,
+                    "stage_us": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge")}})
+    return pts
+
+
+# -------------------------------------------------------------------------------- GIST1M-shaped line ----
+def gist_like(a, torch, np, dev, n=1_000_000, dim=960, nq=1000):
+    """The one operating point the reference publishes (docs/src/assets/recall-vs-latency.webp,
+    refine semantics rust/lancedb/src/query.rs:1302-1332): GIST1M, IVF-PQ + refine, recall@1 against mean single-query
+    latency at nprobes 25 / 50 / 75 / 100 x refine_factor 30 / 50.  GIST itself is not in the container: the column is
+    1 M x 960 unit-scale vectors of low intrinsic dimension (the shape of descriptor / embedding data), the index is
+    built with the reference's defaults for that shape — m = 960 / 16 = 60 (index/vector.rs:306-319), num_partitions =
+    rows / 8192 = 122 (create_index.rs:733-795) — by the engine's own trainer and encoder.  Chart values are context
+    only: their hardware is not stated."""
+    import lancedb_amd
+    from lancedb_amd import _abi
+    t0 = time.perf_counter()
+    m, nlist, idim = dim // 16, max(1, n // 8192), 64
+    dsub = dim // m
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 21)
+    spec = 1.0 / torch.sqrt(1.0 + torch.arange(idim, device=dev, dtype=torch.float32))
+    W = torch.linalg.qr(torch.randn((dim, idim), generator=g, device=dev))[0].T.contiguous()
+    centers = torch.randn((1000, idim), generator=g, device=dev)
+
+    def draw(cnt):
+        z = (centers[torch.randint(0, 1000, (cnt,), generator=g, device=dev)] + 0.5 * torch.randn((cnt, idim), generator=g, device=dev)) * spec
+        return (z @ W + 0.03 * torch.randn((cnt, dim), generator=g, device=dev) * float(spec.norm()) / np.sqrt(dim)).contiguous()
+    x = torch.empty((n, dim), device=dev)
+    for r0 in range(0, n, 250_000):
+        x[r0:r0 + 250_000] = draw(min(250_000, n - r0))
+    q = draw(nq)
+    iters = a.recall_iters
+    pick = torch.randperm(n, generator=g, device=dev)
+    ivf_rows = x[pick[:min(n, 256 * nlist)].sort().values].contiguous()
+    init = ivf_rows[torch.randperm(ivf_rows.shape[0], generator=g, device=dev)[:nlist].sort().values].contiguous()
+    torch.cuda.synchronize()
+    t_tr = time.perf_counter()
+    cen, _ = lancedb_amd.kmeans_train(ivf_rows, init, iters=iters)
+    pq_rows = x[pick[:min(n, 256 * 256)].sort().values].contiguous()
+    torch.cuda.synchronize()
+    resid, _ = lancedb_amd.ivf_residuals(pq_rows, cen)
+    seeds = resid[torch.randperm(resid.shape[0], generator=g, device=dev)[:256].sort().values]
+    cb0 = seeds.reshape(256, m, dsub).permute(1, 0, 2).contiguous()
+    torch.cuda.synchronize()
+    codebook = lancedb_amd.pq_train(resid, cb0, iters=iters)
+    torch.cuda.synchronize()
+    t_tr = time.perf_counter() - t_tr
+    del ivf_rows, pq_rows, resid
+    part_offsets, codes, order = lancedb_amd.ivfpq_encode(x, cen, codebook)
+    xs = x[order].contiguous()
+    torch.cuda.synchronize()
+    ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes, order, raw_vectors=xs)
+    fl = lancedb_amd.FlatIndex(x.contiguous())
+    hq = q.cpu().numpy()
+    truth = fl.search(hq, k=1).rowids[:, 0]
+    del fl
+    ix.configure(profile=0, graph=False, coalesce=False)
+    chart = {"nprobes25_refine30": None, "nprobes50_refine30": None, "nprobes50_refine50": "0.977 @ 5.0 ms (the knee BASELINE.md quotes)"}
+    pts = []
+    for nprobe in (25, 50, 75, 100):
+        for rf in (30, 50):
+            for i in range(5):
+                ix.search(hq[i:i + 1], k=1, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+            lat, hit = [], 0
+            for i in range(nq):
+                t1 = time.perf_counter()
+                r = ix.search(hq[i:i + 1], k=1, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+                lat.append(time.perf_counter() - t1)
+                hit += int(r.counts[0] > 0 and r.rowids[0, 0] == truth[i])
+            lat = np.array(lat) * 1e3
+            pts.append({"nprobes": nprobe, "refine_factor": rf, "recall_at_1": hit / nq, "mean_latency_ms": float(lat.mean()),
+                        "p50_ms": float(np.median(lat)), "p99_ms": float(np.sort(lat)[int(nq * 0.99) - 1])})
+    st = ix.stats()
+    res = {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_refine_l2 (GIST1M-shaped, synthetic)", "n_rows": n, "dim": dim, "m": m,
+           "nlist": nlist, "queries": nq, "scan_variant": st["scan_variant"], "train_s": round(t_tr, 2),
+           "data": f"unit-scale vectors of intrinsic dimension {idim} (1000-cluster mixture through a random orthonormal map + 3 % noise); "
+                   "GIST1M itself is not in the container", "truth": "exact flat search (engine flat path), k = 1",
+           "points": pts, "reference_chart": {"source": "BASELINE.md section 1 (docs/src/assets/recall-vs-latency.webp)",
+                                              "values": chart, "note": "hardware of the chart is not stated: context only"}}
+    if a.cpu_seconds > 0:  # one operating point against the oracle, row for row
+        from oracle import oracle as orc
+        orc.build()
+        ox = orc.OracleIndex(cen.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
+                             order.cpu().numpy().astype(np.uint64), raw_vectors=xs.cpu().numpy())
+        sub = hq[:256]
+        got = ix.search(sub, k=1, nprobe_min=50, nprobe_max=50, refine_factor=30)
+        o_ids, o_d, _, _ = ox.search(sub, k=1, nprobe_min=50, nprobe_max=50, refine_factor=30)
+        res["nprobes50_refine30_vs_oracle_256_queries"] = {"rowids_bit_exact": bool((o_ids == got.rowids).all()),
+                                                           "distances_equal": bool((o_d == got.distances).all())}
+        ox.close()
+    ix.close()
+    res["seconds"] = round(time.perf_counter() - t0, 1)
+    return res
+
+
+# --------------------------------------------------------------------------------------- the summary ----
+def summary_of(result):
+    """A compact dict of the secondary scalars, placed LAST in the JSON line: the driver stores only the tail of it."""
+    sec = result.get("secondary", {})
+
+    def v(d, *path):
+        for p in path:
+            if not isinstance(d, dict) or p not in d:
+                return None
+            d = d[p]
+        return round(d, 4) if isinstance(d, float) else d
+    s = {"c3_qps": v(result, "value"), "c3_scan_frac": v(result, "roofline", "frac"), "c3_lds_gather_frac": v(result, "roofline", "lds_gather", "frac"),
+         "c3_parity_ids": v(result, "cpu_baseline", "parity", "rowids_bit_exact"),
+         "cpu_qps": v(result, "cpu_baseline", "value"), "cpu_cores": v(result, "cpu_baseline", "cores"),
+         "c4_qps": v(sec, "c4", "value"), "c4_scan_frac": v(sec, "c4", "roofline", "frac"), "c4_rows": v(sec, "c4", "config", "n_rows"),
+         "c4_coarse_frac_f32_mfma": v(sec, "c4", "coarse_nlist65536", "frac_of_f32_mfma_peak"),
+         "c4_parity_ids": v(sec, "c4", "cpu_baseline", "parity", "rowids_bit_exact"),
+         "c4_world8_equal": v(sec, "c4", "loopback_world8", "every_rank_equals_unsharded"),
+         "c4_world8_model_qps": v(sec, "c4", "loopback_world8", "step_model", "qps_overlapped"),
+         "c4_world8_frac_of_roofline": v(sec, "c4", "loopback_world8", "step_model", "frac_of_aggregate_roofline"),
+         "c3_world8_equal": v(sec, "loopback_world8", "overlapped", "every_rank_equals_unsharded"),
+         "c3_world8_model_qps": v(sec, "loopback_world8", "step_model", "qps_overlapped"),
+         "refine10_qps": v(sec, "c3_refine10", "value"), "refine25_qps": v(sec, "c3_refine25", "value"),
+         "c5_qps": v(sec, "c5_refine10", "value"), "c5_rows": v(sec, "c5_refine10", "config", "n_rows"),
+         "c5_parity_ids": v(sec, "c5_refine10", "cpu_baseline", "parity", "rowids_bit_exact"),
+         "flat_l2_qps": v(sec, "flat_c2_l2", "value"), "flat_l2_gemm_frac": v(sec, "flat_c2_l2", "roofline", "frac"),
+         "flat_l2_parity_ids": v(sec, "flat_c2_l2", "cpu_baseline", "parity", "rowids_bit_exact"),
+         "flat_cos_qps": v(sec, "flat_c2_cosine", "value"), "flat_cos_gemm_frac": v(sec, "flat_c2_cosine", "roofline", "frac"),
+         "lat_p50_us": v(sec, "latency_c3", "single_query_us_eager", "p50"), "lat_p99_us": v(sec, "latency_c3", "single_query_us_eager", "p99"),
+         "qps_64_threads": v(sec, "latency_c3", "qps_64_threads_coalesced"),
+         "recall10": v(result, "recall_at_10", "nprobe64"), "recall10_rf25": v(result, "recall_at_10", "nprobe64_refine25")}
+    for key, line in sec.items():
+        if key.startswith("c3_shape_"):
+            s[key + "_qps"] = v(line, "value")
+            s[key + "_frac"] = v(line, "roofline", "frac")
+    if "qps_vs_batch" in sec:
+        s["qps_vs_batch"] = {str(p["batch"]): round(p["queries_per_s"]) for p in sec["qps_vs_batch"]}
+    if "gist_like" in sec and "points" in sec["gist_like"]:
+        s["gist_like"] = {f"np{p['nprobes']}_rf{p['refine_factor']}": [round(p["recall_at_1"], 3), round(p["mean_latency_ms"], 3)]
+                          for p in sec["gist_like"]["points"]}
+    return s

@@ -174,7 +174,11 @@ typedef struct mi355_search_params {
   float upper_bound;      /* exclusive */
   uint32_t io_mem;        /* MI355_MEM_*: where queries / outputs live.  DEVICE
                              = enqueue on the handle's stream and return
-                             without waiting (see mi355_*_set_stream) */
+                             without waiting (see mi355_*_set_stream): the results
+                             are ordered on that stream — except in the two opt-in
+                             overlap modes, whose results are complete at
+                             mi355_index_sync (MI355_CFG_DEFER_REFINE for mi355_search,
+                             the default overlap of mi355_search_sharded) */
   uint32_t timeout_ms;    /* 0 = none (QueryExecutionOptions.timeout, query.rs:641).  A device-side
                              deadline: the scan kernels stop taking work items once it has passed and
                              every later kernel of the call exits at once; host-I/O calls then return
@@ -241,7 +245,10 @@ enum {
                             [sub-quantiser][code] table, any m */
   MI355_SCAN_SKEW = 2    /* production: pre-skewed code streams + [code][column]
                             table (bank-conflict-free gathers), partition-major
-                            work queues per XCD; 8-bit codes, m in {32,48,64,80,96} */
+                            work queues per XCD; 8-bit codes, any m up to 768: a table
+                            holds 32 / 48 / 64 / 80 / 96 columns, other m <= 96 are
+                            padded with zero columns, larger m are scanned in slabs
+                            of <= 96 columns (the row sum stays j-ascending) */
 };
 
 /* mi355_index_configure `profile` bits above the low byte */
@@ -252,7 +259,15 @@ enum {
   MI355_CFG_GRAPH = 0x100u,
   /* serve concurrent host-I/O mi355_search calls whose parameters agree from ONE device
      batch (leader / follower hand-off inside the handle, no extra thread) */
-  MI355_CFG_COALESCE = 0x200u
+  MI355_CFG_COALESCE = 0x200u,
+  /* opt-in: a device-I/O mi355_search with refine_factor over a HOST-resident raw column (mapped or
+     attached) leaves its exact re-rank and final merge on a private stream of the handle, so that the
+     NEXT call's scan overlaps the PCIe gather.  Contract of such a call: its outputs are NOT ordered
+     on the handle's stream — they are complete after mi355_index_sync (or any other entry point of the
+     handle, which all join the pending re-rank first); the caller keeps the query and output buffers
+     untouched until then.  Off after open: without it every device-I/O result is ordered on the
+     handle's stream. */
+  MI355_CFG_DEFER_REFINE = 0x400u
 };
 
 /* ---- library ------------------------------------------------------------ */
@@ -277,7 +292,7 @@ int32_t mi355_index_sync(mi355_index *index);
    times of the LAST search, 2 = counters and times ACCUMULATE over searches
    until the next configure().  Times come from hipEvents recorded on the search
    stream with no host synchronisation; they are read back by mi355_last_stats.
-   Higher bits: MI355_CFG_GRAPH / MI355_CFG_COALESCE (latency / concurrency modes,
+   Higher bits: MI355_CFG_DEFER_REFINE (above), MI355_CFG_GRAPH / MI355_CFG_COALESCE (latency / concurrency modes,
    host-I/O calls only; after mi355_index_open coalescing is ON and graph replay is OFF —
    replay measured slower than eager launches; a configure() call sets
    both as given).  A configure() call also drops the handle's captured graphs. */

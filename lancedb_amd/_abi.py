@@ -50,6 +50,7 @@ INDEX_LOCAL_ARRAYS = 4
 PROFILE_MASK = 0xFF
 CFG_GRAPH = 0x100
 CFG_COALESCE = 0x200
+CFG_DEFER_REFINE = 0x400
 
 FLAT_GEMM_AUTO = 0
 FLAT_GEMM_128 = 1

@@ -158,7 +158,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
                     &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt,
-                    &ix->w_partial};
+                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -197,7 +197,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   const uint32_t nlist = d->nlist, m = d->m, mb = ix->mb, cb_entries = 1u << d->nbits;
   for (DevBuf* b : {&ix->w_q, &ix->w_qp, &ix->w_qq, &ix->w_coarse, &ix->w_probes, &ix->w_cand, &ix->w_ids, &ix->w_dist,
                     &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr, &ix->w_ccnt,
-                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial})
+                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial, &ix->w_cand2b, &ix->w_cnt2b})
     b->gen = &ix->ws_gen;  // a re-allocation of any of these invalidates the cached hipGraphs
 
   // -- ownership + local layout
@@ -512,7 +512,8 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
                                          uint32_t slice_rows, uint32_t profile) {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   if (scan_variant > MI355_SCAN_SKEW) return fail(MI355_ERR_INVALID_INPUT, "unknown scan variant");
-  if ((profile & MI355_PROFILE_MASK) > 2 || (profile & ~(uint32_t)(MI355_PROFILE_MASK | MI355_CFG_GRAPH | MI355_CFG_COALESCE)))
+  if ((profile & MI355_PROFILE_MASK) > 2 ||
+      (profile & ~(uint32_t)(MI355_PROFILE_MASK | MI355_CFG_GRAPH | MI355_CFG_COALESCE | MI355_CFG_DEFER_REFINE)))
     return fail(MI355_ERR_INVALID_INPUT, "unknown profile / mode bits 0x%x", profile);
   if (scan_variant != MI355_SCAN_AUTO && scan_variant != ix->layout)
     return fail(MI355_ERR_INVALID_INPUT,
@@ -524,6 +525,7 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   ix->profile = profile & MI355_PROFILE_MASK;
   ix->use_graph = (profile & MI355_CFG_GRAPH) != 0;
   ix->coalesce = (profile & MI355_CFG_COALESCE) != 0;
+  ix->defer_cfg = (profile & MI355_CFG_DEFER_REFINE) != 0;
   ++ix->ws_gen;  // captured graphs bake in the slicing
   HIP_TRY(hipSetDevice(ix->device));
   ST_TRY(join_exchange(ix));
@@ -772,8 +774,10 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   // (refine: the ANN list and the exact list of a chunk; two sets when the refine of one call overlaps the next call's scan)
   const bool defer = pl.defer_refine && pl.refine && !pl.out_cand && chunk >= nq;
   if (pl.defer_refine && !defer) ST_TRY(join_exchange(ix));  // (a batch that needs several chunks keeps the serial path)
-  if (pl.refine && !pl.out_cand) ST_TRY(ix->w_cand2.ensure(sizeof(Cand) * (size_t)chunk * pl.kk * 2 * (defer ? 2 : 1)));
-  uint32_t rset = 0;
+  // (each of the two sets has its own allocation: a set's layout depends on the shape of the call that uses it, and
+  //  the other set may still be read by the re-rank of the call before — ADVICE round 3)
+  const uint32_t rset = pl.rset & 1u;
+  DevBuf& cand2 = rset ? ix->w_cand2b : ix->w_cand2;
   if (defer) {
     if (!ix->rstream) {
       HIP_TRY(hipStreamCreateWithFlags(&ix->rstream, hipStreamNonBlocking));
@@ -782,8 +786,12 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
         HIP_TRY(hipEventCreateWithFlags(&ix->r_done[i], hipEventDisableTiming));
       }
     }
-    rset = (uint32_t)(ix->r_seq++ & 1u);
     if (ix->r_busy[rset]) HIP_TRY(hipStreamWaitEvent(st, ix->r_done[rset], 0));  // the refine two calls back: this set is free again
+  }
+  if (pl.refine && !pl.out_cand) {
+    if (cand2.cap < sizeof(Cand) * (size_t)chunk * pl.kk * 2 && ix->r_busy[rset])
+      HIP_TRY(hipEventSynchronize(ix->r_done[rset]));  // the set grows: its last user must be done before it is freed
+    ST_TRY(cand2.ensure(sizeof(Cand) * (size_t)chunk * pl.kk * 2));
   }
   DevCtl* d_ctl = ix->w_ctl.as<DevCtl>();
   unsigned long long* d_stat = &d_ctl->rows_scanned;
@@ -1002,7 +1010,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       if (prof) HIP_TRY(hipEventRecord(es.ev[4], st));
     } else {
       // refine (query.rs:1313-1317): the kk ANN winners -> exact distances -> (distance, rowid) top k
-      Cand* ann = ix->w_cand2.as<Cand>() + (size_t)rset * chunk * pl.kk * 2;
+      Cand* ann = cand2.as<Cand>();
       Cand* exact = ann + (size_t)chunk * pl.kk;
       ma.k_out = pl.kk;
       ma.out_cand = ann;
@@ -1241,7 +1249,7 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   // untouched until then, as for any device-I/O call): the NEXT call's scan starts at once.  With a host-mapped raw
   // column (C5) the re-rank is a PCIe gather, the scan an LDS / VALU loop: the two overlap almost entirely.
   const bool defer = !host_io && p->refine_factor != 0 && p->timeout_ms == 0 && sh.np_max == sh.np_min && !ext_probes &&
-                     (ix->profile & MI355_PROFILE_MASK) != 1 && calls.size() == 1 && ix->raw_is_host;
+                     (ix->profile & MI355_PROFILE_MASK) != 1 && calls.size() == 1 && ix->raw_is_host && ix->defer_cfg;
   if (!defer) ST_TRY(join_exchange(ix));
   hipStream_t st = ix->stream;
   auto t_start = std::chrono::steady_clock::now();
@@ -1327,9 +1335,12 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   }
   uint32_t* d_cnt_ann = d_cnt;
   if (pl.refine) {
-    ST_TRY(ix->w_cnt2.ensure(sizeof(uint32_t) * n_queries * 2));
-    d_cnt_ann = ix->w_cnt2.as<uint32_t>() + (defer ? (size_t)(ix->r_seq & 1u) * n_queries : 0);  // (the set run_ivfpq takes next)
     pl.defer_refine = defer;
+    pl.rset = defer ? (uint32_t)(ix->r_seq++ & 1u) : 0u;  // deferred calls alternate between two buffer sets
+    DevBuf& cnt2 = pl.rset ? ix->w_cnt2b : ix->w_cnt2;
+    if (cnt2.cap < sizeof(uint32_t) * n_queries && ix->r_busy[pl.rset]) HIP_TRY(hipEventSynchronize(ix->r_done[pl.rset]));
+    ST_TRY(cnt2.ensure(sizeof(uint32_t) * n_queries));
+    d_cnt_ann = cnt2.as<uint32_t>();
   }
   // latency mode: small host batches without profiling / prefilter / external probes replay a graph
   const bool graphable = ix->use_graph && host_io && n_queries <= 64 && (ix->profile & MI355_PROFILE_MASK) == 0 &&

@@ -196,6 +196,8 @@ struct mi355_index {
   // SkewShape of the packed codes (MI355_SCAN_SKEW): columns per slab, slabs per row, generalised kernel or not
   uint32_t sk_M = 0, sk_slabs = 1, sk_slabbed = 0, sk_res_floats = 0;
   DevBuf w_partial;  // per-workgroup partial row sums between the slabs of a work item (sk_slabs > 1)
+  DevBuf w_cand2b, w_cnt2b;  // the second buffer set of the deferred refine (each set has its own allocations)
+  bool defer_cfg = false;    // MI355_CFG_DEFER_REFINE
   // workspace
   DevBuf w_q, w_qp, w_qq, w_coarse, w_probes, w_cand, w_ids, w_dist, w_pos, w_cnt, w_ids2, w_dist2, w_cnt2, w_ctl,
       w_cand2, w_sq, w_sids, w_sdist, w_scnt, w_scnt_ann, w_spill, w_srows, w_ccnt;
@@ -270,6 +272,7 @@ struct SearchPlan {
   ActiveMask act;      // device-side batch size: the maximum_nprobes second pass (slots past *act.n are skipped)
   uint32_t ws_mb = 0;  // workspace budget of this pass in MiB (0 = the default)
   bool defer_refine = false;  // run refine + final merge on the handle's refine stream (results complete at mi355_index_sync)
+  uint32_t rset = 0;          // which of the two refine buffer sets this call uses (deferred calls alternate)
 };
 int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl, uint64_t* d_ids,
                   float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann);

@@ -485,14 +485,24 @@ def execute_query(table, req: VectorQueryRequest, options: QueryExecutionOptions
         from . import wire
         t0 = time.monotonic()  # the deadline covers the round trip (the client's request timeout, remote/table.rs:697)
         body = wire.request_to_json(req)
+        # whether the endpoint takes a timeout is read from its signature — NOT by catching TypeError around the
+        # call, which would also swallow a TypeError raised inside the endpoint and run the request twice
+        import inspect
         try:
-            data = pushdown(body, timeout=options.timeout)
-        except TypeError:  # an endpoint without a timeout parameter
-            data = pushdown(body)
+            prm = inspect.signature(pushdown).parameters
+            takes_timeout = "timeout" in prm or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in prm.values())
+        except (TypeError, ValueError):
+            takes_timeout = False
+        data = pushdown(body, timeout=options.timeout) if takes_timeout else pushdown(body)
         cols = wire.response_from_ipc(data)
-        # the server already applied columns / order_by (they travel in the body); a server that predates
-        # them returns everything in (_distance, _rowid) order, so apply them here as well (idempotent)
-        cols = _order_and_project(cols, req)
+        # the server already applied columns / order_by (they travel in the body); a server that predates them returns
+        # everything in (_distance, _rowid) order, so apply them here as well — but only what the response still
+        # allows: a sort key the server already projected away means the server sorted before projecting
+        if req.order_by and all(col in cols for col, _ in req.order_by):
+            cols = _order_by(cols, req.order_by)
+        if req.select is not None:
+            import dataclasses
+            cols = _order_and_project(cols, dataclasses.replace(req, order_by=None))
         return _batches(cols, options, t0)
     return execute_generic_query(table, req, options)
 

@@ -61,6 +61,9 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#ifdef __AVX2__
+#include <immintrin.h>
+#endif
 
 typedef struct orc_index {
   uint32_t dim, nlist, m, ksub, dsub, metric;
@@ -347,6 +350,63 @@ void orc_coarse(const orc_index *ix, const float *q, float *out /*[nlist]*/) {
   }
 }
 
+/* The same coarse distances, eight centroids at a time: lane l of a 256-bit register carries centroid p + l's own
+   d-ascending fmaf chain (the rows of an 8 x 8 block are transposed in registers, then eight vfmadd231ps with q[d]
+   broadcast), so every lane computes exactly orc_chain_dot's sequence of roundings — bit-identical to orc_coarse
+   (tests/test_oracle_golden.py compares the two with ==).  This is the "optimised path" SURVEY.md section 8d asks the
+   CPU baseline to time; orc_coarse stays the reference the tests read. */
+void orc_coarse_fast(const orc_index *ix, const float *q, float *out /*[nlist]*/) {
+#ifdef __AVX2__
+  const uint32_t dim = ix->dim, d8 = dim & ~7u;
+  float qq = orc_chain_dot(q, q, dim);
+  uint32_t p = 0;
+  for (; p + 8 <= ix->nlist; p += 8) {
+    const float *c = ix->centroids + (size_t)p * dim;
+    __m256 acc = _mm256_setzero_ps();
+    for (uint32_t d = 0; d < d8; d += 8) {
+      __m256 r0 = _mm256_loadu_ps(c + 0 * (size_t)dim + d), r1 = _mm256_loadu_ps(c + 1 * (size_t)dim + d);
+      __m256 r2 = _mm256_loadu_ps(c + 2 * (size_t)dim + d), r3 = _mm256_loadu_ps(c + 3 * (size_t)dim + d);
+      __m256 r4 = _mm256_loadu_ps(c + 4 * (size_t)dim + d), r5 = _mm256_loadu_ps(c + 5 * (size_t)dim + d);
+      __m256 r6 = _mm256_loadu_ps(c + 6 * (size_t)dim + d), r7 = _mm256_loadu_ps(c + 7 * (size_t)dim + d);
+      /* 8 x 8 transpose: t[k] lane l = centroid p + l, element d + k */
+      __m256 a0 = _mm256_unpacklo_ps(r0, r1), a1 = _mm256_unpackhi_ps(r0, r1);
+      __m256 a2 = _mm256_unpacklo_ps(r2, r3), a3 = _mm256_unpackhi_ps(r2, r3);
+      __m256 a4 = _mm256_unpacklo_ps(r4, r5), a5 = _mm256_unpackhi_ps(r4, r5);
+      __m256 a6 = _mm256_unpacklo_ps(r6, r7), a7 = _mm256_unpackhi_ps(r6, r7);
+      __m256 b0 = _mm256_shuffle_ps(a0, a2, 0x44), b1 = _mm256_shuffle_ps(a0, a2, 0xEE);
+      __m256 b2 = _mm256_shuffle_ps(a1, a3, 0x44), b3 = _mm256_shuffle_ps(a1, a3, 0xEE);
+      __m256 b4 = _mm256_shuffle_ps(a4, a6, 0x44), b5 = _mm256_shuffle_ps(a4, a6, 0xEE);
+      __m256 b6 = _mm256_shuffle_ps(a5, a7, 0x44), b7 = _mm256_shuffle_ps(a5, a7, 0xEE);
+      __m256 t0 = _mm256_permute2f128_ps(b0, b4, 0x20), t1 = _mm256_permute2f128_ps(b1, b5, 0x20);
+      __m256 t2 = _mm256_permute2f128_ps(b2, b6, 0x20), t3 = _mm256_permute2f128_ps(b3, b7, 0x20);
+      __m256 t4 = _mm256_permute2f128_ps(b0, b4, 0x31), t5 = _mm256_permute2f128_ps(b1, b5, 0x31);
+      __m256 t6 = _mm256_permute2f128_ps(b2, b6, 0x31), t7 = _mm256_permute2f128_ps(b3, b7, 0x31);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 0]), t0, acc);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 1]), t1, acc);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 2]), t2, acc);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 3]), t3, acc);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 4]), t4, acc);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 5]), t5, acc);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 6]), t6, acc);
+      acc = _mm256_fmadd_ps(_mm256_set1_ps(q[d + 7]), t7, acc);
+    }
+    float qc[8];
+    _mm256_storeu_ps(qc, acc);
+    for (uint32_t l = 0; l < 8; ++l) {
+      float a = qc[l];
+      for (uint32_t d = d8; d < dim; ++d) a = fmaf(q[d], c[(size_t)l * dim + d], a);  /* the chain's last dim % 8 steps */
+      out[p + l] = ix->metric == MI355_METRIC_DOT ? 1.0f - a : fmaf(-2.0f, a, qq + ix->cnorm[p + l]);
+    }
+  }
+  for (; p < ix->nlist; ++p) {
+    float a = orc_chain_dot(q, ix->centroids + (size_t)p * dim, dim);
+    out[p] = ix->metric == MI355_METRIC_DOT ? 1.0f - a : fmaf(-2.0f, a, qq + ix->cnorm[p]);
+  }
+#else
+  orc_coarse(ix, q, out);
+#endif
+}
+
 /* the nprobe smallest partitions by (distance, id); out sorted that way.
    NaN coarse distances sort last. */
 void orc_select_probes(const float *dist, uint32_t nlist, uint32_t nprobe,
@@ -395,7 +455,26 @@ void orc_adc_partition(const orc_index *ix, const float *lut, uint32_t part,
   const uint8_t *codes = ix->codes_t + (size_t)o * ix->mb;
   for (uint64_t i = 0; i < len; ++i) out[i] = 0.0f;
   if (ix->nbits == 8) {
-    for (uint32_t j = 0; j < ix->m; ++j) {
+    /* eight sub-quantisers per sweep of out[]: each row still adds its table values one by one in j order (the same
+       roundings as one sweep per j), with an eighth of the out[] traffic */
+    uint32_t j = 0;
+    for (; j + 8 <= ix->m; j += 8) {
+      const float *t = lut + (size_t)j * 256;
+      const uint8_t *r0 = codes + (size_t)j * len;
+      for (uint64_t i = 0; i < len; ++i) {
+        float acc = out[i];
+        acc = acc + t[0 * 256 + r0[0 * len + i]];
+        acc = acc + t[1 * 256 + r0[1 * len + i]];
+        acc = acc + t[2 * 256 + r0[2 * len + i]];
+        acc = acc + t[3 * 256 + r0[3 * len + i]];
+        acc = acc + t[4 * 256 + r0[4 * len + i]];
+        acc = acc + t[5 * 256 + r0[5 * len + i]];
+        acc = acc + t[6 * 256 + r0[6 * len + i]];
+        acc = acc + t[7 * 256 + r0[7 * len + i]];
+        out[i] = acc;
+      }
+    }
+    for (; j < ix->m; ++j) {
       const float *t = lut + j * 256;
       const uint8_t *row = codes + (size_t)j * len;
       for (uint64_t i = 0; i < len; ++i) out[i] = out[i] + t[row[i]];
@@ -420,23 +499,42 @@ static void preprocess_query(const orc_index *ix, const float *q, float *qp) {
   }
 }
 
+/* CPU seconds per stage, summed over the threads of the last orc_search call: coarse, probe select, LUT build, ADC,
+   top-k heap, refine (orc_last_stage_seconds).  What bench.py prints beside the CPU baseline. */
+#define ORC_N_STAGES 6
+static double g_stage_seconds[ORC_N_STAGES];
+static inline double orc_now(void) {
+#ifdef _OPENMP
+  return omp_get_wtime();
+#else
+  return 0.0;
+#endif
+}
+void orc_last_stage_seconds(double *out /*[6]*/) { memcpy(out, g_stage_seconds, sizeof g_stage_seconds); }
+
 /* one query over `nprobe` partitions -> heap of up to kk approximate hits */
 static void search_one(const orc_index *ix, const float *q,
                        const mi355_search_params *prm, uint32_t nprobe,
                        uint32_t kk, heap_t *hp, float *scratch_lut,
                        float *scratch_dist, uint32_t *probes, float *coarse,
-                       float *qp, uint64_t *n_scanned) {
+                       float *qp, uint64_t *n_scanned, double *stage /*[ORC_N_STAGES]*/) {
+  double t0 = orc_now(), t1;
   preprocess_query(ix, q, qp);
-  orc_coarse(ix, qp, coarse);
+  orc_coarse_fast(ix, qp, coarse);
+  t1 = orc_now(); stage[0] += t1 - t0; t0 = t1;
   orc_select_probes(coarse, ix->nlist, nprobe, probes);
+  t1 = orc_now(); stage[1] += t1 - t0; t0 = t1;
   hp->n = 0;
   hp->cap = kk;
   for (uint32_t pi = 0; pi < nprobe; ++pi) {
     uint32_t p = probes[pi];
     uint64_t o = ix->part_off[p], len = ix->part_off[p + 1] - o;
     if (len == 0) continue;
+    t0 = orc_now();
     orc_build_lut(ix, qp, p, scratch_lut);
+    t1 = orc_now(); stage[2] += t1 - t0; t0 = t1;
     orc_adc_partition(ix, scratch_lut, p, scratch_dist);
+    t1 = orc_now(); stage[3] += t1 - t0; t0 = t1;
     if (n_scanned) *n_scanned += len;
     for (uint64_t i = 0; i < len; ++i) {
       float d = scratch_dist[i];
@@ -445,6 +543,7 @@ static void search_one(const orc_index *ix, const float *q,
       cand_t c = {d, ix->row_ids[o + i], o + i};
       heap_push(hp, c);
     }
+    stage[4] += orc_now() - t0;
   }
 }
 
@@ -497,8 +596,10 @@ int32_t orc_search(const orc_index *ix, const float *queries, uint32_t n_queries
 #else
   nthreads = 1;
 #endif
+  memset(g_stage_seconds, 0, sizeof g_stage_seconds);
 #pragma omp parallel num_threads(nthreads) reduction(+ : total_scanned)
   {
+    double stage[ORC_N_STAGES] = {0, 0, 0, 0, 0, 0};
     float *lut = (float *)malloc(sizeof(float) * ix->m * ix->ksub);
     float *dist = (float *)malloc(sizeof(float) * mpl);
     float *coarse = (float *)malloc(sizeof(float) * ix->nlist);
@@ -512,18 +613,19 @@ int32_t orc_search(const orc_index *ix, const float *queries, uint32_t n_queries
       const float *q = queries + (size_t)qi * ix->dim;
       uint64_t scanned = 0;
       search_one(ix, q, prm, np_min, kk, &hp, lut, dist, probes, coarse, qp,
-                 &scanned);
+                 &scanned, stage);
       /* maximum_nprobes (query.rs:1246-1262): the excess partitions are
          searched only if the first pass found fewer than k rows */
       if (hp.n < kk && np_max > np_min) {
         scanned = 0;
         search_one(ix, q, prm, np_max, kk, &hp, lut, dist, probes, coarse, qp,
-                   &scanned);
+                   &scanned, stage);
       }
       total_scanned += scanned;
       if (prm->refine_factor) {
         /* E9: exact distance on the raw vectors of the kk candidates, range
            filter on the exact distance, re-sort */
+        double tr = orc_now();
         uint32_t w = 0;
         for (uint32_t i = 0; i < hp.n; ++i) {
           load_row(ix->raw, ix->raw_dtype, hp.h[i].pos, ix->dim, rawrow);
@@ -534,6 +636,7 @@ int32_t orc_search(const orc_index *ix, const float *queries, uint32_t n_queries
           ++w;
         }
         hp.n = w;
+        stage[5] += orc_now() - tr;
       }
       qsort(hp.h, hp.n, sizeof(cand_t), cand_cmp_qsort);
       uint32_t cnt = hp.n < k ? hp.n : k;
@@ -550,6 +653,8 @@ int32_t orc_search(const orc_index *ix, const float *queries, uint32_t n_queries
     free(qp);
     free(rawrow);
     free(hp.h);
+#pragma omp critical
+    for (int s2 = 0; s2 < ORC_N_STAGES; ++s2) g_stage_seconds[s2] += stage[s2];
   }
   if (out_vectors_scanned) *out_vectors_scanned = total_scanned;
   return MI355_OK;

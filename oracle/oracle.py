@@ -112,6 +112,9 @@ class OracleIndex:
         st = lib().orc_search(self._h, _ptr(q), C.c_uint32(nq), C.byref(p), _ptr(ids),
                               _ptr(dist), _ptr(cnt), C.c_int32(nthreads), C.byref(scanned))
         self.last_vectors_scanned = scanned.value
+        sec = (C.c_double * 6)()
+        lib().orc_last_stage_seconds(sec)  # CPU seconds summed over the threads (not safe across concurrent searches)
+        self.last_stage_seconds = dict(zip(("coarse", "select", "lut", "adc", "heap", "refine"), (float(x) for x in sec)))
         return ids, dist, cnt, st
 
     # stage-wise entry points for kernel-level parity tests ------------------
@@ -126,6 +129,13 @@ class OracleIndex:
         q = self.preprocess(q)
         out = np.empty(self.nlist, dtype=np.float32)
         lib().orc_coarse(self._h, _ptr(q), _ptr(out))
+        return out
+
+    def coarse_fast(self, q):
+        """The AVX2 form the search uses (eight centroids per register, one chain per lane): must equal coarse() bit for bit."""
+        q = self.preprocess(q)
+        out = np.empty(self.nlist, dtype=np.float32)
+        lib().orc_coarse_fast(self._h, _ptr(q), _ptr(out))
         return out
 
     def select_probes(self, coarse, nprobe):

@@ -3,12 +3,16 @@ rust/lancedb/src/index/vector.rs:61-119, :306-319) on a CPU-only box: the three 
 entry points are stood in for by the CPU oracle (test infrastructure; the GPU runs of the
 same builder are in tests/test_gpu_train.py), so what is under test is the sampling, the
 seeding, the shapes handed to the C ABI and the quality of the resulting index."""
+import os
+
 import numpy as np
 import pytest
 
 import lancedb_amd
 from lancedb_amd import _abi
 from lancedb_amd import build as build_mod
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture()
@@ -156,3 +160,20 @@ def test_weighted_shard_plan_balances_the_rows_that_are_scanned():
     assert imbalance(weighted) < 1.01 < imbalance(plain)
     rows = np.array([lens[weighted == r].sum() for r in range(shards)])
     assert rows.max() / rows.mean() < 1.25  # rows held stay reasonable too
+
+
+def test_no_compiler_copy_of_a_register_with_a_load_in_flight():
+    """The multi-slab scan hands partial row sums from slab to slab through a register that inline asm loads one tile
+    ahead (csrc/kernels_skew.h, SLABBED): hipcc must never copy that register between the load and the counted wait
+    (round 4 saw exactly that: a v_mov of the in-flight register, then its late-landing data overwrote an address).
+    scripts/check_inflight_regs.py compiles the translation unit to assembly and checks every instantiation."""
+    import shutil
+    import subprocess
+    import sys
+    from lancedb_amd import _lib
+    if shutil.which(_lib._hipcc()) is None and not os.path.exists(_lib._hipcc()):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_inflight_regs.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "0 copies of a register in flight" in r.stdout

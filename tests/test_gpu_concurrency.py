@@ -176,6 +176,7 @@ def test_deferred_refine_overlaps_the_next_call_and_stays_exact(oracle):
     for host_mapped in (False, True):
         ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw,
                                     raw_host_mapped=host_mapped)
+        ix.configure(defer_refine=True)  # opt-in (MI355_CFG_DEFER_REFINE): only the host-mapped column actually defers
         qs = [rng.normal(size=(40, dim)).astype(np.float32) for _ in range(6)]
         dq = [DA.from_numpy(q) for q in qs]
         outs = [(DA((40, 10), np.int64), DA((40, 10), np.float32), DA((40,), np.int32)) for _ in qs]
@@ -192,3 +193,39 @@ def test_deferred_refine_overlaps_the_next_call_and_stays_exact(oracle):
         assert ix.stats()["n_queries"] >= 40
         ix.sync()
         assert (r.rowids.numpy().view(np.uint64) == o.search(qs[0], k=10, nprobe_min=12, nprobe_max=12, refine_factor=8)[0]).all()
+
+
+def test_deferred_refine_with_changing_batch_sizes_and_refine_factors(oracle):
+    """back-to-back deferred calls of DIFFERENT shapes.  The two buffer sets used to be carved
+    out of one allocation at offsets that depended on the current call's shape, so a smaller call's ANN list landed in
+    the range the previous call's re-rank was still reading.  Each set now has its own allocation; no sync in between."""
+    rng = np.random.default_rng(3)
+    n, dim, m = 90000, 128, 32
+    s = train.synthetic_index(n, dim, 32, m, seed=8, skew=0.7)
+    raw = rng.normal(size=(n, dim)).astype(np.float32)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
+    DA = lancedb_amd.DeviceArray
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw,
+                                raw_host_mapped=True)
+    ix.configure(defer_refine=True)
+    shapes = [(100, 10, 8), (50, 10, 8), (7, 10, 30), (120, 5, 3), (1, 10, 50), (64, 20, 8), (100, 10, 8), (3, 1, 100)]
+    for rounds in range(2):
+        calls = []
+        for nq, k, rf in shapes:
+            q = rng.normal(size=(nq, dim)).astype(np.float32)
+            out = (DA((nq, k), np.int64), DA((nq, k), np.float32), DA((nq,), np.int32))
+            p = _abi.make_params(k=k, nprobe_min=10, nprobe_max=10, refine_factor=rf)
+            calls.append((q, DA.from_numpy(q), out, p, k, rf))
+        res = [ix.search(c[1], c[3], out=c[2]) for c in calls]  # no sync in between
+        ix.sync()
+        for (q, _, _, _, k, rf), r in zip(calls, res):
+            ids, dist, cnt, _ = o.search(q, k=k, nprobe_min=10, nprobe_max=10, refine_factor=rf)
+            assert (r.counts.numpy() == cnt).all() and (r.rowids.numpy().view(np.uint64) == ids).all() and (r.distances.numpy() == dist).all()
+    # without the opt-in the results of a device-I/O call are ordered on the handle's stream: a plain stream sync suffices
+    ix.configure(defer_refine=False)
+    q, dq, out, p, k, rf = calls[0]
+    r = ix.search(dq, p, out=out)
+    from lancedb_amd import _hip
+    _hip.runtime().hipDeviceSynchronize()
+    ids, dist, cnt, _ = o.search(q, k=k, nprobe_min=10, nprobe_max=10, refine_factor=rf)
+    assert (r.rowids.numpy().view(np.uint64) == ids).all()

@@ -333,3 +333,23 @@ def test_kmeans_restatement_against_numpy_lloyd(oracle, metric):
     np.testing.assert_allclose(got, c, rtol=2e-4, atol=2e-5)
     r, a2 = oracle.ivf_residuals(x, got, metric)
     np.testing.assert_allclose(r, xs - got.astype(np.float64)[a2], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+@pytest.mark.parametrize("dim,nlist", [(768, 4096), (20, 13), (8, 8), (33, 70), (7, 3), (960, 122)])
+def test_vectorised_coarse_is_the_scalar_chain_bit_for_bit(oracle, metric, dim, nlist):
+    """orc_coarse_fast (AVX2: eight centroids per register, one d-ascending fmaf chain per lane — what orc_search and the
+    bench's CPU baseline run) against orc_coarse (the scalar chain the contract is written in)."""
+    from oracle import train
+    rng = np.random.default_rng(dim * 31 + nlist)
+    m = 1
+    s = train.synthetic_index(200, dim, nlist, m, seed=dim)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
+    for _ in range(4):
+        q = (rng.normal(size=dim) * rng.choice([1e-3, 1.0, 1e3])).astype(np.float32)
+        a, b = o.coarse(q), o.coarse_fast(q)
+        assert a.tobytes() == b.tobytes()
+    q = rng.normal(size=dim).astype(np.float32)
+    q[dim // 2] = np.nan
+    a, b = o.coarse(q), o.coarse_fast(q)
+    assert np.isnan(a).all() and np.isnan(b).all()

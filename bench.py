@@ -208,7 +208,9 @@ def main():
     out = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
            torch.empty((B,), dtype=torch.int32, device=dev))
     stream = torch.cuda.current_stream().cuda_stream
-    ix.set_stream(stream)  # engine kernels, RCCL and torch share one ordered stream
+    # (torch's current stream is normally the null stream, handle 0 = "keep the handle's own stream": the fences below are
+    #  device-wide synchronisations, so the timed region is bracketed either way)
+    ix.set_stream(stream)
     ix.configure(scan_variant=a.scan_variant, slice_rows=a.slice_rows, profile=0)
     comm = searcher = None
     if sharded:
@@ -344,6 +346,8 @@ def main():
             del codes, row_ids
             torch.cuda.empty_cache()
         result["secondary"]["latency_c3"] = latency_and_concurrency(a, np, ix, qpool)
+        result["secondary"]["concurrent_callers_c3"] = legs.concurrent_callers(
+            np, ix, qpool[0].cpu().numpy(), _abi.make_params(k=a.k, nprobe_min=a.nprobe, nprobe_max=a.nprobe), a.k)
         result["secondary"]["qps_vs_batch"] = legs.qps_vs_batch(a, torch, np, ix, centroids, dev)
         ix.set_stream(stream)
         result["secondary"].update(refine_operating_point(a, torch, ix, qpool, rows_local, dim, dev))

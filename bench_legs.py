@@ -224,6 +224,7 @@ def c4_leg(a, torch, np, dev, n_rows=1_000_000_000, world=8, parity_queries=64):
         nq = min(parity_queries, B)
         q_dev = qpool[(steps - 1) % P][:nq].contiguous()
         pr, _, _ = ix.coarse_topn(q_dev, nprobe)
+        ix.sync()  # (the handle runs on its own stream when torch's current stream is the null stream: nothing else orders this read)
         parts = np.unique(pr.cpu().numpy().astype(np.int64).reshape(-1))
         parts = parts[(parts >= 0) & (parts < nlist)]
         t1 = time.perf_counter()
@@ -257,9 +258,11 @@ def c4_leg(a, torch, np, dev, n_rows=1_000_000_000, world=8, parity_queries=64):
         gc.manual_seed(SEED + 99)
         qc = s["centroids"][torch.randint(0, nlist, (2048,), generator=gc, device=dev)] + 0.5 * torch.randn((2048, dim), generator=gc, device=dev)
         prc, _, _ = ix.coarse_topn(qc.contiguous(), nprobe)  # calibration batch (not one of the timed ones)
+        ix.sync()
         hits = torch.bincount(prc.flatten().clamp(0, nlist - 1), minlength=nlist).to(torch.float32).cpu().numpy()
         owner = lancedb_amd.shard_plan(s["part_offsets"], world, weights=hits)
         probes_ref, _, _ = ix.coarse_topn(qpool[0], nprobe)  # what a rank's scan stage is timed on when it runs alone
+        ix.sync()
         torch.cuda.synchronize()
         ix.close()
         del ix
@@ -374,6 +377,52 @@ def width_lines(a, torch, np, dev, shapes=((384, 24), (3072, 192)), n_rows=100_0
         ix.close()
         del ix, s
         torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------- concurrent host callers (no GIL) ----
+def build_loadgen():
+    """tests/tools/loadgen.cpp -> tests/tools/libloadgen.so (g++): N std::threads issuing single-query host-I/O calls."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "tools")
+    src, lib = os.path.join(here, "loadgen.cpp"), os.path.join(here, "libloadgen.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", src, "-o", lib], check=True)
+    return lib
+
+
+def concurrent_callers(np, ix, hq, params, k, thread_counts=(1, 8, 64, 256), per_thread=48):
+    """Single-query host-I/O callers from `n` OS threads each (the reference's tokio workers, python/src/runtime.rs:31-37),
+    through the coalescing queue (MI355_CFG_COALESCE, the handle's default) and with it off.  The callers are C++
+    threads (tests/tools/loadgen.cpp): Python threads measure the interpreter lock, not the library."""
+    import ctypes as C
+    from lancedb_amd import _abi
+    from lancedb_amd._lib import lib
+    L = C.CDLL(build_loadgen())
+    L.loadgen_run.restype = C.c_int32
+    fn = C.cast(lib().mi355_search, C.c_void_p)
+    hq = np.ascontiguousarray(hq, dtype=np.float32)
+    params.io_mem = _abi.MEM_HOST
+    out = {}
+    for mode, coalesce in (("coalesced", True), ("serialised", False)):
+        ix.configure(profile=0, graph=False, coalesce=coalesce)
+        for n in thread_counts:
+            if not coalesce and n not in (1, 64):
+                continue
+            per = per_thread if n <= 64 else max(8, per_thread // 4)
+            lat = np.zeros(n * per, dtype=np.float32)
+            sec = C.c_double(0)
+            chk = C.c_uint64(0)
+            for rep in range(2):  # (the first round warms the workspace sizes the batches need)
+                st = L.loadgen_run(fn, ix._h, hq.ctypes.data_as(C.c_void_p), C.c_uint32(hq.shape[0]), C.c_uint32(hq.shape[1]),
+                                   C.byref(params), C.c_uint32(k), C.c_uint32(n), C.c_uint32(per), C.byref(sec),
+                                   lat.ctypes.data_as(C.c_void_p), C.byref(chk))
+                if st != 0:
+                    raise RuntimeError(f"loadgen: mi355_search returned {st}")
+            ls = np.sort(lat)
+            out[f"{mode}_{n}_threads"] = {"queries_per_s": n * per / sec.value, "latency_us_p50": float(ls[len(ls) // 2]),
+                                          "latency_us_p99": float(ls[int(len(ls) * 0.99) - 1]), "calls": n * per}
+    ix.configure(profile=0, graph=False, coalesce=True)
     return out
 
 
@@ -527,6 +576,8 @@ def summary_of(result):
          "lat_p50_us": v(sec, "latency_c3", "single_query_us_eager", "p50"), "lat_p99_us": v(sec, "latency_c3", "single_query_us_eager", "p99"),
          "qps_64_threads": v(sec, "latency_c3", "qps_64_threads_coalesced"),
          "recall10": v(result, "recall_at_10", "nprobe64"), "recall10_rf25": v(result, "recall_at_10", "nprobe64_refine25")}
+    cc = sec.get("concurrent_callers_c3", {})
+    s["callers_qps"] = {k2.replace("_threads", ""): round(v2["queries_per_s"]) for k2, v2 in cc.items()}
     for key, line in sec.items():
         if key.startswith("c3_shape_"):
             s[key + "_qps"] = v(line, "value")

@@ -1,9 +1,13 @@
 // ann_internal.h — host-side internals shared by the translation units of
 // libmi355_ann.so (include/mi355_ann.h is the only public surface).
 //
-//   ann_core.hip    library calls, error slot, shard plan
-//   ann_index.hip   IVF-PQ handle: open / configure / search / probes / merge
-//   ann_flat.hip    flat handle: open / search (MFMA filter + exact re-rank)
+//   ann_core.hip          library calls, error slot, shard plan
+//   ann_index_open.hip    IVF-PQ handle lifecycle: open (packing, planner tables) / close / configure / raw column
+//   ann_index.hip         the search pipeline of one device batch (run_ivfpq), stage timers, statistics
+//   ann_index_search.hip  call driver: request checks, coalescing queue, graph cache, host I/O, mi355_search*
+//   ann_scan_skew*.hip    launchers / instantiations of the production scan kernel (plain and padded / multi-slab)
+//   ann_scan_pair.hip     launcher of the generic scan kernel (4-bit codes, MI355_INDEX_GENERIC_SCAN)
+//   ann_flat.hip          flat handle: open / search (MFMA filter + exact re-rank)
 //   ann_build.hip   index training and population
 //   ann_comm.hip    RCCL exchange behind the ABI: mi355_comm_*, mi355_search_sharded
 #pragma once

@@ -158,7 +158,7 @@ int32_t expand_short_device(mi355_index* ix, const uint32_t* d_cnt_ann, uint32_t
 
 static int32_t expand_short_queries(mi355_index* ix, const float* d_q, uint32_t n_queries, const SearchPlan& pl,
                                     uint32_t np_max, uint64_t* d_ids, float* d_dist, uint32_t* d_cnt,
-                                    const uint32_t* d_cnt_ann) {
+                                    const uint32_t* d_cnt_ann, bool host_io) {
   hipStream_t st = ix->stream;
   const uint32_t k = pl.k;
   ST_TRY(ix->w_sids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
@@ -169,9 +169,22 @@ static int32_t expand_short_queries(mi355_index* ix, const float* d_q, uint32_t 
   p2.nprobe = np_max;
   p2.ws_mb = 512;  // slots, not queries, size the workspace of this pass
   ST_TRY(expand_short_device(ix, d_cnt_ann, n_queries, pl.kk, d_q, ix->w_srows, ix->w_sq, st, &p2.act));
-  ST_TRY(run_ivfpq(ix, ix->w_sq.as<float>(), n_queries, p2, ix->w_sids.as<uint64_t>(), ix->w_sdist.as<float>(),
+  // A host-I/O call synchronises anyway: it reads the number of short queries and runs the second pass over exactly
+  // those slots — none, in the common case (with maximum_nprobes = all partitions and a large batch the
+  // device-side form walked thousands of mostly empty chunks).  Device-I/O calls keep the count on the device.
+  uint32_t n2 = n_queries;
+  if (host_io) {
+    HIP_TRY(hipMemcpyAsync(&n2, p2.act.n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    n2 = std::min(n2, n_queries);
+    if (n2 == 0) {
+      ix->second_np = np_max;
+      return MI355_OK;
+    }
+  }
+  ST_TRY(run_ivfpq(ix, ix->w_sq.as<float>(), n2, p2, ix->w_sids.as<uint64_t>(), ix->w_sdist.as<float>(),
                    ix->w_scnt.as<uint32_t>(), pl.refine ? ix->w_scnt_ann.as<uint32_t>() : ix->w_scnt.as<uint32_t>()));
-  hipLaunchKernelGGL(k_scatter_results, dim3(n_queries), dim3(64), 0, st, ix->w_srows.as<uint32_t>(), k, ix->w_sids.as<uint64_t>(),
+  hipLaunchKernelGGL(k_scatter_results, dim3(n2), dim3(64), 0, st, ix->w_srows.as<uint32_t>(), k, ix->w_sids.as<uint64_t>(),
                      ix->w_sdist.as<float>(), ix->w_scnt.as<uint32_t>(), d_ids, d_dist, d_cnt, p2.act);
   HIP_TRY(hipGetLastError());
   ix->second_np = np_max;
@@ -302,7 +315,7 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
     ST_TRY(launch_sequence(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt, d_cnt_ann, p->timeout_ms));
   account(ix, n_queries, pl.nprobe);
 
-  if (sh.np_max > sh.np_min) ST_TRY(expand_short_queries(ix, d_q, n_queries, pl, sh.np_max, d_ids, d_dist, d_cnt, d_cnt_ann));
+  if (sh.np_max > sh.np_min) ST_TRY(expand_short_queries(ix, d_q, n_queries, pl, sh.np_max, d_ids, d_dist, d_cnt, d_cnt_ann, host_io));
 
   if (host_io) {
     DevCtl h_ctl;

@@ -369,13 +369,11 @@ enum {
   MI355_FLAT_GEMM_AUTO = 0,
   MI355_FLAT_GEMM_128 = 1,       /* 128 x 128 tile, 4 waves, two barriers per k-step */
   MI355_FLAT_GEMM_256 = 2,       /* 256 x 256 tile, 8 waves, two barriers per k-step */
-  /* 3, 6, 7, 8 of rounds 1-2: schedules measured as no gain and removed (profiles/r02_*) */
+  /* 3, 6, 7, 8: schedules measured as no gain in rounds 1-2 and removed (profiles/r02_*) */
   MI355_FLAT_GEMM_8PHASE = 4,    /* 256 x 256, 8-phase schedule (counted vmcnt, staggered wave
                                     groups), fast epilogue: AUTO's choice above 128 queries */
-  MI355_FLAT_GEMM_8PHASE_REF = 5,/* the same schedule with variant 2's epilogue arithmetic
+  MI355_FLAT_GEMM_8PHASE_REF = 5 /* the same schedule with variant 2's epilogue arithmetic
                                     (bit-identical filter matrix: the schedule's own check) */
-  MI355_FLAT_GEMM_8PHASE_W32 = 9 /* the 8-phase schedule on v_mfma_f32_32x32x16_bf16 (round 4): half the matrix
-                                    instructions per flop; its matrix differs from variant 4's in rounding only */
 };
 enum {
   MI355_FLAT_CHECKSUM = 1u,

@@ -57,7 +57,6 @@ FLAT_GEMM_128 = 1
 FLAT_GEMM_256 = 2
 FLAT_GEMM_8PHASE = 4
 FLAT_GEMM_8PHASE_REF = 5
-FLAT_GEMM_8PHASE_W32 = 9
 FLAT_CHECKSUM = 1
 FLAT_PROFILE = 2
 

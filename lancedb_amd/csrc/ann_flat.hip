@@ -192,7 +192,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
     ga.omc = 1.f - f->c_err;
     ga.gm = f->g_gm.as<float>();
     ga.vw = nullptr;
-    if ((variant == MI355_FLAT_GEMM_8PHASE || variant == MI355_FLAT_GEMM_8PHASE_W32) && metric != MI355_METRIC_L2) {
+    if (variant == MI355_FLAT_GEMM_8PHASE && metric != MI355_METRIC_L2) {
       DevBuf& vw = metric == MI355_METRIC_COSINE ? f->vw_cos : f->vw_dot;
       if (!vw.p) {  // once per column and metric
         const uint64_t vv_rows = ((f->n_rows + 255) / 256) * 256;
@@ -223,9 +223,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
 #define LAUNCH_FG(MET)                                                                              \
   {                                                                                                 \
     if (oct) {                                                                                      \
-      void (*kern)(FlatGemmArgs) = k_flat_gemm8<MET, 0, false>;                                     \
-      if (variant == MI355_FLAT_GEMM_8PHASE_W32) kern = k_flat_gemm8<MET, 1, true>;                 \
-      else if (variant == MI355_FLAT_GEMM_8PHASE) kern = k_flat_gemm8<MET, 1, false>;               \
+      auto kern = variant == MI355_FLAT_GEMM_8PHASE ? k_flat_gemm8<MET, 1> : k_flat_gemm8<MET, 0>;  \
       HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)gemm_lds));                                                  \
       hipLaunchKernelGGL(kern, dim3(gemm_blocks), dim3(512), gemm_lds, st, ga);                     \
@@ -464,7 +462,7 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
 extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, uint32_t grid_workgroups,
                                         uint32_t flags) {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
-  if (gemm_variant > MI355_FLAT_GEMM_8PHASE_W32 || gemm_variant == 3 || (gemm_variant > MI355_FLAT_GEMM_8PHASE_REF && gemm_variant < MI355_FLAT_GEMM_8PHASE_W32))
+  if (gemm_variant > MI355_FLAT_GEMM_8PHASE_REF || gemm_variant == 3)
     return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
   if (flags & ~(uint32_t)(MI355_FLAT_CHECKSUM | MI355_FLAT_PROFILE)) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
   std::lock_guard<std::mutex> lk(f->mu);

@@ -492,8 +492,7 @@ def test_c5_config_shape_1536d_cosine_refine10(oracle, raw_dtype):
 
 
 GEMM_VARIANTS = {"128": _abi.FLAT_GEMM_128, "256": _abi.FLAT_GEMM_256,
-                 "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF,
-                 "8phase_w32": _abi.FLAT_GEMM_8PHASE_W32}  # (w32: the same schedule on 32 x 32 x 16 MFMAs, round 4)
+                 "8phase": _abi.FLAT_GEMM_8PHASE, "8phase_ref": _abi.FLAT_GEMM_8PHASE_REF}
 
 
 @pytest.mark.parametrize("tile", sorted(GEMM_VARIANTS))
@@ -521,7 +520,7 @@ def test_flat_mfma_persistent_workgroups_walk_many_tiles(oracle, tile):
     assert f1.info()[0] == 1
 
 
-@pytest.mark.parametrize("variant", ["8phase", "8phase_ref", "8phase_w32"])
+@pytest.mark.parametrize("variant", ["8phase", "8phase_ref"])
 @pytest.mark.parametrize("grid", [0, 1, 16])
 def test_flat_mfma_eight_phase_schedule(oracle, variant, grid):
     """The persistent 8-phase schedule against the exact sweep: ragged last row tile, 2 / 3 / 12
@@ -598,7 +597,7 @@ def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):
     q = np.concatenate([v[[100, 5000, 6000, 6002]], np.zeros((1, dim), np.float32),
                         rng.normal(size=(251, dim)).astype(np.float32)])
     f = lancedb_amd.FlatIndex(v)
-    for variant, grid in ((_abi.FLAT_GEMM_8PHASE, 0), (_abi.FLAT_GEMM_8PHASE, 8), (_abi.FLAT_GEMM_8PHASE_W32, 0), (_abi.FLAT_GEMM_8PHASE_W32, 8)):
+    for variant, grid in ((_abi.FLAT_GEMM_8PHASE, 0), (_abi.FLAT_GEMM_8PHASE, 8)):
         f.configure(gemm_variant=variant, grid_workgroups=grid)
         for metric in ("l2", "cosine", "dot"):
             mt = _abi.METRIC_NAMES[metric]

@@ -48,13 +48,6 @@
 #ifndef SK_LUT_INFLIGHT
 #define SK_LUT_INFLIGHT 8  // 16-B codebook loads in flight per thread while the distance table is built
 #endif
-#ifndef SK_STEAL_PIECES
-// > 1: a unit's tile positions are cut into this many pieces and the sixteen waves of a workgroup draw pieces from an LDS
-// counter (their own unit's first piece first), so that a wave the arbiter favoured takes work from one it starved: the
-// first-to-last-wave spread at the end of an item was 16 of 53 us (profiles/r03_f_scan_dev_counters_after.txt).  Each
-// piece pays the ring's prologue and the two tail chunks of a stream end.
-#define SK_STEAL_PIECES 1
-#endif
 #ifndef SK_RING_FULL
 #define SK_RING_FULL 0  // dev knob: 1 = ring of a whole tile's chunks (prefetch distance CPT-1 chunks)
 #endif
@@ -583,9 +576,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   // q = ceil(kk / NW) (WaveList QTRACK); the kk <= 64 kernel keeps the per-wave bound alone
   constexpr bool QSHARE = LR >= 3;
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
-  uint32_t* s_steal = s_q + 9;                                // [1] next piece of the item's scan (SK_STEAL_PIECES > 1)
-  SkewItem* s_rec = (SkewItem*)(((size_t)(s_steal + 1) + 31) & ~(size_t)31);  // [2] current / next item
-  constexpr bool STEAL = SK_STEAL_PIECES > 1 && NW == (int)SK_UNITS && !SLABBED;
+  SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
   PassFloor* s_floor = (PassFloor*)(s_rec + 2);                          // [1] (MULTI)
   // the gather address is (code << 9) | column bytes: the table must start at LDS address 0
   if ((uint32_t)(size_t)smem != 0u) __builtin_trap();
@@ -667,7 +658,6 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       if (d < res_n) res[d] = pre_q[u] - pre_c[u];  // dot: pre_c == 0, q - 0 == q exactly
     }
     if (tid == 0) *s_thr = __hip_atomic_load(a.qthr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (STEAL && tid == 0) *s_steal = NW;  // (pieces 0 .. NW-1 are the waves' own first pieces)
     if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
     if (OPT && tid == 0) *s_ovf = 0u;
     __syncthreads();
@@ -926,18 +916,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     const uint8_t* pcodes = ix.codes + code_off + (SLABBED ? slab * slab_bytes : (size_t)0);
     // two streams (chains A = 2u, B = 2u + 1) per wave; codes arrive chunk by chunk through a
     // ring of RING register slots per chain (prefetch distance RING - 1 chunks)
-    auto next_piece = [&](uint32_t cur) -> uint32_t {  // wave-uniform
-      if constexpr (STEAL) {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(s_steal, 1u);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-      } else {
-        return cur + NW;
-      }
-    };
-    constexpr uint32_t PIECES = STEAL ? (uint32_t)SK_STEAL_PIECES : 1u;
-    for (uint32_t piece = wid; piece < SK_UNITS * PIECES && !(a.dbg & 2u); piece = next_piece(piece)) {
-      const uint32_t u = piece % SK_UNITS, sub = piece / SK_UNITS;
+    for (uint32_t u = wid; u < SK_UNITS && !(a.dbg & 2u); u += NW) {
       const uint32_t nt = sk_unit_tiles(n_tiles, u);
       if (!nt) continue;
       constexpr int RING = SK_RING_FULL ? CPT : ((CPT % 3 == 0) ? 3 : (CPT % 2 == 0 ? 2 : CPT));
@@ -952,9 +931,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       // starts inside the stream meets the tails of tile n0 - 1 in its first steps (they only feed Y, which the
       // n > n0 test below never consumes) and ends like the stream does: the first two chunks of position n1
       // hold the tails of tile n1 - 1 (their tile-n1 bytes go to a dummy accumulator)
-      const uint32_t s0 = (uint32_t)((uint64_t)nt * slice / a.n_slices), s1 = (uint32_t)((uint64_t)nt * (slice + 1u) / a.n_slices);
-      // (stealing: this piece of the slice's positions; a piece starts and ends like a slice does)
-      const uint32_t n0 = s0 + (uint32_t)((uint64_t)(s1 - s0) * sub / PIECES), n1 = s0 + (uint32_t)((uint64_t)(s1 - s0) * (sub + 1u) / PIECES);
+      const uint32_t n0 = (uint32_t)((uint64_t)nt * slice / a.n_slices), n1 = (uint32_t)((uint64_t)nt * (slice + 1u) / a.n_slices);
       if (n0 == n1) continue;
       // partial row sums of the slabs before this one: [tile position][unit][lane] float2 (chains A, B), parked by this
       // very lane in the previous slab.  The load of position n + 1 is issued at the top of position n — before that
@@ -1127,7 +1104,6 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         if (tid == 0) {
           *s_ovf = 0u;
           *s_thr = thr0_key;
-          if (STEAL) *s_steal = NW;
         }
         if (tid < NW) s_part[tid] = 0xFFFFFFFFu;
         __syncthreads();
@@ -1281,7 +1257,6 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
     }
     __syncthreads();  // the floor is published; the lists and the block threshold are rebuilt
     if (tid == 0) *s_thr = thr0_key;
-    if (STEAL && tid == 0) *s_steal = NW;
     if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
     __syncthreads();
     }  // passes

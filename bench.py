@@ -149,7 +149,14 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)  # (torch's eager RCCL init prints the same banner)
+        try:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     n, dim, nlist, m = a.n_rows, a.dim, a.nlist, a.m
     if a.batch_per_gpu and world > 1:
@@ -220,7 +227,15 @@ def main():
         from lancedb_amd.distributed import Comm, ShardedSearcher, unique_id
         uid = [unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        comm = Comm(uid[0], rank, world, device=local_rank)
+        # (RCCL prints its version banner on stdout when a communicator is created: keep rank 0's stdout to the one JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = Comm(uid[0], rank, world, device=local_rank)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         searcher = ShardedSearcher(ix, comm, shard_coarse=a.shard_coarse, overlap=not a.no_overlap)
 
     def step(i):

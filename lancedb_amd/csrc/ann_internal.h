@@ -232,6 +232,7 @@ struct mi355_index {
   std::condition_variable qcv;
   std::vector<PendingSearch*> queue;
   bool busy = false;
+  uint32_t last_batch_calls = 0;  // calls the last coalesced batch served (> 1 arms the leader's batching window)
 };
 
 struct mi355_flat {

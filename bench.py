@@ -427,11 +427,9 @@ def scan_roofline(achieved, bytes_per_launch, us_per_launch, launches, traffic, 
 
 
 def latency_and_concurrency(a, np, ix, qpool):
-    """Host-I/O callers on the 100 M index (SURVEY.md §8b threading: callers are tokio workers,
-    python/src/runtime.rs:31-37): single-query latency from one thread (the launch sequence is a
-    replayed hipGraph, MI355_CFG_GRAPH) and 64 threads issuing single queries at once (calls that
-    arrive while the device is busy are served from one device batch, MI355_CFG_COALESCE)."""
-    import threading
+    """Host-I/O single-query latency on the 100 M index from one thread (callers are tokio workers,
+    python/src/runtime.rs:31-37), eager launches and a replayed hipGraph (MI355_CFG_GRAPH); per-stage device times of
+    one query.  Concurrent callers: bench_legs.concurrent_callers."""
     from lancedb_amd import _abi
     hq = qpool[0].cpu().numpy()
     kw = dict(k=a.k, nprobe_min=a.nprobe, nprobe_max=a.nprobe)
@@ -454,22 +452,7 @@ def latency_and_concurrency(a, np, ix, qpool):
     ix.search(hq[7:8], **kw)
     st = ix.stats()
     out["single_query_stage_us"] = {s2: st["us_" + s2] for s2 in ("coarse", "select", "scan", "merge")}
-    for mode, coalesce in (("coalesced", True), ("serialised", False)):
-        ix.configure(profile=0, graph=False, coalesce=coalesce)
-        n_threads, per = 64, 24
-        barrier = threading.Barrier(n_threads + 1)
-
-        def worker(t):
-            barrier.wait()
-            for i in range(per):
-                ix.search(hq[(t * per + i) % 2048:(t * per + i) % 2048 + 1], **kw)
-
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
-        [t.start() for t in th]
-        barrier.wait()
-        t0 = time.perf_counter()
-        [t.join() for t in th]
-        out[f"qps_64_threads_{mode}"] = n_threads * per / (time.perf_counter() - t0)
+    # (concurrent callers: secondary.concurrent_callers_c3 — C++ threads; Python threads measured the interpreter lock)
     ix.configure(profile=0, graph=False, coalesce=True)  # the defaults of a freshly opened handle
     return out
 
@@ -768,7 +751,7 @@ def c5_refine10(a, torch, np, dev):
         import bench_legs as legs
         hc = legs.host_cores()
         cores = hc["usable"]
-        nq = min(B, cores)
+        nq = min(B, 256)  # (the parity sample does not shrink with the container's CPU quota)
         h_raw = raw if host_mapped else col.cpu().numpy().view(np.uint16)
         ox = orc.OracleIndex(centroids.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
                              row_ids.cpu().numpy().astype(np.uint64), raw_vectors=h_raw, raw_dtype=_abi.DTYPE_BF16,

@@ -574,7 +574,6 @@ def summary_of(result):
          "flat_l2_parity_ids": v(sec, "flat_c2_l2", "cpu_baseline", "parity", "rowids_bit_exact"),
          "flat_cos_qps": v(sec, "flat_c2_cosine", "value"), "flat_cos_gemm_frac": v(sec, "flat_c2_cosine", "roofline", "frac"),
          "lat_p50_us": v(sec, "latency_c3", "single_query_us_eager", "p50"), "lat_p99_us": v(sec, "latency_c3", "single_query_us_eager", "p99"),
-         "qps_64_threads": v(sec, "latency_c3", "qps_64_threads_coalesced"),
          "recall10": v(result, "recall_at_10", "nprobe64"), "recall10_rf25": v(result, "recall_at_10", "nprobe64_refine25")}
     cc = sec.get("concurrent_callers_c3", {})
     s["callers_qps"] = {k2.replace("_threads", ""): round(v2["queries_per_s"]) for k2, v2 in cc.items()}

@@ -185,3 +185,24 @@ def test_no_compiler_copy_of_a_register_with_a_load_in_flight():
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "0 copies of a register in flight" in r.stdout
+
+
+def test_bench_helpers_host_cores_and_summary():
+    """bench_legs.host_cores: what the CPU legs are printed with — the affinity mask capped by the cgroup CPU quota (round 3 printed
+    os.cpu_count() = 256 on a box that grants the container 16 CPUs); summary_of: the compact trailer of the bench line."""
+    import bench_legs as legs
+    hc = legs.host_cores()
+    assert 1 <= hc["usable"] <= hc["affinity"] <= hc["box"]
+    if hc["cgroup_cpu_quota"] is not None:
+        assert hc["usable"] <= max(1, int(hc["cgroup_cpu_quota"] + 0.5))
+    line = {"value": 65000.0, "roofline": {"frac": 1.23, "lds_gather": {"frac": 0.5}},
+            "secondary": {"c4": {"value": 41000.0, "roofline": {"frac": 1.05}, "config": {"n_rows": 10 ** 9}},
+                          "c3_shape_dim384_m24": {"value": 110000.0, "roofline": {"frac": 0.53}},
+                          "qps_vs_batch": [{"batch": 1, "queries_per_s": 4800.0}, {"batch": 2048, "queries_per_s": 65000.0}],
+                          "concurrent_callers_c3": {"coalesced_64_threads": {"queries_per_s": 40000.0}}}}
+    s = legs.summary_of(line)
+    assert s["c3_qps"] == 65000.0 and s["c4_rows"] == 10 ** 9 and s["c3_shape_dim384_m24_frac"] == 0.53
+    assert s["qps_vs_batch"] == {"1": 4800, "2048": 65000} and s["callers_qps"] == {"coalesced_64": 40000}
+    assert s["c5_qps"] is None  # absent legs stay visible as null
+    import json
+    assert len(json.dumps(s)) < 2000  # the driver keeps the last 2000 characters of the line

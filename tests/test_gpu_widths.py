@@ -159,3 +159,22 @@ def test_generic_scan_flag_matches_oracle(oracle, metric, shape):
         _same(g.search(q, **kw), o.search(q, **kw))
     qb = rng.normal(size=(300, dim)).astype(np.float32)
     _same(g.search(qb, k=10, nprobe_min=3, nprobe_max=3), o.search(qb, k=10, nprobe_min=3, nprobe_max=3))
+
+
+def test_multi_slab_scan_of_a_very_long_partition(oracle):
+    """m > 96 keeps 8 B of partial sums per (tile position, unit, lane) of the LONGEST partition per workgroup; a partition of
+    2.2 M rows makes that 8.8 MB per workgroup, more than the 2 GiB the handle allows for 256 of them: the launch then runs on
+    fewer workgroups (the persistent kernel takes any count).  Sliced (40 queries x 1 probe = 320 work items) and a batch."""
+    rng = np.random.default_rng(11)
+    m, dsub, nlist = 128, 2, 2
+    dim = m * dsub
+    lens = np.array([2_200_000, 3_000], dtype=np.int64)
+    n = int(lens.sum())
+    s = train.synthetic_index(n, dim, nlist, m, seed=5)
+    s["part_offsets"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    s["centroids"][1] += 50.0  # every query probes the long partition first
+    g, o = _pair(oracle, s)
+    q = (s["centroids"][0] + rng.normal(0, 0.5, size=(40, dim))).astype(np.float32)
+    for kw in (dict(k=10, nprobe_min=1, nprobe_max=1), dict(k=100, nprobe_min=2, nprobe_max=2)):
+        _same(g.search(q, **kw), o.search(q, **kw))
+    assert g.stats()["scan_variant"] == _abi.SCAN_SKEW

@@ -178,3 +178,32 @@ def test_multi_slab_scan_of_a_very_long_partition(oracle):
     for kw in (dict(k=10, nprobe_min=1, nprobe_max=1), dict(k=100, nprobe_min=2, nprobe_max=2)):
         _same(g.search(q, **kw), o.search(q, **kw))
     assert g.stats()["scan_variant"] == _abi.SCAN_SKEW
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_against_the_oracle(oracle, seed):
+    """Seeded random shapes across the SkewShape rules (padding, 2-8 slabs), sub-vector lengths with and without the 16-B table
+    builder, all metrics, k across the list-length and multi-pass regimes, ranges, sliced and chip-filling batches."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([1, 3, 7, 8, 12, 20, 24, 31, 33, 40, 60, 72, 90, 97, 110, 128, 150, 192, 200, 256, 320, 400, 500, 700]))
+    dsub = int(rng.choice([1, 2, 3, 4, 8, 16] if m <= 128 else [1, 2, 4]))
+    dim = m * dsub
+    nlist = int(rng.integers(3, 20))
+    lens = rng.integers(0, 6000, size=nlist)
+    lens[rng.integers(0, nlist)] = int(rng.integers(6000, 40000))
+    n = int(lens.sum())
+    metric = ["l2", "cosine", "dot"][seed % 3]
+    s = train.synthetic_index(n, dim, nlist, m, seed=seed)
+    s["part_offsets"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    g, o = _pair(oracle, s, metric)
+    for nq in (1, 5, int(rng.integers(20, 400))):
+        q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.5, size=(nq, dim))).astype(np.float32)
+        k = int(rng.choice([1, 10, 64, 100, 129, 256, 300]))
+        nprobe = int(rng.integers(1, nlist + 1))
+        exp = o.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe)
+        _same(g.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe), exp)
+        fin = exp[1][0][np.isfinite(exp[1][0])]
+        if len(fin) > 4:
+            kw = dict(k=k, nprobe_min=nprobe, nprobe_max=nprobe, lower_bound=float(fin[1]), upper_bound=float(fin[-2]))
+            _same(g.search(q, **kw), o.search(q, **kw))
+    assert g.stats()["scan_variant"] == _abi.SCAN_SKEW

@@ -380,9 +380,10 @@ def main():
         if a.c4_rows > 0:
             result["secondary"]["c4"] = legs.c4_leg(a, torch, np, dev, n_rows=a.c4_rows, world=a.loopback_world)
         if a.widths:
-            result["secondary"].update(legs.width_lines(a, torch, np, dev))
+            result["secondary"].update(legs.width_lines(a, torch, np, dev, n_rows=a.n_rows))
         if a.gist_rows > 0:
             result["secondary"]["gist_like"] = legs.gist_like(a, torch, np, dev, n=a.gist_rows)
+        result["secondary"]["c1_flat"] = legs.c1_flat(a, np)
         for metric in ("l2", "cosine"):
             result["secondary"]["flat_c2_" + metric] = flat_c2(a, metric, cpu_queries=32 if metric == "l2" else 16)
     if rank == 0 and "secondary" in result and "recall_at_10" in result:

@@ -545,6 +545,44 @@ def gist_like(a, torch, np, dev, n=1_000_000, dim=960, nq=1000):
     return res
 
 
+# ------------------------------------------------------------------------------------------------ C1 ----
+def c1_flat(a, np, n=100_000, dim=128):
+    """BASELINE.json configs[0]: flat (no index) L2 KNN, 100 k x 128 f32, ONE query — the reference's own CPU-runnable case
+    (python/python/lancedb/query.py:1365-1370: KNNVectorDistance + TopK).  Both sides: the CPU oracle's exact sweep (one thread:
+    the reference answers a query on one tokio worker) and the engine's flat handle on the same column from host buffers
+    (single-query latency through the C ABI); row ids and distances must be equal."""
+    import lancedb_amd
+    rng = np.random.default_rng(SEED)
+    v = rng.random((n, dim), dtype=np.float32)
+    qs = rng.random((64, dim), dtype=np.float32)
+    fl = lancedb_amd.FlatIndex(v)
+    for i in range(5):
+        fl.search(qs[i:i + 1], k=a.k)
+    lat = []
+    for i in range(200):
+        t0 = time.perf_counter()
+        got = fl.search(qs[i % 64:i % 64 + 1], k=a.k)
+        lat.append(time.perf_counter() - t0)
+    lat = np.sort(np.array(lat)) * 1e6
+    res = {"workload": f"flat_{n}x{dim}_f32_batch1_k{a.k}_l2", "n_rows": n, "dim": dim,
+           "engine_single_query_us": {"p50": float(lat[100]), "p99": float(lat[197])}, "engine_queries_per_s_one_caller": 1e6 / float(lat.mean()),
+           "algorithmic_bytes_per_query": n * dim * 4, "path": "MFMA filter + exact re-rank" if fl.info()[0] == 1 else "exact sweep"}
+    if a.cpu_seconds > 0:
+        from oracle import oracle as orc
+        orc.build()
+        t0 = time.perf_counter()
+        reps = 20
+        for i in range(reps):
+            ids, dist, cnt, _ = orc.flat_search(v, qs[i % 64:i % 64 + 1], k=a.k, nthreads=1)
+        t_cpu = (time.perf_counter() - t0) / reps
+        got = fl.search(qs[(reps - 1) % 64:(reps - 1) % 64 + 1], k=a.k)
+        res["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port", "us_per_query": t_cpu * 1e6,
+                               "sample": f"{reps} single queries, one thread; C restatement (oracle/ann_oracle.c), not the reference binary",
+                               "parity": {"rowids_bit_exact": bool((got.rowids == ids).all()), "distances_equal": bool((got.distances == dist).all())}}
+    fl.close()
+    return res
+
+
 # --------------------------------------------------------------------------------------- the summary ----
 def summary_of(result):
     """A compact dict of the secondary scalars, placed LAST in the JSON line: the driver stores only the tail of it."""
@@ -574,6 +612,7 @@ def summary_of(result):
          "flat_l2_parity_ids": v(sec, "flat_c2_l2", "cpu_baseline", "parity", "rowids_bit_exact"),
          "flat_cos_qps": v(sec, "flat_c2_cosine", "value"), "flat_cos_gemm_frac": v(sec, "flat_c2_cosine", "roofline", "frac"),
          "lat_p50_us": v(sec, "latency_c3", "single_query_us_eager", "p50"), "lat_p99_us": v(sec, "latency_c3", "single_query_us_eager", "p99"),
+         "c1_engine_us": v(sec, "c1_flat", "engine_single_query_us", "p50"), "c1_cpu_us": v(sec, "c1_flat", "cpu_baseline", "us_per_query"),
          "recall10": v(result, "recall_at_10", "nprobe64"), "recall10_rf25": v(result, "recall_at_10", "nprobe64_refine25")}
     cc = sec.get("concurrent_callers_c3", {})
     s["callers_qps"] = {k2.replace("_threads", ""): round(v2["queries_per_s"]) for k2, v2 in cc.items()}

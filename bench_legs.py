@@ -39,21 +39,21 @@ def host_cores():
 
 
 # --------------------------------------------------------------------------------- synthetic indexes ----
-def synth_tables(torch, np, dev, n, dim, nlist, m, skew, seed=SEED, cen_scale=1.0, cb_scale=0.5):
+def synth_tables(torch, np, dev, n, dim, nlist, m, skew, seed=SEED, cen_scale=1.0, cb_scale=0.5, nbits=8):
     """The small tables of a throughput dataset, identical on every rank: centroids ~ N(0,1),
     codebook ~ N(0,0.25), log-normally skewed partition lengths.  `gen` is the device generator, positioned behind
     the tables (the query batches are drawn from it next)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     centroids = torch.randn((nlist, dim), generator=g, device=dev, dtype=torch.float32) * cen_scale
-    codebook = torch.randn((m, 256, dim // m), generator=g, device=dev, dtype=torch.float32) * cb_scale
+    codebook = torch.randn((m, 1 << nbits, dim // m), generator=g, device=dev, dtype=torch.float32) * cb_scale
     rng = np.random.default_rng(seed)
     w = np.exp(rng.normal(0.0, skew, size=nlist))
     lens = rng.multinomial(n, w / w.sum())
     part_offsets = np.zeros(nlist + 1, dtype=np.uint64)
     part_offsets[1:] = np.cumsum(lens)
     return {"centroids": centroids, "codebook": codebook, "part_offsets": part_offsets, "lens": lens, "gen": g, "n": n, "m": m,
-            "seed": seed}
+            "seed": seed, "mb": m * nbits // 8}
 
 
 def synth_rows(torch, np, dev, t, owner=None, rank=0):
@@ -61,7 +61,7 @@ def synth_rows(torch, np, dev, t, owner=None, rank=0):
     ids = an affine permutation of the global index position, generated PER PARTITION (seed = f(seed, partition)) for the
     partitions of `owner == rank` only (all when owner is None) — a rank never materialises another rank's rows and the
     index is the same for every world size."""
-    n, m, seed, lens, part_offsets = t["n"], t["m"], t["seed"], t["lens"], t["part_offsets"]
+    n, m, seed, lens, part_offsets = t["n"], t["mb"], t["seed"], t["lens"], t["part_offsets"]  # (m here = code BYTES per row)
     nlist = len(lens)
     mine = np.arange(nlist) if owner is None else np.nonzero(owner == rank)[0]
     lm = lens[mine].astype(np.int64)
@@ -90,8 +90,8 @@ def synth_rows(torch, np, dev, t, owner=None, rank=0):
     return t
 
 
-def synth_ivfpq(torch, np, dev, n, dim, nlist, m, skew, seed=SEED, owner=None, rank=0):
-    return synth_rows(torch, np, dev, synth_tables(torch, np, dev, n, dim, nlist, m, skew, seed), owner, rank)
+def synth_ivfpq(torch, np, dev, n, dim, nlist, m, skew, seed=SEED, owner=None, rank=0, nbits=8):
+    return synth_rows(torch, np, dev, synth_tables(torch, np, dev, n, dim, nlist, m, skew, seed, nbits=nbits), owner, rank)
 
 
 def query_pool(torch, s, nlist, dim, batch, n_batches, noise=0.5):
@@ -345,23 +345,24 @@ def c4_leg(a, torch, np, dev, n_rows=1_000_000_000, world=8, parity_queries=64):
 
 
 # -------------------------------------------------------------------- the reference's default PQ widths ----
-def width_lines(a, torch, np, dev, shapes=((384, 24), (3072, 192)), n_rows=100_000_000):
+def width_lines(a, torch, np, dev, shapes=((384, 24, 8), (3072, 192, 8), (768, 96, 4)), n_rows=100_000_000):
     """`suggested_num_sub_vectors` (rust/lancedb/src/index/vector.rs:306-319) gives m = dim / 16: 24 for 384-d, 192 for
     3072-d — neither is a kernel width of the production scan.  Round 4 runs them on it anyway (padding / slabs,
     csrc/kernels_skew.h SkewShape); these lines are the C3 workload at those shapes with the section-8d fraction of each
-    (algorithmic bytes = the REAL m bytes per scanned row: padding bytes are not credited)."""
+    (algorithmic bytes = the REAL m bytes per scanned row: padding bytes are not credited).  The third line is 4-bit PQ
+    (`num_bits = 4`, table/create_index.rs:86-102) at the C3 shape: the generic kernel (k_scan_pair), 48 code bytes per row."""
     import lancedb_amd
     from lancedb_amd import _abi
     out = {}
     nlist, nprobe, k, B = a.nlist, a.nprobe, a.k, a.batch
-    for dim, m in shapes:
+    for dim, m, nbits in shapes:
         free, _ = torch.cuda.mem_get_info(dev)
         n = n_rows
         while n * (m + 8) * 2.2 + (8 << 30) > free and n > 10_000_000:
             n //= 2
-        s = synth_ivfpq(torch, np, dev, n, dim, nlist, m, a.skew, seed=SEED + dim)
+        s = synth_ivfpq(torch, np, dev, n, dim, nlist, m, a.skew, seed=SEED + dim + nbits, nbits=nbits)
         ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric="l2",
-                                    codes_layout=_abi.CODES_PART_TRANSPOSED)
+                                    codes_layout=_abi.CODES_PART_TRANSPOSED, nbits=nbits)
         del s["codes"], s["row_ids"]
         torch.cuda.empty_cache()
         qpool = query_pool(torch, s, nlist, dim, B, 2)
@@ -371,9 +372,11 @@ def width_lines(a, torch, np, dev, shapes=((384, 24), (3072, 192)), n_rows=100_0
         steps = max(3, a.steps // 3)
         dt, st, _ = timed_steps(torch, ix, qpool, params, outb, steps, warmup=1)
         line = scan_line(st, steps, B, dt, torch.cuda.get_device_properties(dev).multi_processor_count)
-        line["config"] = {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{nprobe}_k{k}_l2", "n_rows": n, "dim": dim, "m": m,
-                          "batch_queries": B, "table": "padded to 32 columns" if m < 32 else f"{(m + 95) // 96} slabs of {((-(-m // ((m + 95) // 96))) + 15) // 16 * 16} columns"}
-        out[f"c3_shape_dim{dim}_m{m}"] = line
+        line["config"] = {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x{nbits}_nprobe{nprobe}_k{k}_l2", "n_rows": n, "dim": dim, "m": m,
+                          "num_bits": nbits, "batch_queries": B,
+                          "table": "generic kernel: [m][16] table, two codes per byte" if nbits == 4 else "padded to 32 columns" if m < 32
+                          else f"{(m + 95) // 96} slabs of {((-(-m // ((m + 95) // 96))) + 15) // 16 * 16} columns"}
+        out[f"c3_shape_dim{dim}_m{m}" + ("_pq4" if nbits == 4 else "")] = line
         ix.close()
         del ix, s
         torch.cuda.empty_cache()

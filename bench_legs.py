@@ -350,7 +350,8 @@ def width_lines(a, torch, np, dev, shapes=((384, 24, 8), (3072, 192, 8), (768, 9
     3072-d — neither is a kernel width of the production scan.  Round 4 runs them on it anyway (padding / slabs,
     csrc/kernels_skew.h SkewShape); these lines are the C3 workload at those shapes with the section-8d fraction of each
     (algorithmic bytes = the REAL m bytes per scanned row: padding bytes are not credited).  The third line is 4-bit PQ
-    (`num_bits = 4`, table/create_index.rs:86-102) at the C3 shape: the generic kernel (k_scan_pair), 48 code bytes per row."""
+    (`num_bits = 4`, table/create_index.rs:86-102) at the C3 shape: 48 code bytes per row algorithmically; the production scan
+    reads them expanded to one byte per sub-quantiser (the generic packed-nibble kernel measured 30.0 k QPS, 0.29)."""
     import lancedb_amd
     from lancedb_amd import _abi
     out = {}
@@ -374,7 +375,7 @@ def width_lines(a, torch, np, dev, shapes=((384, 24, 8), (3072, 192, 8), (768, 9
         line = scan_line(st, steps, B, dt, torch.cuda.get_device_properties(dev).multi_processor_count)
         line["config"] = {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x{nbits}_nprobe{nprobe}_k{k}_l2", "n_rows": n, "dim": dim, "m": m,
                           "num_bits": nbits, "batch_queries": B,
-                          "table": "generic kernel: [m][16] table, two codes per byte" if nbits == 4 else "padded to 32 columns" if m < 32
+                          "table": "16-row table; nibbles expanded to one byte per column at pack time" if nbits == 4 else "padded to 32 columns" if m < 32
                           else f"{(m + 95) // 96} slabs of {((-(-m // ((m + 95) // 96))) + 15) // 16 * 16} columns"}
         out[f"c3_shape_dim{dim}_m{m}" + ("_pq4" if nbits == 4 else "")] = line
         ix.close()

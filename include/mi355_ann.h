@@ -245,10 +245,11 @@ enum {
                             [sub-quantiser][code] table, any m */
   MI355_SCAN_SKEW = 2    /* production: pre-skewed code streams + [code][column]
                             table (bank-conflict-free gathers), partition-major
-                            work queues per XCD; 8-bit codes, any m up to 768: a table
-                            holds 32 / 48 / 64 / 80 / 96 columns, other m <= 96 are
-                            padded with zero columns, larger m are scanned in slabs
-                            of <= 96 columns (the row sum stays j-ascending) */
+                            work queues per XCD; any m up to 768: a table holds
+                            32 / 48 / 64 / 80 / 96 columns, other m <= 96 are padded
+                            with zero columns, larger m are scanned in slabs of <= 96
+                            columns (the row sum stays j-ascending); 4-bit codes are
+                            expanded to one byte per sub-quantiser when packed */
 };
 
 /* mi355_index_configure `profile` bits above the low byte */

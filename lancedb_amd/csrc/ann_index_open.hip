@@ -213,7 +213,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     // there is one slab) + the candidate lists of eight waves; a thread stages at most four residual elements.
     SkewShape shp{};
     ix->layout = MI355_SCAN_PAIR;
-    if (!force_pair && d->nbits == 8 && sk_shape(m, &shp)) {
+    if (!force_pair && sk_shape(m, &shp)) {  // (4-bit codes are expanded to one byte per column at pack time)
       const uint32_t res_floats = shp.n_slabs > 1 ? shp.M * ix->dsub : d->dim;
       if (res_floats <= 2048 && sk_scan_lds(res_floats, 8, 5) <= 160u * 1024) {
         ix->layout = MI355_SCAN_SKEW;
@@ -302,6 +302,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
       sp.plen = ra.plen;
       sp.m = ix->sk_M;
       sp.m_src = m;
+      sp.nbits = d->nbits;
       sp.transposed = ra.transposed;
       // grid.y is limited to 65535: split very wide batches
       for (size_t y0 = 0; y0 < pids.size(); y0 += 32768) {
@@ -359,10 +360,10 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
 
   // -- skewed layout: transposed codebook, static partition order and planner buffers
   if (skew) {
-    const size_t cb_elems = (size_t)m * 256 * ix->dsub;
+    const size_t cb_elems = (size_t)m * cb_entries * ix->dsub;
     ST_TRY(ix->cbT.ensure(sizeof(float) * cb_elems));
     hipLaunchKernelGGL(k_transpose_codebook, dim3((uint32_t)((cb_elems + 255) / 256)), dim3(256), 0, st,
-                       ix->codebook.as<float>(), m, ix->dsub, ix->cbT.as<float>());
+                       ix->codebook.as<float>(), m, ix->dsub, cb_entries, ix->cbT.as<float>());
     HIP_TRY(hipGetLastError());
     // Queue x (the XCD that scans it first) gets partitions by greedy
     // longest-first bin packing; inside a queue the longest partitions go first

@@ -169,8 +169,12 @@ struct SkewPackArgs {
   const uint64_t* code_off;   // [nlist] byte offset of the partition block in dst
   const uint32_t* plen;
   uint32_t m;                 // columns per slab (SkewShape::M): the packed row width
-  uint32_t m_src;             // code bytes per source row (the index's m); slab z packs columns z*m .. of it, zero-padded
-  uint32_t transposed;        // source layout: 1 = [m_src][len] per partition, 0 = [len][m_src]
+  uint32_t m_src;             // columns per source row (the index's m); slab z packs columns z*m .. of it, zero-padded
+  uint32_t transposed;        // source layout: 1 = [bytes per row][len] per partition, 0 = [len][bytes per row]
+  // 4: 4-bit PQ (table/create_index.rs:86-102) — a source row is m_src / 2 bytes, sub-quantiser 2t in the low nibble of byte t; the
+  // packed streams hold one BYTE per column (values 0..15): the scan is the 8-bit one against a 16-row table, at twice the stored
+  // bytes of the packed-nibble form and 2.5 x the speed of the generic 4-bit kernel (round 4: 30 k -> see DESIGN.md section 4.1)
+  uint32_t nbits;
 };
 
 // grid = (slots, partitions of the batch, slabs); a partition block holds its slabs one after the other, each laid
@@ -208,8 +212,16 @@ static __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
         j = e % m;
       }
       uint32_t v = 0;
-      if (r0 + i < len && j0 + j < a.m_src)
-        v = a.transposed ? src[(size_t)(j0 + j) * len + r0 + i] : src[(size_t)(r0 + i) * a.m_src + j0 + j];
+      if (r0 + i < len && j0 + j < a.m_src) {
+        const uint32_t col = j0 + j;
+        if (a.nbits == 4) {
+          const uint32_t byte = col >> 1, mbs = a.m_src >> 1;
+          const uint32_t bv = a.transposed ? src[(size_t)byte * len + r0 + i] : src[(size_t)(r0 + i) * mbs + byte];
+          v = (bv >> (4u * (col & 1u))) & 15u;
+        } else {
+          v = a.transposed ? src[(size_t)col * len + r0 + i] : src[(size_t)(r0 + i) * a.m_src + col];
+        }
+      }
       t[i * pitch + j] = (unsigned char)v;
     }
   }
@@ -244,12 +256,12 @@ static __global__ __launch_bounds__(256) void k_pack_skew(SkewPackArgs a) {
 
 // codebook [m][256][dsub] -> [256][m][dsub]: the LUT builder then walks
 // consecutive j with consecutive lanes (coalesced reads, conflict-free writes)
-static __global__ void k_transpose_codebook(const float* __restrict__ cb, uint32_t m, uint32_t dsub,
+static __global__ void k_transpose_codebook(const float* __restrict__ cb, uint32_t m, uint32_t dsub, uint32_t ksub,
                                      float* __restrict__ out) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // over m*256*dsub
-  const uint32_t total = m * 256u * dsub;
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // over m*ksub*dsub (ksub = 256, or 16 for 4-bit PQ)
+  const uint32_t total = m * ksub * dsub;
   if (e >= total) return;
-  const uint32_t t = e % dsub, c = (e / dsub) % 256u, j = e / (dsub * 256u);
+  const uint32_t t = e % dsub, c = (e / dsub) % ksub, j = e / (dsub * ksub);
   out[((size_t)c * m + j) * dsub + t] = cb[e];
 }
 
@@ -666,6 +678,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       const uint32_t dsub = ix.dsub;
       const bool dotm = ix.metric == MI355_METRIC_DOT;
       const uint32_t jbase = SLABBED ? slab * (uint32_t)M : 0u;
+      const uint32_t n_codes = ix.nbits == 4 ? 16u : 256u;  // table rows that exist (4-bit PQ: codes 0..15, one per byte of the streams)
       auto put = [&](uint32_t e, float acc, bool valid) {
         const uint32_t c = e / (uint32_t)M, j = e % (uint32_t)M;
         if (dotm) acc = 1.0f - acc;
@@ -693,11 +706,12 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       };
       // sub-vector lengths 4 / 8 / 16 (dim / m of the reference's defaults, index/vector.rs:306-310: 768 / 96,
       // 1536 / 96): whole entries as 16-B loads, 8 of them in flight per thread, the chain in element order
-      auto lut_fast = [&](auto ds_tag) {
+      auto lut_fast = [&](auto ds_tag, auto ks_tag) {
         constexpr int DS = decltype(ds_tag)::value;
+        constexpr uint32_t KSUB = decltype(ks_tag)::value;  // table rows that exist: 256, or 16 (4-bit PQ)
         constexpr int V = DS / 4;    // 16-B pieces per codebook entry
         constexpr int EPR = (SK_LUT_INFLIGHT / V) > 0 ? (SK_LUT_INFLIGHT / V) : 1;  // entries per thread per round
-        constexpr uint32_t TOTAL = 256u * M;
+        constexpr uint32_t TOTAL = KSUB * (uint32_t)M;
         for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
           float4 cv4[EPR][V];
           bool ok[EPR];
@@ -746,14 +760,20 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
           }
         }
       };
-      if (dsub == 8) {
-        lut_fast(std::integral_constant<int, 8>{});
-      } else if (dsub == 16) {
-        lut_fast(std::integral_constant<int, 16>{});
-      } else if (dsub == 4) {
-        lut_fast(std::integral_constant<int, 4>{});
+      constexpr std::integral_constant<uint32_t, 256u> K256{};
+      constexpr std::integral_constant<uint32_t, 16u> K16{};
+      if (n_codes == 256u && dsub == 8) {
+        lut_fast(std::integral_constant<int, 8>{}, K256);
+      } else if (n_codes == 256u && dsub == 16) {
+        lut_fast(std::integral_constant<int, 16>{}, K256);
+      } else if (n_codes == 256u && dsub == 4) {
+        lut_fast(std::integral_constant<int, 4>{}, K256);
+      } else if (n_codes == 16u && dsub == 8) {
+        lut_fast(std::integral_constant<int, 8>{}, K16);
+      } else if (n_codes == 16u && dsub == 16) {
+        lut_fast(std::integral_constant<int, 16>{}, K16);
       } else {
-        for (uint32_t e = tid; e < 256u * M; e += NT) {
+        for (uint32_t e = tid; e < n_codes * (uint32_t)M; e += NT) {
           bool valid;
           const size_t at = cb_of(e, valid);
           float acc = 0.f;

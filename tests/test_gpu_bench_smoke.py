@@ -33,7 +33,7 @@ def test_default_bench_line_at_toy_sizes():
     assert sec["loopback_world4"]["overlapped"]["every_rank_equals_unsharded"] and sec["loopback_world4"]["serial"]["every_rank_equals_unsharded"]
     for key in ("c3_shape_dim384_m24", "c3_shape_dim3072_m192"):
         assert sec[key]["scan_variant"] == 2 and sec[key]["value"] > 0
-    assert sec["c3_shape_dim768_m96_pq4"]["scan_variant"] == 1 and sec["c3_shape_dim768_m96_pq4"]["value"] > 0
+    assert sec["c3_shape_dim768_m96_pq4"]["scan_variant"] == 2 and sec["c3_shape_dim768_m96_pq4"]["value"] > 0
     assert [p["batch"] for p in sec["qps_vs_batch"]] == [1, 8, 64, 256, 512, 1024, 2048]
     assert sec["concurrent_callers_c3"]["coalesced_64_threads"]["queries_per_s"] > 0
     assert sec["gist_like"]["scan_variant"] == 2 and len(sec["gist_like"]["points"]) == 8

@@ -18,25 +18,29 @@ def _same(got, exp):
     assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()
 
 
+@pytest.mark.parametrize("generic", [False, True], ids=["production", "generic"])
 @pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
-@pytest.mark.parametrize("shape", [(20000, 64, 16, 16), (9000, 96, 8, 96), (3000, 24, 5, 2)])
-def test_pq4_search_matches_oracle(oracle, metric, shape):
+@pytest.mark.parametrize("shape", [(20000, 64, 16, 16), (9000, 96, 8, 96), (3000, 24, 5, 2), (12000, 256, 6, 128)])
+def test_pq4_search_matches_oracle(oracle, metric, shape, generic):
+    """Round 4: 4-bit indexes run the production scan too — the nibbles are expanded to one byte per sub-quantiser when the
+    streams are packed and the table has 16 rows (`generic`: the packed-nibble generic kernel, MI355_INDEX_GENERIC_SCAN)."""
     n, dim, nlist, m = shape
     s = train.synthetic_index(n, dim, nlist, m, seed=n + m, empty_parts=1, nbits=4)
     assert s["codes"].shape == (n, m // 2) and s["codebook"].shape == (m, 16, dim // m)
-    g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric, nbits=4)
+    g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric, nbits=4,
+                               generic_scan=generic)
     o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric, nbits=4)
     q = np.random.default_rng(3).normal(size=(9, dim)).astype(np.float32)
     for nprobe in (1, max(1, nlist // 2), nlist):
         for k in (1, 10, 70, 300):
             _same(g.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe), o.search(q, k=k, nprobe_min=nprobe, nprobe_max=nprobe))
     st = g.stats()
-    assert st["scan_variant"] == _abi.SCAN_PAIR and st["vectors_scanned"] == o.last_vectors_scanned
+    assert st["scan_variant"] == (_abi.SCAN_PAIR if generic else _abi.SCAN_SKEW) and st["vectors_scanned"] == o.last_vectors_scanned
     assert st["code_bytes_scanned"] == o.last_vectors_scanned * (m // 2)  # algorithmic bytes: m * nbits / 8
     # lance's per-partition transposed storage of the packed bytes
     tr = train.to_part_transposed(s["codes"], s["part_offsets"])
     g2 = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], tr, s["row_ids"], metric=metric, nbits=4,
-                                codes_layout=_abi.CODES_PART_TRANSPOSED)
+                                codes_layout=_abi.CODES_PART_TRANSPOSED, generic_scan=generic)
     _same(g2.search(q, k=10, nprobe_min=nlist, nprobe_max=nlist), o.search(q, k=10, nprobe_min=nlist, nprobe_max=nlist))
 
 

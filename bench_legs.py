@@ -413,7 +413,7 @@ def concurrent_callers(np, ix, hq, params, k, thread_counts=(1, 8, 64, 256), per
         for n in thread_counts:
             if not coalesce and n not in (1, 64):
                 continue
-            per = per_thread if n <= 64 else max(8, per_thread // 4)
+            per = per_thread if n <= 64 else max(24, per_thread // 2)  # (a 256-thread round must outlast its ramp-up)
             lat = np.zeros(n * per, dtype=np.float32)
             sec = C.c_double(0)
             chk = C.c_uint64(0)

@@ -168,8 +168,12 @@ struct PendingSearch {
   uint32_t* out_counts;
   int32_t status = MI355_OK;
   std::string error;
-  bool done = false;
+  // 0 = parked, QS_SERVED = another caller's batch carried it (status / error are final), QS_LEAD = handed the device: this
+  // caller runs the next batch.  Written last by the thread that decides, read without the queue lock by the owner.
+  std::atomic<uint32_t> state{0};
+  uint32_t cohort = 0;  // which of the handle's two wake words it sleeps on (parity of the collection it arrived before)
 };
+enum : uint32_t { QS_PARKED = 0, QS_SERVED = 1, QS_LEAD = 2 };
 
 struct mi355_index {
   int32_t device = 0;
@@ -229,9 +233,13 @@ struct mi355_index {
   // coalescing queue (guarded by qmu): callers that find the handle busy park here and the
   // thread that owns the device batches every compatible request it finds when it is done
   std::mutex qmu;
-  std::condition_variable qcv;
   std::vector<PendingSearch*> queue;
   bool busy = false;
+  // Parked callers sleep on one of two futex words (Linux; the product is ROCm-only): everything a batch collects arrived
+  // before that collection and shares a word, so ONE wake call releases the callers a batch served, none of them needs the
+  // queue lock to leave, and the callers that parked meanwhile (the other word) sleep on.
+  uint32_t collect_gen = 0;
+  std::atomic<uint32_t> wake_word[2] = {{0}, {0}};
   uint32_t last_batch_calls = 0;  // calls the last coalesced batch served (> 1 arms the leader's batching window)
 };
 

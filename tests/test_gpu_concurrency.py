@@ -229,3 +229,39 @@ def test_deferred_refine_with_changing_batch_sizes_and_refine_factors(oracle):
     _hip.runtime().hipDeviceSynchronize()
     ids, dist, cnt, _ = o.search(q, k=k, nprobe_min=10, nprobe_max=10, refine_factor=rf)
     assert (r.rowids.numpy().view(np.uint64) == ids).all()
+
+
+@pytest.mark.timeout(300, method="thread")  # (a lost wake-up would block inside the C call: end the process, do not hang the box)
+def test_two_hundred_native_threads_each_get_their_own_results():
+    """The coalescing queue under the reference's kind of caller (OS threads, no interpreter lock; tests/tools/loadgen.cpp):
+    200 threads x 16 single-query calls must return, call by call, what one thread gets for the same queries — the load
+    generator sums the row ids every call returned.  Parked callers are released by futex word, the device is handed from
+    leader to leader: a lost wake-up hangs this test (pytest's timeout), a mixed-up result changes the sum."""
+    import ctypes as C
+
+    import bench_legs as legs
+    from lancedb_amd._lib import lib
+
+    s = train.synthetic_index(150000, 64, 128, 16, seed=9, skew=0.6)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    rng = np.random.default_rng(5)
+    pool = 512
+    hq = np.ascontiguousarray(rng.normal(size=(pool, 64)), dtype=np.float32)
+    params = _abi.make_params(k=10, nprobe_min=8, nprobe_max=8)
+    params.io_mem = _abi.MEM_HOST
+    L = C.CDLL(legs.build_loadgen())
+    L.loadgen_run.restype = C.c_int32
+    fn = C.cast(lib().mi355_search, C.c_void_p)
+
+    def run(threads, per):
+        sec, chk = C.c_double(0), C.c_uint64(0)
+        st = L.loadgen_run(fn, ix._h, hq.ctypes.data_as(C.c_void_p), C.c_uint32(pool), C.c_uint32(64), C.byref(params), C.c_uint32(10),
+                           C.c_uint32(threads), C.c_uint32(per), C.byref(sec), None, C.byref(chk))
+        assert st == 0
+        return chk.value, threads * per / sec.value
+
+    one, _ = run(1, 3200)
+    for threads, per in ((200, 16), (64, 50), (8, 400)):
+        got, qps = run(threads, per)
+        assert got == one, (threads, got, one)
+        print(f"{threads} native threads: {qps:.0f} QPS")

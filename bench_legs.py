@@ -371,8 +371,9 @@ def width_lines(a, torch, np, dev, shapes=((384, 24, 8), (3072, 192, 8), (768, 9
         outb = out_buffers(torch, dev, B, k)
         ix.set_stream(torch.cuda.current_stream().cuda_stream)
         steps = max(3, a.steps // 3)
-        dt, st, _ = timed_steps(torch, ix, qpool, params, outb, steps, warmup=1)
+        dt, st, last = timed_steps(torch, ix, qpool, params, outb, steps, warmup=1)
         line = scan_line(st, steps, B, dt, torch.cuda.get_device_properties(dev).multi_processor_count)
+        line["rowid_checksum"] = int(torch.as_tensor(last.rowids).to(torch.int64).sum().item())  # (A/B runs: equal results)
         line["config"] = {"workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x{nbits}_nprobe{nprobe}_k{k}_l2", "n_rows": n, "dim": dim, "m": m,
                           "num_bits": nbits, "batch_queries": B,
                           "table": "16-row table; nibbles expanded to one byte per column at pack time" if nbits == 4 else "padded to 32 columns" if m < 32

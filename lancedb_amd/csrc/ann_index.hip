@@ -389,7 +389,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
         ka.partial = ix->w_partial.as<float2>();
         ka.partial_stride = (uint32_t)stride;
       }
-      ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, pl.kk, st));
+      ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
     } else {
       ScanArgs sa;
       sa.ix = view;

@@ -215,7 +215,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     ix->layout = MI355_SCAN_PAIR;
     if (!force_pair && sk_shape(m, &shp)) {  // (4-bit codes are expanded to one byte per column at pack time)
       const uint32_t res_floats = shp.n_slabs > 1 ? shp.M * ix->dsub : d->dim;
-      if (res_floats <= 2048 && sk_scan_lds(res_floats, 8, 5) <= 160u * 1024) {
+      if (res_floats <= 2048 && sk_scan_lds(shp.M, res_floats, 8, 5) <= 160u * 1024) {
         ix->layout = MI355_SCAN_SKEW;
         ix->sk_M = shp.M;
         ix->sk_slabs = shp.n_slabs;

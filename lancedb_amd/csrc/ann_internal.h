@@ -299,7 +299,7 @@ struct SkewArgs;
 int32_t launch_scan_pair(const ScanArgs& sa, dim3 grid, hipStream_t st, uint32_t vpt, uint32_t nt);
 size_t scan_pair_lds(uint32_t m, uint32_t nbits, uint32_t dim, uint32_t lr, uint32_t nt);
 uint32_t scan_pair_m_lds(uint32_t m, uint32_t nbits, uint32_t dim);
-int32_t launch_scan_skew(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint32_t n_blocks, uint32_t kk, hipStream_t st);
+int32_t launch_scan_skew(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st);
 
 struct IndexView;
 int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,

@@ -7,18 +7,37 @@
 #include "kernels_skew.h"
 
 template <int M, bool SLABBED>
-static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_t kk, hipStream_t st) {
-  auto lds_of = [&](int nw, int lr) { return sk_scan_lds(sa.res_floats, nw, lr); };
-#define LAUNCH_SK(LR, NT, MULTI, OPT)                                                           \
+static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st) {
+  auto lds_of = [&](int nw, int lr) { return sk_scan_lds(M, sa.res_floats, nw, lr); };
+#define LAUNCH_SK_(LR, NT, MULTI, OPT, TWO, GRID)                                               \
   {                                                                                             \
-    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT, SLABBED>;                                    \
+    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT, SLABBED, TWO>;                               \
     const size_t lds = lds_of(NT / 64, LR);                                                     \
     if (lds > 160u * 1024)                                                                      \
       return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)lds));                                                     \
-    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(NT), lds, st, sa);                            \
+    hipLaunchKernelGGL(kern, dim3(GRID), dim3(NT), lds, st, sa);                                \
   }
+#define LAUNCH_SK(LR, NT, MULTI, OPT) LAUNCH_SK_(LR, NT, MULTI, OPT, false, n_blocks)
+#ifndef SK_NO_PAIRED_WG
+  // Tables of 32 columns (m <= 32: 128- to 512-d vectors at the reference's dim / 16) are 64 KiB, so TWO eight-wave
+  // workgroups share a CU: a work item of so few columns spends a third of its time building its table and merging,
+  // phases that leave the LDS gather and VALU pipes idle — the other workgroup's scan fills them.
+  if constexpr (M == 32) {
+    const uint32_t grid2 = (uint32_t)std::min<uint64_t>(2ull * n_blocks, std::max<uint64_t>(n_items, 1));
+    if (kk <= 64 && 2 * lds_of(8, 2) <= 160u * 1024) {
+      LAUNCH_SK_(2, 512, false, false, true, grid2)
+      HIP_TRY(hipGetLastError());
+      return MI355_OK;
+    }
+    if (kk > 64 && kk <= 128 && 2 * lds_of(8, 3) <= 160u * 1024) {  // (192-row lists: fits up to ~500 residual floats)
+      LAUNCH_SK_(3, 512, false, false, true, grid2)
+      HIP_TRY(hipGetLastError());
+      return MI355_OK;
+    }
+  }
+#endif
   // kk <= 128: sixteen waves with lists of 128 / 192 rows; beyond: sixteen waves with 192-row
   // lists and optimistic passes of SCAN_PASS_ROWS rows (k_scan_skew OPT) when that fits the LDS,
   // else eight waves with 320-row lists
@@ -30,6 +49,7 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint32_
   else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
   else LAUNCH_SK(5, 512, true, false)
 #undef LAUNCH_SK
+#undef LAUNCH_SK_
   HIP_TRY(hipGetLastError());
   return MI355_OK;
 }

@@ -146,8 +146,10 @@ __host__ __device__ __forceinline__ bool sk_shape(uint32_t m, SkewShape* out) {
   return true;
 }
 // dynamic LDS of a scan workgroup: table + residual (res_floats f32) + nw lists of lr * 64 entries + small words
-__host__ __device__ __forceinline__ size_t sk_scan_lds(uint32_t res_floats, int nw, int lr) {
-  return (size_t)SK_TABLE_BYTES + (((size_t)res_floats * 4 + 15) & ~(size_t)15) + (size_t)nw * lr * 64 * 8 +
+// LDS bytes of a table of M columns per slab: table columns u = 1 .. M + 31; up to M = 32 they all sit in slab 0
+__host__ __device__ constexpr uint32_t sk_table_bytes(uint32_t M) { return M <= 32u ? 65536u : SK_TABLE_BYTES; }
+__host__ __device__ __forceinline__ size_t sk_scan_lds(uint32_t M, uint32_t res_floats, int nw, int lr) {
+  return (size_t)sk_table_bytes(M) + (((size_t)res_floats * 4 + 15) & ~(size_t)15) + (size_t)nw * lr * 64 * 8 +
          (size_t)(2 * nw + 11) * 4 + 128;
 }
 // LUT pitch in dwords: >= m + 32 columns and a power of two, so that the address
@@ -562,8 +564,11 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
 // and with n_slabs > 1 a work item walks the slabs: build table s, scan code slab s with every row's accumulator
 // starting from the row's partial sum of slabs < s (`partial`, written and read back by the same lane), select in the
 // last slab.  Every row sum is still LUT[0] + LUT[1] + ... in j order followed by exact `+ 0.0f` terms.
-template <int M, int LR, int NT, bool MULTI, bool OPT = false, bool SLABBED = false>
-__global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
+// TWO: an eight-wave workgroup that shares its CU with a second one (a 32-column table is 64 KiB): one builds its table or
+// merges while the other scans.  The second launch-bound figure is waves per SIMD: 4 keeps both at <= 128 VGPRs.
+template <int M, int LR, int NT, bool MULTI, bool OPT = false, bool SLABBED = false, bool TWO = false>
+__global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a) {
+  static_assert(!TWO || (NT == 512 && M <= 32), "two workgroups per CU: eight waves and a one-slab table each");
   static_assert(!OPT || (MULTI && LR * 64 >= (int)SK_SAFE_PASS), "OPT rides on the pass machinery");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / MI355_WAVE;
@@ -577,9 +582,10 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lm = sk_phase(lane);
   float* lut = (float*)smem;                                  // [256][P] (dual: two slabs)
-  float* res = (float*)(smem + SK_TABLE_BYTES);               // [dim] (SLABBED: [M * dsub], the current slab's)
+  constexpr uint32_t TABLE_BYTES = sk_table_bytes(M);
+  float* res = (float*)(smem + TABLE_BYTES);                  // [dim] (SLABBED: [M * dsub], the current slab's)
   const uint32_t res_n = SLABBED ? a.res_floats : ix.dim;     // residual elements of the first (only) slab
-  ListEnt* lists = (ListEnt*)(smem + SK_TABLE_BYTES + (((size_t)res_n * 4 + 15) & ~(size_t)15));
+  ListEnt* lists = (ListEnt*)(smem + TABLE_BYTES + (((size_t)res_n * 4 + 15) & ~(size_t)15));
   uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);  // [NW]
   uint32_t* s_part = s_cnt + NW;                              // [NW] every wave's q-th best (sort key), QSHARE
   uint32_t* s_ovf = s_part + NW;                              // [1] OPT: a list overflowed in the optimistic pass
@@ -912,6 +918,24 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       }
     };
 
+    // Both rows of a tile position.  Once a work item holds a bound nearly every position is rejected whole, and that must be
+    // cheap: consume() — twice ~45 instructions, two LDS round trips — has no effect unless a lane passes `d <= thr`, so test
+    // that first for both rows with the same refreshed bound (a NaN fails the compare like consume()'s `d == d`; the fused
+    // form of finalize_dist is the same single rounding: x * 1 - 0, x * 0.5 - 0, x * 1 - (m - 1)).
+    const float fd_scale = ix.metric == MI355_METRIC_COSINE ? 0.5f : 1.0f;
+    const float fd_bias = ix.metric == MI355_METRIC_DOT ? -(float)(ix.m - 1) : -0.0f;
+    [[maybe_unused]] auto consume2 = [&](const sk_f32x2& acc2, uint32_t sa, uint32_t sb, uint32_t tp) {
+      const uint32_t bk = __hip_atomic_load(s_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (bk != 0xFFFFFFFFu) {
+        const float t = f32_from_sort_key(bk);
+        thr = t < thr ? t : thr;
+      }
+      const float d0 = __fmaf_rn(acc2.x, fd_scale, fd_bias), d1 = __fmaf_rn(acc2.y, fd_scale, fd_bias);
+      if (!__any(d0 <= thr || d1 <= thr)) return;
+      consume(acc2.x, sa, tp);
+      consume(acc2.y, sb, tp);
+    };
+
 #ifdef SK_DUAL
     for (uint32_t slab = 0; slab < n_slabs; ++slab) {
     const bool first_slab = !SLABBED || slab == 0, last_slab = !SLABBED || slab + 1 == n_slabs;
@@ -974,6 +998,16 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
       const uint32_t sa = u * SK_CHAINS, sb = sa + 1;
       for (uint32_t n = n0; n < n1; ++n) {
         const uint32_t c0 = n * CPT;
+#ifdef SK_PRIO_ROTATE
+        // dev experiment: the four waves of a SIMD take turns at the issue priority, tile position by tile position, so that
+        // they reach the end of their streams together (the arbiter otherwise favours the oldest wave)
+        switch ((uint32_t)(wid + (wid >> 2) + n) & 3u) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
         if constexpr (SLABBED) {
           if (!first_slab) {
             // ONE statement: wait for this position's partial sums, start x from them, request the next position's into
@@ -995,8 +1029,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
             if constexpr (G == 1) {
               if (n > n0) {  // rows of tile position n-1 are complete on every lane after step 30
                 if (last_slab) {
-                  consume(y.x, sa, n - 1);
-                  consume(y.y, sb, n - 1);
+                  consume2(y, sa, sb, n - 1);
                 } else {
                   park(y, n - 1);
                 }
@@ -1023,8 +1056,7 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
         skew_dchunk<0>(ra[0], rb[0], r, r2, slab_bit, dummy, y);
         skew_dchunk<1>(ra[1 % RING], rb[1 % RING], r, r2, slab_bit, dummy, y);
         if (last_slab) {
-          consume(y.x, sa, n1 - 1);
-          consume(y.y, sb, n1 - 1);
+          consume2(y, sa, sb, n1 - 1);
         } else {
           park(y, n1 - 1);
         }
@@ -1088,6 +1120,9 @@ __global__ __launch_bounds__(NT) void k_scan_skew(SkewArgs a) {
 
 #endif
 
+#ifdef SK_PRIO_ROTATE
+    __builtin_amdgcn_s_setprio(0);
+#endif
     SK_DEV(const unsigned long long dv_pw = wall_clock64();)  // this wave's streams are done
     // ---- block result: exact kk_pass best of all waves' lists, written sorted ----
     if (wl.cnt > kk_pass) wl.compact(lane, idof);

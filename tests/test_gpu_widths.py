@@ -38,8 +38,9 @@ def _pair(oracle, s, metric="l2", raw=None, **kw):
 
 # (m, dsub): the reference's default widths (dsub 16) plus a few that stress the shape rules: m = 1 (dim not divisible
 # by 8), 100 -> two slabs of 64 with 28 padding columns, 112 -> 2 x 64 (16 padding), 144 -> 2 x 80, 240 -> 3 x 80,
-# 288 -> 3 x 96 exactly, 300 -> 4 slabs
-WIDTHS = [(8, 16), (16, 16), (24, 16), (60, 16), (128, 16), (192, 16), (1, 20), (2, 4), (33, 8), (100, 4), (112, 8),
+# 288 -> 3 x 96 exactly, 300 -> 4 slabs.  Tables of 32 columns (m <= 32) run as two eight-wave workgroups per CU for k <= 64,
+# and for k <= 128 while two sets of 192-row lists fit beside the residuals (m = 32 x 16 does not: 512-d residuals)
+WIDTHS = [(8, 16), (16, 16), (24, 16), (32, 16), (32, 4), (60, 16), (128, 16), (192, 16), (1, 20), (2, 4), (33, 8), (100, 4), (112, 8),
           (144, 4), (240, 2), (288, 4), (300, 2)]
 
 

@@ -85,6 +85,15 @@ __host__ __device__ __forceinline__ uint32_t sk_phase(uint32_t l) {
 #endif
 }
 
+__device__ __forceinline__ void sk_rotate_prio(uint32_t turn) {  // (s_setprio takes an immediate)
+  switch (turn & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 // Unit w of a partition = the SK_CHAINS streams w*SK_CHAINS .. scanned together by
 // one wave.  Its chains are padded to the tile count of its first stream.
 __host__ __device__ __forceinline__ uint32_t sk_unit_tiles(uint32_t n_tiles, uint32_t w) {
@@ -998,16 +1007,11 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       const uint32_t sa = u * SK_CHAINS, sb = sa + 1;
       for (uint32_t n = n0; n < n1; ++n) {
         const uint32_t c0 = n * CPT;
-#ifdef SK_PRIO_ROTATE
-        // dev experiment: the four waves of a SIMD take turns at the issue priority, tile position by tile position, so that
-        // they reach the end of their streams together (the arbiter otherwise favours the oldest wave)
-        switch ((uint32_t)(wid + (wid >> 2) + n) & 3u) {
-          case 0: __builtin_amdgcn_s_setprio(0); break;
-          case 1: __builtin_amdgcn_s_setprio(1); break;
-          case 2: __builtin_amdgcn_s_setprio(2); break;
-          default: __builtin_amdgcn_s_setprio(3); break;
-        }
-#endif
+        // The SIMD's arbiter favours its oldest wave: left alone, the four waves of a SIMD finish their streams one after
+        // the other and the last one runs ~16 us of a 52 us scan with idle pipes around it.  They take turns at the issue
+        // priority instead, tile position by tile position (wid + wid / 4 differs between the waves of a SIMD whichever
+        // way waves map to SIMDs): C3-shaped scan 14.96 -> 14.26 ms per 1024 queries (profiles/r04_j_*).
+        sk_rotate_prio((uint32_t)(wid + (wid >> 2)) + n);
         if constexpr (SLABBED) {
           if (!first_slab) {
             // ONE statement: wait for this position's partial sums, start x from them, request the next position's into
@@ -1120,9 +1124,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
 
 #endif
 
-#ifdef SK_PRIO_ROTATE
     __builtin_amdgcn_s_setprio(0);
-#endif
     SK_DEV(const unsigned long long dv_pw = wall_clock64();)  // this wave's streams are done
     // ---- block result: exact kk_pass best of all waves' lists, written sorted ----
     if (wl.cnt > kk_pass) wl.compact(lane, idof);

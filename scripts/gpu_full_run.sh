@@ -7,11 +7,13 @@ O=${1:-gpurun_out/full_run}
 mkdir -p $O
 export PYTHONFAULTHANDLER=1
 S=$(date +%s)
-timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 > $O/pytest.txt 2>&1
 echo "pytest rc=$? wall=$(( $(date +%s) - S ))s"; tail -3 $O/pytest.txt
+if [ -z "$SKIP_SYSTEM_RUNTIME_PASS" ]; then
 S=$(date +%s)
-MI355_HIP_RUNTIME=system timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest_system_runtime.txt 2>&1
+MI355_HIP_RUNTIME=system timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/pytest_system_runtime.txt 2>&1
 echo "pytest (MI355_HIP_RUNTIME=system, torch-free) rc=$? wall=$(( $(date +%s) - S ))s"; tail -3 $O/pytest_system_runtime.txt
+fi
 S=$(date +%s)
 timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench rc=$? wall=$(( $(date +%s) - S ))s"; tail -3 $O/bench_default.err | cut -c1-300

@@ -380,7 +380,15 @@ enum {
   MI355_FLAT_CHECKSUM = 1u,
   /* accumulate the GEMM kernel's own device time (HIP events recorded around its launches on the
      search stream, no host synchronisation) until the next configure(): mi355_flat_last_stats */
-  MI355_FLAT_PROFILE = 2u
+  MI355_FLAT_PROFILE = 2u,
+  /* Path choice.  By default a search takes the cheaper of the two exact paths by a cost model of the
+     call (rows x queries): the bf16 MFMA filter + exact re-rank pays ~0.3 ms of fixed launches and pads
+     the batch to whole 256-query tiles, the exact sweep re-reads the column once per query — a single
+     query, or a table of a few hundred thousand rows, is faster swept.  Both return the same bits.
+     These two pin the choice (tests and A/B runs; FILTER is ignored when the call cannot be filtered:
+     lower bound, prefilter, a column opened without filter data). */
+  MI355_FLAT_FORCE_FILTER = 4u,
+  MI355_FLAT_FORCE_SWEEP = 8u
 };
 int32_t mi355_flat_configure(mi355_flat *flat, uint32_t gemm_variant,
                              uint32_t grid_workgroups, uint32_t flags);

@@ -59,6 +59,8 @@ FLAT_GEMM_8PHASE = 4
 FLAT_GEMM_8PHASE_REF = 5
 FLAT_CHECKSUM = 1
 FLAT_PROFILE = 2
+FLAT_FORCE_FILTER = 4
+FLAT_FORCE_SWEEP = 8
 
 SHARD_COARSE = 1
 SHARD_NO_OVERLAP = 2

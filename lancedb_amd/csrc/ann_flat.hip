@@ -324,6 +324,7 @@ extern "C" int32_t mi355_flat_close(mi355_flat* f) {
                     &f->shadow,  &f->vv,      &f->vw_cos,  &f->vw_dot, &f->vmax, &f->g_qb,   &f->g_qa,   &f->g_qg,   &f->g_slack,
                     &f->g_tau,   &f->g_gm,    &f->g_seg, &f->g_cnt, &f->g_cand, &f->w_filter, &f->w_sum, &f->w_fallback};
   for (DevBuf* b : bufs) b->release();
+  if (f->h_pin) (void)hipHostFree(f->h_pin);
   for (auto* v : {&f->ev_free, &f->ev_pending})
     for (auto& fe : *v)
       for (auto& e : fe.ev) (void)hipEventDestroy(e);
@@ -363,13 +364,26 @@ int32_t run_flat_search_device(mi355_flat* f, const float* d_q, uint32_t nq, con
   RowFilter flt;
   ST_TRY(make_row_filter(p, f->w_filter, st, &flt));
   // (the filter's k-th-best bound assumes every row is eligible: prefiltered searches sweep exactly)
-  const bool use_mfma = f->mfma && !p->has_lower_bound && flt.mode == MI355_FILTER_NONE;
+  bool use_mfma = f->mfma && !p->has_lower_bound && flt.mode == MI355_FILTER_NONE;
+  if (use_mfma && (f->cfg_flags & MI355_FLAT_FORCE_SWEEP)) use_mfma = false;
+  if (use_mfma && !(f->cfg_flags & MI355_FLAT_FORCE_FILTER) && f->gemm_variant == MI355_FLAT_GEMM_AUTO) {
+    // Both paths are exact and return the same bits; take the cheaper one for THIS call (measured on MI355X,
+    // tests/tools/flat_path_time.py): the sweep reads the column once per query at ~2.5 TB/s
+    // behind ~30 us of launches; the filter runs whole 256-query GEMM tiles at ~1 PFLOP/s behind ~0.3 ms of launches
+    // (query prep, GEMM, segment minima, thresholds, compaction, re-rank) and re-ranks a few hundred rows per query.
+    const double col_bytes = (double)f->n_rows * f->dim * (f->dtype == MI355_DTYPE_F32 ? 4.0 : 2.0);
+    const double sweep_us = 30.0 + (double)nq * col_bytes / 2.5e6;
+    const double tiles = (double)((nq + 255u) / 256u);
+    const double filter_us = 300.0 + tiles * (double)f->n_rows * 256.0 * (double)f->dimp * 2.0 / 1.0e9;
+    use_mfma = filter_us < sweep_us;
+  }
   f->last_path = use_mfma ? 1 : 2;
   if (use_mfma) {
     ST_TRY(run_flat_mfma(f, d_q, nq, metric, k, rng, d_ids, d_dist, d_cnt));
   } else {
-  // enough work items to fill 256 CUs, at least 1024 rows each
-  uint32_t slice = (uint32_t)std::max<uint64_t>(1024, (f->n_rows + 2047) / 2048);
+  // enough work items to fill 256 CUs; at least one row per thread of a 256-thread block (a table of 100 k rows is
+  // 391 blocks of one row per thread: the call's time is then one row's chain, not four)
+  uint32_t slice = (uint32_t)std::max<uint64_t>(256, (f->n_rows + 2047) / 2048);
   slice = (slice + 255u) & ~255u;
   const uint32_t n_slices = (uint32_t)std::max<uint64_t>(1, (f->n_rows + slice - 1) / slice);
   // the per-slice candidate slots stay within ~2 GiB
@@ -433,23 +447,58 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
   uint64_t* d_ids = out_rowids;
   float* d_dist = out_dist;
   uint32_t* d_cnt = out_counts;
+  // Small host batches (single queries: BASELINE configs[0]) travel through ONE page-locked block, as on the IVF-PQ
+  // handle: pageable copies stage (and, device-to-host, block) per call — four round trips for one query's results.
+  const size_t q_bytes = sizeof(float) * (size_t)n_queries * f->dim;
+  const size_t q_pad = (q_bytes + 63) & ~(size_t)63;
+  const size_t r_bytes = (size_t)n_queries * k * (sizeof(uint64_t) + sizeof(float)) + sizeof(uint32_t) * (size_t)n_queries;
+  const bool pinned = host_io && q_pad + r_bytes <= ((size_t)4 << 20);
   if (host_io) {
-    ST_TRY(f->w_q.ensure(sizeof(float) * (size_t)n_queries * f->dim));
-    ST_TRY(f->w_ids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
-    ST_TRY(f->w_dist.ensure(sizeof(float) * (size_t)n_queries * k));
-    ST_TRY(f->w_cnt.ensure(sizeof(uint32_t) * n_queries));
-    HIP_TRY(hipMemcpyAsync(f->w_q.p, queries, sizeof(float) * (size_t)n_queries * f->dim, hipMemcpyHostToDevice, st));
+    ST_TRY(f->w_q.ensure(q_bytes));
+    if (pinned) {
+      const size_t need = q_pad + r_bytes + 64;
+      if (f->h_pin_cap < need) {
+        if (f->h_pin) (void)hipHostFree(f->h_pin);
+        f->h_pin = nullptr;
+        f->h_pin_cap = 0;
+        HIP_TRY(hipHostMalloc(&f->h_pin, need * 2, hipHostMallocDefault));
+        f->h_pin_cap = need * 2;
+      }
+      memcpy(f->h_pin, queries, q_bytes);
+      HIP_TRY(hipMemcpyAsync(f->w_q.p, f->h_pin, q_bytes, hipMemcpyHostToDevice, st));
+      ST_TRY(f->w_ids.ensure(r_bytes));  // ids | distances | counts carved out of one buffer: one copy back
+      d_ids = f->w_ids.as<uint64_t>();
+      d_dist = (float*)(d_ids + (size_t)n_queries * k);
+      d_cnt = (uint32_t*)(d_dist + (size_t)n_queries * k);
+    } else {
+      ST_TRY(f->w_ids.ensure(sizeof(uint64_t) * (size_t)n_queries * k));
+      ST_TRY(f->w_dist.ensure(sizeof(float) * (size_t)n_queries * k));
+      ST_TRY(f->w_cnt.ensure(sizeof(uint32_t) * n_queries));
+      HIP_TRY(hipMemcpyAsync(f->w_q.p, queries, q_bytes, hipMemcpyHostToDevice, st));
+      d_ids = f->w_ids.as<uint64_t>();
+      d_dist = f->w_dist.as<float>();
+      d_cnt = f->w_cnt.as<uint32_t>();
+    }
     d_q = f->w_q.as<float>();
-    d_ids = f->w_ids.as<uint64_t>();
-    d_dist = f->w_dist.as<float>();
-    d_cnt = f->w_cnt.as<uint32_t>();
   }
   ST_TRY(run_flat_search_device(f, d_q, n_queries, p, d_ids, d_dist, d_cnt));
   if (host_io) {
-    HIP_TRY(hipMemcpyAsync(out_rowids, d_ids, sizeof(uint64_t) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (pinned) {
+      unsigned char* h_res = (unsigned char*)f->h_pin + q_pad;
+      HIP_TRY(hipMemcpyAsync(h_res, d_ids, r_bytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      const uint64_t* r_ids = (const uint64_t*)h_res;
+      const float* r_dist = (const float*)(r_ids + (size_t)n_queries * k);
+      const uint32_t* r_cnt = (const uint32_t*)(r_dist + (size_t)n_queries * k);
+      memcpy(out_rowids, r_ids, sizeof(uint64_t) * (size_t)n_queries * k);
+      memcpy(out_dist, r_dist, sizeof(float) * (size_t)n_queries * k);
+      memcpy(out_counts, r_cnt, sizeof(uint32_t) * n_queries);
+    } else {
+      HIP_TRY(hipMemcpyAsync(out_rowids, d_ids, sizeof(uint64_t) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(float) * (size_t)n_queries * k, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(uint32_t) * n_queries, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
     if (p->timeout_ms) {
       auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
       if (ms > (long long)p->timeout_ms)
@@ -464,7 +513,9 @@ extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, ui
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   if (gemm_variant > MI355_FLAT_GEMM_8PHASE_REF || gemm_variant == 3)
     return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
-  if (flags & ~(uint32_t)(MI355_FLAT_CHECKSUM | MI355_FLAT_PROFILE)) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
+  if ((flags & MI355_FLAT_FORCE_FILTER) && (flags & MI355_FLAT_FORCE_SWEEP))
+    return fail(MI355_ERR_INVALID_INPUT, "MI355_FLAT_FORCE_FILTER and MI355_FLAT_FORCE_SWEEP exclude each other");
+  if (flags & ~(uint32_t)(MI355_FLAT_CHECKSUM | MI355_FLAT_PROFILE | MI355_FLAT_FORCE_FILTER | MI355_FLAT_FORCE_SWEEP)) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
   std::lock_guard<std::mutex> lk(f->mu);
   f->gemm_variant = gemm_variant;
   f->grid_workgroups = grid_workgroups;

@@ -253,6 +253,8 @@ struct mi355_flat {
   DevBuf vectors, row_ids;
   bool has_row_ids = false;
   DevBuf w_q, w_cand, w_ids, w_dist, w_cnt;
+  void* h_pin = nullptr;  // page-locked staging of small host-I/O calls (queries in, the three result arrays out)
+  size_t h_pin_cap = 0;
   // MFMA filter + exact re-rank (kernels_flat_mfma.h)
   bool mfma = false;      // built at open when the column is large enough
   bool shadowed = false;  // GEMM reads a bf16 shadow (column is f32/f16 or dim % 64 != 0)

@@ -721,7 +721,8 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       };
       // sub-vector lengths 4 / 8 / 16 (dim / m of the reference's defaults, index/vector.rs:306-310: 768 / 96,
       // 1536 / 96): whole entries as 16-B loads, 8 of them in flight per thread, the chain in element order
-      auto lut_fast = [&](auto ds_tag, auto ks_tag) {
+      auto lut_fast_m = [&](auto ds_tag, auto ks_tag, auto dot_tag) {
+        constexpr bool dotm = decltype(dot_tag)::value;  // (shadows the run-time flag: no metric branch inside the chains)
         constexpr int DS = decltype(ds_tag)::value;
         constexpr uint32_t KSUB = decltype(ks_tag)::value;  // table rows that exist: 256, or 16 (4-bit PQ)
         constexpr int V = DS / 4;    // 16-B pieces per codebook entry
@@ -774,6 +775,10 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
             }
           }
         }
+      };
+      auto lut_fast = [&](auto ds_tag, auto ks_tag) {
+        if (dotm) lut_fast_m(ds_tag, ks_tag, std::true_type{});
+        else lut_fast_m(ds_tag, ks_tag, std::false_type{});
       };
       constexpr std::integral_constant<uint32_t, 256u> K256{};
       constexpr std::integral_constant<uint32_t, 16u> K16{};

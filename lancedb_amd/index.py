@@ -282,9 +282,13 @@ class FlatIndex(_Handle):
     def sync(self):
         check(lib().mi355_flat_sync(self._h))
 
-    def configure(self, gemm_variant=_abi.FLAT_GEMM_AUTO, grid_workgroups=0, checksum=False, profile=False):
-        """Tuning of the GEMM filter (include/mi355_ann.h mi355_flat_configure)."""
+    def configure(self, gemm_variant=_abi.FLAT_GEMM_AUTO, grid_workgroups=0, checksum=False, profile=False, path=None):
+        """Tuning of the GEMM filter (include/mi355_ann.h mi355_flat_configure).  `path`: None = the cheaper exact path
+        per call, "filter" = MFMA filter + exact re-rank whenever the call allows it, "sweep" = the exact sweep."""
         flags = (_abi.FLAT_CHECKSUM if checksum else 0) | (_abi.FLAT_PROFILE if profile else 0)
+        if path not in (None, "filter", "sweep"):
+            raise ValueError("path must be None, 'filter' or 'sweep'")
+        flags |= _abi.FLAT_FORCE_FILTER if path == "filter" else _abi.FLAT_FORCE_SWEEP if path == "sweep" else 0
         check(lib().mi355_flat_configure(self._h, C.c_uint32(gemm_variant), C.c_uint32(grid_workgroups), C.c_uint32(flags)))
 
     def stats(self):

@@ -85,6 +85,7 @@ def test_flat_limits_beyond_one_selection_pass(oracle):
     v[500:1500] = v[500]  # a thousand exact ties
     q = np.concatenate([v[[500]], rng.normal(size=(140, 72)).astype(np.float32)])
     f = lancedb_amd.FlatIndex(v)
+    f.configure(path="filter")  # (a table this small is swept by default: the cheaper of the two exact paths)
     for metric in ("l2", "cosine", "dot"):
         mt = _abi.METRIC_NAMES[metric]
         for k in (300, 1000, 2500):

@@ -88,6 +88,7 @@ def test_flat_distances_are_within_1e4_of_float64_and_find_the_float64_neighbour
     v = rng.normal(size=(30000, 768)).astype(np.float32)
     q = rng.normal(size=(16, 768)).astype(np.float32)
     fl = lancedb_amd.FlatIndex(v)
+    fl.configure(path="filter")  # (the bar is about the bf16 filter; 16 queries on 30 k rows would be swept by default)
     got = fl.search(q, k=10, metric=_abi.METRIC_NAMES[metric])
     assert fl.info()[0] == 1, "the MFMA filter path did not run"
     for i in range(len(q)):

@@ -365,6 +365,7 @@ def test_flat_mfma_filter_is_exact_on_adversarial_columns(oracle):
     q = np.concatenate([v[[100, 5000, 6000, 6002]], rng.normal(size=(127, dim)).astype(np.float32)])
     f = lancedb_amd.FlatIndex(v)
     assert f.info()[1] == 1
+    f.configure(path="filter")  # (by default the cheaper exact path per call: this table would be swept)
     for metric in ("l2", "cosine", "dot"):
         mt = _abi.METRIC_NAMES[metric]
         for k in (1, 10, 200):
@@ -390,6 +391,7 @@ def test_flat_mfma_bf16_column_c2_shape(oracle):
     rid = rng.permutation(n).astype(np.uint64)
     q = rng.normal(size=(256, dim)).astype(np.float32)
     f = lancedb_amd.FlatIndex(bf, rid, dtype=_abi.DTYPE_BF16)
+    f.configure(path="filter")
     for metric in ("l2", "cosine"):
         mt = _abi.METRIC_NAMES[metric]
         _assert_same(f.search(q, k=10, metric=mt),
@@ -604,3 +606,24 @@ def test_flat_adversarial_columns_on_the_eight_phase_schedule(oracle):
             for k in (1, 10, 200):
                 _assert_same(f.search(q, k=k, metric=mt), oracle.flat_search(v, q, k=k, metric=mt))
                 assert f.info()[0] == 1
+
+
+def test_flat_takes_the_cheaper_exact_path_per_call_and_both_return_the_same(oracle):
+    """Flat search (python/python/lancedb/query.py:1365-1370) has two exact paths; by default the call's size picks one
+    (csrc/ann_flat.hip, run_flat_search_device): a single query sweeps, a batch of hundreds runs the MFMA filter.  The
+    `path` pins (`MI355_FLAT_FORCE_FILTER` / `_SWEEP`) and the default must agree bit for bit, host and device I/O."""
+    rng = np.random.default_rng(23)
+    v = rng.normal(size=(20000, 64)).astype(np.float32)
+    q = rng.normal(size=(300, 64)).astype(np.float32)
+    f = lancedb_amd.FlatIndex(v)
+    for nq, default_path in ((1, 2), (3, 2), (300, 1)):
+        exp = oracle.flat_search(v, q[:nq], k=10)
+        for path, took in ((None, default_path), ("filter", 1), ("sweep", 2)):
+            f.configure(path=path)
+            _assert_same(f.search(q[:nq], k=10), exp)
+            assert f.info()[0] == took, (nq, path)
+    with pytest.raises(Exception):
+        check_both = _abi.FLAT_FORCE_FILTER | _abi.FLAT_FORCE_SWEEP
+        from lancedb_amd._lib import check, lib
+        import ctypes as C
+        check(lib().mi355_flat_configure(f._h, C.c_uint32(0), C.c_uint32(0), C.c_uint32(check_both)))

@@ -6,9 +6,6 @@
 #include <thread>
 
 #include "ann_internal.h"
-#include <linux/futex.h>
-#include <sys/syscall.h>
-#include <unistd.h>
 #include "kernels_ivfpq.h"
 #include "kernels_skew.h"
 
@@ -367,15 +364,6 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   return MI355_OK;
 }
 
-// Linux futex on a 32-bit word of the handle (std::atomic<uint32_t> is a plain aligned uint32_t on this ABI)
-static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
-static void futex_wait(std::atomic<uint32_t>* a, uint32_t expected) {
-  (void)syscall(SYS_futex, (uint32_t*)a, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);  // EAGAIN / EINTR: the caller re-checks
-}
-static void futex_wake_all(std::atomic<uint32_t>* a) {
-  (void)syscall(SYS_futex, (uint32_t*)a, FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0);
-}
-
 static bool same_search(const mi355_search_params* a, const mi355_search_params* b) {
   return a->k == b->k && a->nprobe_min == b->nprobe_min && a->nprobe_max == b->nprobe_max &&
          a->refine_factor == b->refine_factor && a->metric == b->metric && a->has_lower_bound == b->has_lower_bound &&
@@ -407,10 +395,7 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
     std::lock_guard<std::mutex> lk(ix->mu);
     return search_locked(ix, calls, p, sh, ext_probes, ext_nprobe);
   }
-  // ---- coalescing queue (SURVEY.md §8b threading: callers are tokio workers, python/src/runtime.rs:31-37;
-  // BaseTable: Send + Sync, table.rs:549).  A caller that finds the handle busy parks its request; the
-  // thread that owns the device takes every parked request with the same parameters into ONE device
-  // batch when it starts, so N concurrent single-query calls cost about one launch sequence.
+  // ---- coalescing queue (call_queue.h): N concurrent single-query calls cost about one launch sequence
   PendingSearch me;
   me.queries = queries;
   me.nq = n_queries;
@@ -419,68 +404,14 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
   me.out_dist = out_dist;
   me.out_counts = out_counts;
   std::vector<PendingSearch*> served;
-  {
-    std::unique_lock<std::mutex> ql(ix->qmu);
-    if (ix->busy) {
-      me.cohort = ix->collect_gen & 1u;
-      ix->queue.push_back(&me);
-      ql.unlock();
-      std::atomic<uint32_t>& word = ix->wake_word[me.cohort];
-      uint32_t st;
-      for (;;) {  // the word is read BEFORE the state: a wake between the two makes the kernel's compare fail
-        const uint32_t w = word.load(std::memory_order_acquire);
-        st = me.state.load(std::memory_order_acquire);
-        if (st != QS_PARKED) break;
-        futex_wait(&word, w);
-      }
-      if (st == QS_SERVED) {
-        if (me.status != MI355_OK) return fail(me.status, "%s", me.error.c_str());
-        return MI355_OK;
-      }
-      // nobody served it: the finished leader took it off the queue and handed it the device (busy stays set)
-      ql.lock();
-    }
-    ix->busy = true;
-    // Batching window (round 4).  Closed-loop callers split into two cohorts that alternate — the calls that arrived while
-    // batch n ran form batch n + 1, whose callers are back just AFTER batch n + 2 was collected — so 64 callers ran as
-    // batches of ~32 (35 k QPS against 45 k for batches of 64).  When the last batch served more than one call, the
-    // leader waits for stragglers: until nothing new has arrived for ~15 us, at most ~60 us + 1 us per caller of the last
-    // batch (one futex call wakes them all, but the kernel releases them one by one) — a single caller never waits.
-    if (ix->last_batch_calls > 1) {
-      using clk = std::chrono::steady_clock;
-      const auto cap = std::chrono::microseconds(60 + (ix->last_batch_calls < 512u ? ix->last_batch_calls : 512u));
-      const auto t0 = clk::now();
-      auto t_last = t0;
-      size_t seen = ix->queue.size();
-      for (;;) {
-        ql.unlock();
-        std::this_thread::yield();
-        ql.lock();
-        const auto now = clk::now();
-        if (ix->queue.size() > seen) {
-          seen = ix->queue.size();
-          t_last = now;
-        }
-        if (now - t_last > std::chrono::microseconds(15) || now - t0 > cap || seen >= ix->last_batch_calls * 2u) break;
-      }
-    }
-    ++ix->collect_gen;  // later arrivals sleep on the other word
-    uint32_t total = n_queries;
-    for (auto it = ix->queue.begin(); it != ix->queue.end();) {
-      if (same_search(p, (*it)->params) && total + (*it)->nq <= 4096) {
-        total += (*it)->nq;
-        served.push_back(*it);
-        calls.push_back({(*it)->queries, (*it)->nq, (*it)->out_rowids, (*it)->out_dist, (*it)->out_counts});
-        it = ix->queue.erase(it);
-      } else {
-        ++it;
-      }
-    }
+  if (!ix->cq.enter(me, [&](const PendingSearch& o) { return same_search(p, o.params); }, 4096u, served)) {
+    if (me.status != MI355_OK) return fail(me.status, "%s", me.error.c_str());  // (the batch that carried it failed)
+    return MI355_OK;
   }
+  for (PendingSearch* o : served) calls.push_back({o->queries, o->nq, o->out_rowids, o->out_dist, o->out_counts});
   int32_t status;
   {
     std::lock_guard<std::mutex> lk(ix->mu);
-    ix->last_batch_calls = (uint32_t)calls.size();
     status = search_locked(ix, calls, p, sh, nullptr, 0);
   }
   std::string err;
@@ -489,33 +420,7 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
     mi355_last_error(buf, sizeof buf);
     err = buf;
   }
-  // Wake-ups are targeted (round 4): one shared condition variable used to wake EVERY parked caller after every batch —
-  // with 256 callers ~128 threads that had nothing to collect, all queueing for qmu against the next leader.  Now the callers
-  // a batch served share a futex word and leave without the lock; a successor, if somebody parked meanwhile, is handed the
-  // device directly.  A PendingSearch lives on its caller's stack: its state is stored LAST and it is not touched after that.
-  uint32_t wake_mask = 0;
-  {
-    std::lock_guard<std::mutex> ql(ix->qmu);
-    if (!ix->queue.empty()) {
-      PendingSearch* next = ix->queue.front();
-      ix->queue.erase(ix->queue.begin());
-      wake_mask |= 1u << next->cohort;
-      next->state.store(QS_LEAD, std::memory_order_release);
-    } else {
-      ix->busy = false;
-    }
-    for (PendingSearch* f : served) {
-      f->status = status;
-      f->error = err;
-      wake_mask |= 1u << f->cohort;
-      f->state.store(QS_SERVED, std::memory_order_release);
-    }
-  }
-  for (uint32_t c = 0; c < 2; ++c)
-    if (wake_mask >> c & 1u) {
-      ix->wake_word[c].fetch_add(1u, std::memory_order_release);
-      futex_wake_all(&ix->wake_word[c]);
-    }
+  ix->cq.leave(served, status, err);
   return status;
 }
 

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/mi355_ann.h"
+#include "call_queue.h"
 #include "device_common.h"
 
 // ------------------------------------------------------------------ errors --
@@ -158,22 +159,14 @@ struct GraphEntry {
   uint64_t work_items = 0;
 };
 
-// one waiting host-I/O search of the coalescing queue
-struct PendingSearch {
+// one waiting host-I/O search of the coalescing queue (call_queue.h)
+struct PendingSearch : QueueWaiter {
   const float* queries;
-  uint32_t nq;
   const mi355_search_params* params;
   uint64_t* out_rowids;
   float* out_dist;
   uint32_t* out_counts;
-  int32_t status = MI355_OK;
-  std::string error;
-  // 0 = parked, QS_SERVED = another caller's batch carried it (status / error are final), QS_LEAD = handed the device: this
-  // caller runs the next batch.  Written last by the thread that decides, read without the queue lock by the owner.
-  std::atomic<uint32_t> state{0};
-  uint32_t cohort = 0;  // which of the handle's two wake words it sleeps on (parity of the collection it arrived before)
 };
-enum : uint32_t { QS_PARKED = 0, QS_SERVED = 1, QS_LEAD = 2 };
 
 struct mi355_index {
   int32_t device = 0;
@@ -230,17 +223,7 @@ struct mi355_index {
   mi355_stats stats{};
   std::vector<EventSet> ev_free, ev_pending;
   std::map<GraphKey, GraphEntry> graphs;
-  // coalescing queue (guarded by qmu): callers that find the handle busy park here and the
-  // thread that owns the device batches every compatible request it finds when it is done
-  std::mutex qmu;
-  std::vector<PendingSearch*> queue;
-  bool busy = false;
-  // Parked callers sleep on one of two futex words (Linux; the product is ROCm-only): everything a batch collects arrived
-  // before that collection and shares a word, so ONE wake call releases the callers a batch served, none of them needs the
-  // queue lock to leave, and the callers that parked meanwhile (the other word) sleep on.
-  uint32_t collect_gen = 0;
-  std::atomic<uint32_t> wake_word[2] = {{0}, {0}};
-  uint32_t last_batch_calls = 0;  // calls the last coalesced batch served (> 1 arms the leader's batching window)
+  CallQueue<PendingSearch> cq;  // coalescing queue of concurrent host-I/O callers (call_queue.h)
 };
 
 struct mi355_flat {

@@ -206,3 +206,25 @@ def test_bench_helpers_host_cores_and_summary():
     assert s["c5_qps"] is None  # absent legs stay visible as null
     import json
     assert len(json.dumps(s)) < 2000  # the driver keeps the last 2000 characters of the line
+
+
+def test_coalescing_queue_under_thread_sanitizer(tmp_path):
+    """The handle's coalescing queue (csrc/call_queue.h: futex-word wake-ups, direct hand-over of the device, batching
+    window) compiled alone with ThreadSanitizer and driven by 48 CPU threads — a mutex-free stand-in for the device checks
+    exclusive ownership, every call runs in exactly one batch, failed batches reach every caller they carried, and a lost
+    wake-up would hang (timeout).  tests/test_gpu_concurrency.py runs the same header inside the library on the GPU."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "queue_stress")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", os.path.join(root, "lancedb_amd", "csrc"),
+           os.path.join(root, "tests", "tools", "queue_stress.cpp"), "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("this toolchain has no ThreadSanitizer runtime")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, "48", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout + r.stderr)[-3000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]

@@ -1,0 +1,78 @@
+// queue_stress.cpp — TEST TOOL: the handle's coalescing queue (lancedb_amd/csrc/call_queue.h, the very header the library
+// compiles) driven by N threads on the CPU, with a mutex standing in for the device.  Built with -fsanitize=thread by
+// tests/test_build_host.py: data races in the hand-over (who may touch a parked request, when), lost wake-ups (the
+// program would hang: the test runs it under a timeout) and mixed-up results all show here, without a GPU.
+//
+//   g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -I lancedb_amd/csrc tests/tools/queue_stress.cpp -o queue_stress
+//   ./queue_stress [threads] [calls per thread]      -> "ok ..." and exit code 0
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "call_queue.h"
+
+struct Req : QueueWaiter {
+  int param = 0;          // only requests with equal parameters share a batch
+  uint64_t payload = 0;   // "query"
+  uint64_t result = 0;    // "output buffer" of the caller, written by whoever runs the batch
+};
+
+int main(int argc, char** argv) {
+  const unsigned n_threads = argc > 1 ? (unsigned)atoi(argv[1]) : 48, per = argc > 2 ? (unsigned)atoi(argv[2]) : 400;
+  CallQueue<Req> q;
+  std::atomic<int> in_device{0};
+  std::atomic<uint64_t> batches{0}, carried{0}, failed_calls{0}, errors{0}, biggest{0};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < n_threads; ++t)
+    th.emplace_back([&, t] {
+      for (unsigned i = 0; i < per; ++i) {
+        Req me;
+        me.nq = 1 + (t + i) % 3;
+        me.param = (int)(t % 3);
+        me.payload = ((uint64_t)t << 32) | i;
+        std::vector<Req*> served;
+        int32_t status;
+        if (q.enter(me, [&](const Req& o) { return o.param == me.param; }, 64u, served)) {
+          // this caller owns the device: nobody else may be in here
+          if (in_device.fetch_add(1) != 0) errors.fetch_add(1);
+          uint32_t total = me.nq;
+          for (Req* o : served) {
+            if (o->param != me.param) errors.fetch_add(1);
+            total += o->nq;
+          }
+          if (total > 64u) errors.fetch_add(1);
+          const uint64_t b = batches.fetch_add(1);
+          status = (b % 97 == 96) ? 7 : 0;  // every 97th batch "fails": its callers must all see the error
+          if (status == 0) {
+            me.result = me.payload * 3 + 1;
+            for (Req* o : served) o->result = o->payload * 3 + 1;
+          }
+          carried.fetch_add(served.size() + 1);
+          uint64_t big = biggest.load();
+          while (served.size() + 1 > big && !biggest.compare_exchange_weak(big, served.size() + 1)) {
+          }
+          if ((b & 7) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (a batch takes a while)
+          in_device.fetch_sub(1);
+          q.leave(served, status, status ? "boom" : "");
+        } else {
+          status = me.status;
+          if (status != 0 && me.error != "boom") errors.fetch_add(1);
+        }
+        if (status == 0) {
+          if (me.result != me.payload * 3 + 1) errors.fetch_add(1);
+        } else {
+          failed_calls.fetch_add(1);
+        }
+      }
+    });
+  for (auto& x : th) x.join();
+  const uint64_t calls = (uint64_t)n_threads * per;
+  if (carried.load() != calls) errors.fetch_add(1);  // every call ran in exactly one batch
+  if (q.busy || !q.queue.empty()) errors.fetch_add(1);
+  std::printf("%s: %llu calls in %llu batches (largest %llu), %llu calls saw their batch fail, %llu errors\n",
+              errors.load() ? "FAILED" : "ok", (unsigned long long)calls, (unsigned long long)batches.load(),
+              (unsigned long long)biggest.load(), (unsigned long long)failed_calls.load(), (unsigned long long)errors.load());
+  return errors.load() ? 1 : 0;
+}

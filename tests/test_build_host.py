@@ -225,6 +225,7 @@ def test_coalescing_queue_under_thread_sanitizer(tmp_path):
     if b.returncode != 0 and "sanitize" in b.stderr:
         pytest.skip("this toolchain has no ThreadSanitizer runtime")
     assert b.returncode == 0, b.stderr[-2000:]
-    r = subprocess.run([exe, "48", "300"], capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")}  # (scripts/asan_abi_tests.sh preloads ASan)
+    r = subprocess.run([exe, "48", "300"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout + r.stderr)[-3000:]
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]

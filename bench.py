@@ -114,7 +114,8 @@ def main_flat(a):
         raise SystemExit("--workload flat is a single-GPU line (rows shard over ranks through mi355_flat_search_sharded)")
     res = flat_c2(a, a.flat_metric, cpu_queries=32 if a.cpu_seconds > 0 else 0)
     res.update({"n_gpus": 1, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None})
-    print(json.dumps(res), flush=True)
+    import bench_legs as legs
+    legs.emit(res)
 
 
 def main():
@@ -133,7 +134,7 @@ def main():
             torch.cuda.set_device(0)
             res = legs.c4_leg(a, torch, np, torch.device("cuda", 0), n_rows=a.c4_rows, world=a.loopback_world)
             res.update({"n_gpus": 1, "warmup": 2, "higher_is_better": True, "scaling": "strong", "vs_baseline": None})
-            print(json.dumps(res), flush=True)
+            legs.emit(res)
             return
         # the sharded run of configs[3]: same code path as the C3 scaling run, C4's shape, sharded coarse stage
         a.n_rows, a.nlist, a.m, a.nprobe, a.shard_coarse = a.c4_rows, 65536, 96, 128, True
@@ -393,8 +394,8 @@ def main():
             {"refine_factor": 10, "queries_per_s": sec.get("c3_refine10", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine10")},
             {"refine_factor": 25, "queries_per_s": sec.get("c3_refine25", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine25")}]
     if rank == 0:
-        result["summary"] = legs.summary_of(result)  # LAST key: the driver keeps only the tail of the line
-        print(json.dumps(result), flush=True)
+        result["summary"] = legs.summary_of(result)
+        legs.emit(result)  # full document -> bench_detail.json; stdout gets ONE line of < 4 KB (contract keys + roofline + cpu_baseline + summary)
     if sharded:
         # tear down in dependency order: the communicator before the index whose stream it used
         torch.cuda.synchronize()

@@ -20,9 +20,20 @@ def test_default_bench_line_at_toy_sizes():
            "--loopback-world", "4", "--cpu-seconds", "3"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert list(d)[-1] == "summary"
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]  # ONE line on stdout, nothing else
+    line = lines[0]
+    assert len(line) < 4096, len(line)  # round 4's 29.7 KB line was not parsed by the driver
+    head = json.loads(line)
+    assert list(head)[-1] == "summary"
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in head, key
+    assert head["roofline"]["frac"] > 0 and head["roofline"]["bound"] == "hbm" and head["roofline"]["us_per_launch"] > 0
+    assert head["cpu_baseline"]["kind"] == "port" and head["cpu_baseline"]["parity"]["rowids_bit_exact"] and "sample" in head["cpu_baseline"]
+    with open(os.path.join(ROOT, "bench_detail.json")) as f:
+        d = json.load(f)  # the full document
+    assert d["value"] == pytest.approx(head["value"], rel=1e-6) and d["summary"]["c3_qps"] == head["summary"]["c3_qps"]
     assert d["unit"] == "queries/s" and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["scan_variant"] == 2
     assert d["cpu_baseline"]["parity"]["rowids_bit_exact"] and d["cpu_baseline"]["cores"] >= 1
     sec = d["secondary"]

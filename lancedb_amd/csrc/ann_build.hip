@@ -50,7 +50,7 @@ static int32_t stable_order(hipStream_t st, const uint32_t* d_assign, uint64_t n
 
 extern "C" int32_t mi355_ivfpq_encode(const mi355_encode_desc* d, const float* vectors, uint64_t n_rows,
                                       uint64_t* out_part_offsets, uint8_t* out_codes, uint64_t* out_order,
-                                      uint32_t* out_assign) {
+                                      uint32_t* out_assign) try {
   if (!d) return fail(MI355_ERR_INVALID_INPUT, "desc is NULL");
   if (d->struct_size != sizeof(mi355_encode_desc))
     return fail(MI355_ERR_INVALID_INPUT, "mi355_encode_desc.struct_size %u != %zu (ABI mismatch)", d->struct_size,
@@ -179,7 +179,7 @@ extern "C" int32_t mi355_ivfpq_encode(const mi355_encode_desc* d, const float* v
                            host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_ivfpq_encode")
 
 // ---------------------------------------------------------------- training --
 namespace {
@@ -289,7 +289,7 @@ static int32_t lloyd_on_scratch(TrainScratch& w, const mi355_kmeans_desc* d, con
 }
 
 extern "C" int32_t mi355_kmeans_train(const mi355_kmeans_desc* d, const float* vectors, uint64_t n_rows,
-                                      float* centroids, uint64_t* out_counts) {
+                                      float* centroids, uint64_t* out_counts) try {
   ST_TRY(check_kmeans_desc(d));
   if (!centroids || (n_rows && !vectors)) return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
   if (n_rows >> 40) return fail(MI355_ERR_NOT_SUPPORTED, "too many training rows");
@@ -316,12 +316,12 @@ extern "C" int32_t mi355_kmeans_train(const mi355_kmeans_desc* d, const float* v
   }
   HIP_TRY(hipStreamSynchronize(st));
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_kmeans_train")
 
 // All m PQ sub-quantisers in one call: the residual matrix crosses to the device once and the m
 // trainers share one scratch set and one stream (sub-quantiser j = mi355_kmeans_train on columns
 // [j * dsub, (j + 1) * dsub) with ld = dim, bit for bit).
-extern "C" int32_t mi355_pq_train(const mi355_pq_train_desc* d, const float* residuals, uint64_t n_rows, float* codebook) {
+extern "C" int32_t mi355_pq_train(const mi355_pq_train_desc* d, const float* residuals, uint64_t n_rows, float* codebook) try {
   if (!d) return fail(MI355_ERR_INVALID_INPUT, "desc is NULL");
   if (d->struct_size != sizeof(mi355_pq_train_desc))
     return fail(MI355_ERR_INVALID_INPUT, "mi355_pq_train_desc.struct_size %u != %zu (ABI mismatch)", d->struct_size,
@@ -369,10 +369,10 @@ extern "C" int32_t mi355_pq_train(const mi355_pq_train_desc* d, const float* res
                          host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_pq_train")
 
 extern "C" int32_t mi355_ivf_residuals(const mi355_kmeans_desc* d, const float* vectors, uint64_t n_rows,
-                                       const float* centroids, float* out_residuals, uint32_t* out_assign) {
+                                       const float* centroids, float* out_residuals, uint32_t* out_assign) try {
   ST_TRY(check_kmeans_desc(d));
   if (!centroids || (n_rows && (!vectors || !out_residuals))) return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
   if (n_rows >> 40) return fail(MI355_ERR_NOT_SUPPORTED, "too many rows");
@@ -403,4 +403,4 @@ extern "C" int32_t mi355_ivf_residuals(const mi355_kmeans_desc* d, const float* 
                            host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_ivf_residuals")

@@ -223,7 +223,7 @@ static void comm_free(mi355_comm* c) {
   delete c;
 }
 
-extern "C" int32_t mi355_comm_unique_id(void* out_id) {
+extern "C" int32_t mi355_comm_unique_id(void* out_id) try {
   if (!out_id) return fail(MI355_ERR_INVALID_INPUT, "out_id is NULL");
   const RcclApi* api = nullptr;
   ST_TRY(rccl_api(&api));
@@ -232,9 +232,9 @@ extern "C" int32_t mi355_comm_unique_id(void* out_id) {
   memset(out_id, 0, MI355_COMM_ID_BYTES);
   memcpy(out_id, &id, sizeof id);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_comm_unique_id")
 
-extern "C" int32_t mi355_comm_create(const void* id, uint32_t rank, uint32_t world, int32_t device, mi355_comm** out) {
+extern "C" int32_t mi355_comm_create(const void* id, uint32_t rank, uint32_t world, int32_t device, mi355_comm** out) try {
   if (!out) return fail(MI355_ERR_INVALID_INPUT, "out is NULL");
   *out = nullptr;
   if (!id) return fail(MI355_ERR_INVALID_INPUT, "id is NULL");
@@ -264,9 +264,9 @@ extern "C" int32_t mi355_comm_create(const void* id, uint32_t rank, uint32_t wor
   }
   *out = c;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_comm_create")
 
-extern "C" int32_t mi355_comm_create_loopback(uint32_t world, int32_t device, mi355_comm** out) {
+extern "C" int32_t mi355_comm_create_loopback(uint32_t world, int32_t device, mi355_comm** out) try {
   if (!out) return fail(MI355_ERR_INVALID_INPUT, "out is NULL");
   for (uint32_t r = 0; r < world && r < MI355_MAX_RANKS; ++r) out[r] = nullptr;
   if (world == 0 || world > MI355_MAX_RANKS)
@@ -303,16 +303,16 @@ extern "C" int32_t mi355_comm_create_loopback(uint32_t world, int32_t device, mi
     }
   }
   return s;
-}
+} MI355_ABI_GUARD("mi355_comm_create_loopback")
 
-extern "C" int32_t mi355_comm_destroy(mi355_comm* c) {
+extern "C" int32_t mi355_comm_destroy(mi355_comm* c) try {
   if (!c) return MI355_OK;
   if (c->loop) c->loop->abort();  // a peer still waiting for this rank must not wait for ever
   comm_free(c);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_comm_destroy")
 
-extern "C" int32_t mi355_comm_last_stats(mi355_comm* c, mi355_comm_stats* out) {
+extern "C" int32_t mi355_comm_last_stats(mi355_comm* c, mi355_comm_stats* out) try {
   if (!c || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
   if (out->struct_size != sizeof(mi355_comm_stats)) return fail(MI355_ERR_INVALID_INPUT, "mi355_comm_stats.struct_size mismatch");
   std::lock_guard<std::mutex> lk(c->mu);
@@ -343,14 +343,14 @@ extern "C" int32_t mi355_comm_last_stats(mi355_comm* c, mi355_comm_stats* out) {
   *out = c->stats;
   out->struct_size = sizeof(mi355_comm_stats);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_comm_last_stats")
 
-extern "C" int32_t mi355_coarse_slice(uint32_t nlist, uint32_t world, uint32_t rank, uint32_t* out_lo, uint32_t* out_hi) {
+extern "C" int32_t mi355_coarse_slice(uint32_t nlist, uint32_t world, uint32_t rank, uint32_t* out_lo, uint32_t* out_hi) try {
   if (!out_lo || !out_hi || world == 0 || rank >= world) return fail(MI355_ERR_INVALID_INPUT, "bad arguments");
   *out_lo = (uint32_t)(((uint64_t)nlist * rank) / world);
   *out_hi = (uint32_t)(((uint64_t)nlist * (rank + 1)) / world);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_coarse_slice")
 
 // ---- slab layout --------------------------------------------------------------------------------
 struct Slab {
@@ -640,7 +640,7 @@ static int32_t sharded_body(mi355_index* ix, mi355_comm* c, const float* queries
 
 extern "C" int32_t mi355_search_sharded(mi355_index* ix, mi355_comm* c, const float* queries, uint32_t n_queries,
                                         const mi355_search_params* p, uint32_t flags, uint64_t* out_rowids,
-                                        float* out_dist, uint32_t* out_counts) {
+                                        float* out_dist, uint32_t* out_counts) try {
   if (!c) return fail(MI355_ERR_INVALID_INPUT, "comm is NULL");
   if (flags & ~(uint32_t)(MI355_SHARD_COARSE | MI355_SHARD_NO_OVERLAP)) return fail(MI355_ERR_INVALID_INPUT, "unknown flags 0x%x", flags);
   SearchShape sh;
@@ -666,7 +666,7 @@ extern "C" int32_t mi355_search_sharded(mi355_index* ix, mi355_comm* c, const fl
     if (c->loop) c->loop->abort();
   }
   return s;
-}
+} MI355_ABI_GUARD("mi355_search_sharded")
 
 // ---- flat, rows sharded across ranks -------------------------------------------------------------
 static int32_t flat_sharded_body(mi355_flat* f, mi355_comm* c, const float* queries, uint32_t n_queries,
@@ -728,7 +728,7 @@ static int32_t flat_sharded_body(mi355_flat* f, mi355_comm* c, const float* quer
 
 extern "C" int32_t mi355_flat_search_sharded(mi355_flat* f, mi355_comm* c, const float* queries, uint32_t n_queries,
                                              const mi355_search_params* p, uint64_t* out_rowids, float* out_dist,
-                                             uint32_t* out_counts) {
+                                             uint32_t* out_counts) try {
   if (!f || !c) return fail(MI355_ERR_INVALID_INPUT, "NULL handle");
   ST_TRY(validate_params(p));
   const uint32_t metric = p->metric == MI355_METRIC_DEFAULT ? (uint32_t)MI355_METRIC_L2 : p->metric;
@@ -752,4 +752,4 @@ extern "C" int32_t mi355_flat_search_sharded(mi355_flat* f, mi355_comm* c, const
     if (c->loop) c->loop->abort();
   }
   return s;
-}
+} MI355_ABI_GUARD("mi355_flat_search_sharded")

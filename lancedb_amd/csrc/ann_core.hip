@@ -4,15 +4,14 @@
 #include "ann_internal.h"
 
 // ------------------------------------------------------------------ errors --
-static thread_local std::string g_last_error;
+// A fixed per-thread slot: recording a failure must not allocate (the failure may BE "out of host memory").
+static thread_local char g_last_error[512];
 
 int32_t fail(int32_t code, const char* fmt, ...) {
-  char buf[512];
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
+  vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
   va_end(ap);
-  g_last_error = buf;
   return code;
 }
 
@@ -59,7 +58,7 @@ void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::v
 // ---------------------------------------------------------------- library ---
 extern "C" uint32_t mi355_abi_version(void) { return MI355_ANN_ABI_VERSION; }
 
-extern "C" int32_t mi355_device_count(int32_t* out_count) {
+extern "C" int32_t mi355_device_count(int32_t* out_count) try {
   if (!out_count) return fail(MI355_ERR_INVALID_INPUT, "out_count is NULL");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -69,33 +68,33 @@ extern "C" int32_t mi355_device_count(int32_t* out_count) {
   }
   *out_count = n;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_device_count")
 
-extern "C" int32_t mi355_last_error(char* buf, size_t buf_len) {
+extern "C" int32_t mi355_last_error(char* buf, size_t buf_len) try {
   if (!buf || buf_len == 0) return MI355_ERR_INVALID_INPUT;
-  snprintf(buf, buf_len, "%s", g_last_error.c_str());
+  snprintf(buf, buf_len, "%s", g_last_error);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_last_error")
 
 extern "C" int32_t mi355_shard_plan(const uint64_t* part_offsets, uint32_t nlist,
-                                    uint32_t shard_count, uint32_t* out_owner) {
+                                    uint32_t shard_count, uint32_t* out_owner) try {
   if (!part_offsets || !out_owner || shard_count == 0 || nlist == 0)
     return fail(MI355_ERR_INVALID_INPUT, "mi355_shard_plan: bad arguments");
   std::vector<uint32_t> owner;
   shard_plan_host(part_offsets, nlist, shard_count, owner);
   memcpy(out_owner, owner.data(), sizeof(uint32_t) * nlist);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_shard_plan")
 
 extern "C" int32_t mi355_shard_plan_weighted(const uint64_t* part_offsets, const float* weight, uint32_t nlist,
-                                             uint32_t shard_count, uint32_t* out_owner) {
+                                             uint32_t shard_count, uint32_t* out_owner) try {
   if (!part_offsets || !out_owner || shard_count == 0 || nlist == 0)
     return fail(MI355_ERR_INVALID_INPUT, "mi355_shard_plan_weighted: bad arguments");
   std::vector<uint32_t> owner;
   shard_plan_host(part_offsets, nlist, shard_count, owner, weight);
   memcpy(out_owner, owner.data(), sizeof(uint32_t) * nlist);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_shard_plan_weighted")
 
 int32_t need_device(int32_t device) {
   int n = 0;

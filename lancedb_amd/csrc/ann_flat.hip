@@ -14,7 +14,7 @@
 #define MI355_FLAT_GEMM_AUTO_BIG MI355_FLAT_GEMM_8PHASE
 
 // -------------------------------------------------------------------- flat --
-extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
+extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) try {
   if (!out) return fail(MI355_ERR_INVALID_INPUT, "out is NULL");
   *out = nullptr;
   if (!d) return fail(MI355_ERR_INVALID_INPUT, "desc is NULL");
@@ -100,7 +100,7 @@ extern "C" int32_t mi355_flat_open(const mi355_flat_desc* d, mi355_flat** out) {
   if (hipStreamSynchronize(f->stream) != hipSuccess) return bail(fail(MI355_ERR_RUNTIME, "sync failed"));
   *out = f;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_open")
 
 // The MFMA filter + exact re-rank over queries [d_q, d_q + n) (device), results in d_ids/d_dist/d_cnt
 static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint32_t metric, uint32_t k,
@@ -317,7 +317,7 @@ static int32_t run_flat_mfma(mi355_flat* f, const float* d_q, uint32_t nq, uint3
   return MI355_OK;
 }
 
-extern "C" int32_t mi355_flat_close(mi355_flat* f) {
+extern "C" int32_t mi355_flat_close(mi355_flat* f) try {
   if (!f) return MI355_OK;
   (void)hipSetDevice(f->device);
   DevBuf* bufs[] = {&f->vectors, &f->row_ids, &f->w_q,  &f->w_cand, &f->w_ids,  &f->w_dist, &f->w_cnt,
@@ -331,21 +331,21 @@ extern "C" int32_t mi355_flat_close(mi355_flat* f) {
   if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_close")
 
-extern "C" int32_t mi355_flat_set_stream(mi355_flat* f, void* hip_stream) {
+extern "C" int32_t mi355_flat_set_stream(mi355_flat* f, void* hip_stream) try {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   std::lock_guard<std::mutex> lk(f->mu);
   f->stream = hip_stream ? (hipStream_t)hip_stream : f->own_stream;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_set_stream")
 
-extern "C" int32_t mi355_flat_sync(mi355_flat* f) {
+extern "C" int32_t mi355_flat_sync(mi355_flat* f) try {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   HIP_TRY(hipSetDevice(f->device));
   HIP_TRY(hipStreamSynchronize(f->stream));
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_sync")
 
 // the device work of a flat search over device-resident queries (f->mu held by the caller; stream work only)
 int32_t run_flat_search_device(mi355_flat* f, const float* d_q, uint32_t nq, const mi355_search_params* p,
@@ -424,7 +424,7 @@ int32_t run_flat_search_device(mi355_flat* f, const float* d_q, uint32_t nq, con
 
 extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32_t n_queries,
                                      const mi355_search_params* p, uint64_t* out_rowids,
-                                     float* out_dist, uint32_t* out_counts) {
+                                     float* out_dist, uint32_t* out_counts) try {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   ST_TRY(validate_params(p));
   uint32_t metric = p->metric == MI355_METRIC_DEFAULT ? (uint32_t)MI355_METRIC_L2 : p->metric;
@@ -506,10 +506,10 @@ extern "C" int32_t mi355_flat_search(mi355_flat* f, const float* queries, uint32
     }
   }
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_search")
 
 extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, uint32_t grid_workgroups,
-                                        uint32_t flags) {
+                                        uint32_t flags) try {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   if (gemm_variant > MI355_FLAT_GEMM_8PHASE_REF || gemm_variant == 3)
     return fail(MI355_ERR_INVALID_INPUT, "unknown gemm variant %u", gemm_variant);
@@ -526,9 +526,9 @@ extern "C" int32_t mi355_flat_configure(mi355_flat* f, uint32_t gemm_variant, ui
   f->ev_pending.clear();
   f->fstats = mi355_flat_stats{};
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_configure")
 
-extern "C" int32_t mi355_flat_last_stats(mi355_flat* f, mi355_flat_stats* out) {
+extern "C" int32_t mi355_flat_last_stats(mi355_flat* f, mi355_flat_stats* out) try {
   if (!f || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
   if (out->struct_size != sizeof(mi355_flat_stats)) return fail(MI355_ERR_INVALID_INPUT, "mi355_flat_stats.struct_size mismatch");
   std::lock_guard<std::mutex> lk(f->mu);
@@ -548,27 +548,27 @@ extern "C" int32_t mi355_flat_last_stats(mi355_flat* f, mi355_flat_stats* out) {
   *out = f->fstats;
   out->struct_size = sizeof(mi355_flat_stats);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_last_stats")
 
-extern "C" int32_t mi355_flat_checksum(mi355_flat* f, uint64_t* out) {
+extern "C" int32_t mi355_flat_checksum(mi355_flat* f, uint64_t* out) try {
   if (!f || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
   std::lock_guard<std::mutex> lk(f->mu);
   *out = f->checksum;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_checksum")
 
-extern "C" int32_t mi355_flat_census(mi355_flat* f, uint64_t* out_never_filter, uint64_t* out_not_finite, double* out_sum) {
+extern "C" int32_t mi355_flat_census(mi355_flat* f, uint64_t* out_never_filter, uint64_t* out_not_finite, double* out_sum) try {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   std::lock_guard<std::mutex> lk(f->mu);
   if (out_never_filter) *out_never_filter = f->census[0];
   if (out_not_finite) *out_not_finite = f->census[1];
   if (out_sum) *out_sum = f->census_sum;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_census")
 
-extern "C" int32_t mi355_flat_info(const mi355_flat* f, uint32_t* out_last_path, uint32_t* out_has_filter) {
+extern "C" int32_t mi355_flat_info(const mi355_flat* f, uint32_t* out_last_path, uint32_t* out_has_filter) try {
   if (!f) return fail(MI355_ERR_INVALID_INPUT, "flat handle is NULL");
   if (out_last_path) *out_last_path = f->last_path;
   if (out_has_filter) *out_has_filter = f->mfma ? 1u : 0u;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_flat_info")

@@ -42,7 +42,7 @@ void reset_stats(mi355_index* ix) {
   ix->stats.struct_size = sizeof(mi355_stats);
 }
 
-extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) {
+extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) try {
   if (!ix || !out) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
   if (out->struct_size != sizeof(mi355_stats))
     return fail(MI355_ERR_INVALID_INPUT, "mi355_stats.struct_size mismatch");
@@ -63,11 +63,11 @@ extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) {
   out->partitions_probed += (uint64_t)h_ctl.short_queries * ix->second_np;
   out->struct_size = sizeof(mi355_stats);
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_last_stats")
 
 #ifdef MI355_DEV_COUNTERS
 // dev builds only (never in the product library): the scan's phase ticks and selection counters
-extern "C" int32_t mi355_dev_counters(mi355_index* ix, uint32_t* out8, int32_t reset) {
+extern "C" int32_t mi355_dev_counters(mi355_index* ix, uint32_t* out8, int32_t reset) try {
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   DevCtl h;
@@ -75,7 +75,7 @@ extern "C" int32_t mi355_dev_counters(mi355_index* ix, uint32_t* out8, int32_t r
   memcpy(out8, h.dev, sizeof h.dev);
   if (reset) HIP_TRY(hipMemset(ix->w_ctl.as<DevCtl>()->dev, 0, sizeof h.dev));
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_dev_counters")
 #endif
 
 // ------------------------------------------------------------------ search --

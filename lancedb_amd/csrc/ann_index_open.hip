@@ -467,7 +467,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   return MI355_OK;
 }
 
-extern "C" int32_t mi355_index_open(const mi355_index_desc* desc, mi355_index** out) {
+extern "C" int32_t mi355_index_open(const mi355_index_desc* desc, mi355_index** out) try {
   if (!out) return fail(MI355_ERR_INVALID_INPUT, "out is NULL");
   *out = nullptr;
   ST_TRY(validate_index_desc(desc));
@@ -481,19 +481,19 @@ extern "C" int32_t mi355_index_open(const mi355_index_desc* desc, mi355_index** 
   }
   *out = ix;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_index_open")
 
-extern "C" int32_t mi355_index_close(mi355_index* index) { return index_free(index); }
+extern "C" int32_t mi355_index_close(mi355_index* index) try { return index_free(index); } MI355_ABI_GUARD("mi355_index_close")
 
-extern "C" int32_t mi355_index_set_stream(mi355_index* ix, void* hip_stream) {
+extern "C" int32_t mi355_index_set_stream(mi355_index* ix, void* hip_stream) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   std::lock_guard<std::mutex> lk(ix->mu);
   ST_TRY(join_exchange(ix));
   ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_index_set_stream")
 
-extern "C" int32_t mi355_index_sync(mi355_index* ix) {
+extern "C" int32_t mi355_index_sync(mi355_index* ix) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -503,10 +503,10 @@ extern "C" int32_t mi355_index_sync(mi355_index* ix) {
   HIP_TRY(hipMemcpy(&timed_out, &ix->w_ctl.as<DevCtl>()->timed_out, 4, hipMemcpyDeviceToHost));
   if (timed_out) return fail(MI355_ERR_TIMEOUT, "Query timeout: the last search was stopped on the device");
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_index_sync")
 
 extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
-                                         uint32_t slice_rows, uint32_t profile) {
+                                         uint32_t slice_rows, uint32_t profile) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   if (scan_variant > MI355_SCAN_SKEW) return fail(MI355_ERR_INVALID_INPUT, "unknown scan variant");
   if ((profile & MI355_PROFILE_MASK) > 2 ||
@@ -531,9 +531,9 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   reset_stats(ix);
   HIP_TRY(hipMemset(ix->w_ctl.p, 0, sizeof(DevCtl)));
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_index_configure")
 
-extern "C" int32_t mi355_index_attach_raw(mi355_index* ix, const void* raw_vectors, uint32_t raw_dtype) {
+extern "C" int32_t mi355_index_attach_raw(mi355_index* ix, const void* raw_vectors, uint32_t raw_dtype) try {
   if (!ix || !raw_vectors) return fail(MI355_ERR_INVALID_INPUT, "NULL argument");
   if (raw_dtype > MI355_DTYPE_F16) return fail(MI355_ERR_INVALID_INPUT, "bad raw_dtype enum");
   std::lock_guard<std::mutex> lk(ix->mu);
@@ -549,9 +549,9 @@ extern "C" int32_t mi355_index_attach_raw(mi355_index* ix, const void* raw_vecto
   }
   ++ix->ws_gen;  // captured graphs hold the old column's address
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_index_attach_raw")
 
-extern "C" int32_t mi355_index_detach_raw(mi355_index* ix) {
+extern "C" int32_t mi355_index_detach_raw(mi355_index* ix) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   std::lock_guard<std::mutex> lk(ix->mu);
   HIP_TRY(hipSetDevice(ix->device));
@@ -561,13 +561,13 @@ extern "C" int32_t mi355_index_detach_raw(mi355_index* ix) {
   ix->raw_is_host = ix->raw_mapped_dev != nullptr;
   ++ix->ws_gen;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_index_detach_raw")
 
 extern "C" int32_t mi355_index_info(const mi355_index* ix, uint64_t* out_rows,
-                                    uint32_t* out_partitions_owned) {
+                                    uint32_t* out_partitions_owned) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   if (out_rows) *out_rows = ix->n_local;
   if (out_partitions_owned) *out_partitions_owned = ix->parts_owned;
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_index_info")
 

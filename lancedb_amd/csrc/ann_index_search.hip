@@ -405,37 +405,43 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
   me.out_counts = out_counts;
   std::vector<PendingSearch*> served;
   if (!ix->cq.enter(me, [&](const PendingSearch& o) { return same_search(p, o.params); }, 4096u, served)) {
-    if (me.status != MI355_OK) return fail(me.status, "%s", me.error.c_str());  // (the batch that carried it failed)
+    if (me.status != MI355_OK) return fail(me.status, "%s", me.error);  // (the batch that carried it failed)
     return MI355_OK;
   }
+  // This caller owns the device now and other callers sleep on its batch: whatever happens below — a failing status OR
+  // a C++ exception on its way to the ABI guard — they must be released and the device handed on, so leave() runs
+  // from a scope guard.
+  struct LeaveGuard {
+    mi355_index* ix;
+    std::vector<PendingSearch*>& served;
+    int32_t status = MI355_ERR_RUNTIME;
+    char err[256] = "the batch that carried this call failed with a C++ exception in its leading call";
+    ~LeaveGuard() { ix->cq.leave(served, status, err); }
+  } guard{ix, served};
   for (PendingSearch* o : served) calls.push_back({o->queries, o->nq, o->out_rowids, o->out_dist, o->out_counts});
   int32_t status;
   {
     std::lock_guard<std::mutex> lk(ix->mu);
     status = search_locked(ix, calls, p, sh, nullptr, 0);
   }
-  std::string err;
-  if (status != MI355_OK) {
-    char buf[600];
-    mi355_last_error(buf, sizeof buf);
-    err = buf;
-  }
-  ix->cq.leave(served, status, err);
+  guard.status = status;
+  guard.err[0] = 0;
+  if (status != MI355_OK) mi355_last_error(guard.err, sizeof guard.err);
   return status;
 }
 
 extern "C" int32_t mi355_search(mi355_index* ix, const float* queries, uint32_t n_queries,
                                 const mi355_search_params* p, uint64_t* out_rowids,
-                                float* out_dist, uint32_t* out_counts) {
+                                float* out_dist, uint32_t* out_counts) try {
   return search_impl(ix, queries, n_queries, p, nullptr, 0, out_rowids, out_dist, out_counts);
-}
+} MI355_ABI_GUARD("mi355_search")
 
 extern "C" int32_t mi355_search_probes(mi355_index* ix, const float* queries, uint32_t n_queries,
                                        const mi355_search_params* p, const uint64_t* probes, uint32_t nprobe,
-                                       uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) {
+                                       uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) try {
   if (!probes) return fail(MI355_ERR_INVALID_INPUT, "probes is NULL");
   return search_impl(ix, queries, n_queries, p, probes, nprobe, out_rowids, out_dist, out_counts);
-}
+} MI355_ABI_GUARD("mi355_search_probes")
 
 // the coarse stage over centroid slice [cent_lo, cent_hi) for device-resident queries (stream work only)
 int32_t coarse_topn_device(mi355_index* ix, const float* d_q, uint32_t nq, uint32_t nprobe, uint32_t cent_lo,
@@ -468,7 +474,7 @@ int32_t coarse_topn_device(mi355_index* ix, const float* d_q, uint32_t nq, uint3
 
 extern "C" int32_t mi355_coarse_topn(mi355_index* ix, const float* queries, uint32_t n_queries, uint32_t nprobe,
                                      uint32_t cent_lo, uint32_t cent_hi, uint32_t io_mem, uint64_t* out_part_ids,
-                                     float* out_dist, uint32_t* out_counts) {
+                                     float* out_dist, uint32_t* out_counts) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   if (io_mem > MI355_MEM_DEVICE) return fail(MI355_ERR_INVALID_INPUT, "bad io_mem");
   if (cent_lo >= cent_hi || cent_hi > ix->nlist)
@@ -505,12 +511,12 @@ extern "C" int32_t mi355_coarse_topn(mi355_index* ix, const float* queries, uint
     HIP_TRY(hipStreamSynchronize(st));
   }
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_coarse_topn")
 // ------------------------------------------------------------------- merge --
 extern "C" int32_t mi355_merge_topk(int32_t device, void* hip_stream, const uint64_t* in_rowids,
                                     const float* in_dist, const uint32_t* in_counts,
                                     uint32_t n_lists, uint32_t n_queries, uint32_t k,
-                                    uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) {
+                                    uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) try {
   if (n_queries == 0) return MI355_OK;
   if (!in_rowids || !in_dist || !in_counts || !out_rowids || !out_dist || !out_counts)
     return fail(MI355_ERR_INVALID_INPUT, "NULL buffer");
@@ -526,5 +532,5 @@ extern "C" int32_t mi355_merge_topk(int32_t device, void* hip_stream, const uint
     hipLaunchKernelGGL(k_merge_lists<4>, dim3(n_queries), dim3(64), 0, st, in_rowids, in_dist, in_counts, n_lists, n_queries, k, out_rowids, out_dist, out_counts);
   HIP_TRY(hipGetLastError());
   return MI355_OK;
-}
+} MI355_ABI_GUARD("mi355_merge_topk")
 

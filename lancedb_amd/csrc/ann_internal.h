@@ -24,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -35,6 +36,16 @@
 // ------------------------------------------------------------------ errors --
 // message of the last failing call on this thread (mi355_last_error)
 int32_t fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Exception barrier of the C ABI (include/mi355_ann.h: "no exception or abort crosses the ABI"; the statuses are
+// rust/lancedb/src/error.rs:55-145's Runtime).  Every extern "C" entry point is a function-try-block closed by this
+// macro: a std::bad_alloc from a host container, any other C++ exception, or a foreign one becomes status 2 with a
+// message in the per-thread slot (which does not allocate) instead of unwinding into a Rust / C caller (undefined
+// behaviour there).  tests/test_abi.py::test_out_of_host_memory_is_a_status_not_a_crash runs an entry point under RLIMIT_AS.
+#define MI355_ABI_GUARD(name)                                                                            \
+  catch (const std::bad_alloc&) { return fail(MI355_ERR_RUNTIME, name ": out of host memory"); }          \
+  catch (const std::exception& e_) { return fail(MI355_ERR_RUNTIME, name ": C++ exception: %s", e_.what()); } \
+  catch (...) { return fail(MI355_ERR_RUNTIME, name ": unknown C++ exception"); }
 
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \

@@ -15,6 +15,15 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_
     const size_t lds = lds_of(NT / 64, LR);                                                     \
     if (lds > 160u * 1024)                                                                      \
       return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
+    static std::atomic<int> table_at_lds_zero{0}; /* per instantiation: 0 unknown, 1 yes, -1 no */ \
+    if (table_at_lds_zero.load(std::memory_order_relaxed) == 0) {                               \
+      hipFuncAttributes fa;                                                                     \
+      HIP_TRY(hipFuncGetAttributes(&fa, (const void*)kern));                                    \
+      table_at_lds_zero.store(fa.sharedSizeBytes == 0 ? 1 : -1, std::memory_order_relaxed);     \
+    }                                                                                           \
+    if (table_at_lds_zero.load(std::memory_order_relaxed) < 0)                                  \
+      return fail(MI355_ERR_NOT_SUPPORTED, "scan kernel was built with static LDS in front of its table " \
+                  "(the gather address assumes the table at LDS address 0)");                   \
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)lds));                                                     \
     hipLaunchKernelGGL(kern, dim3(GRID), dim3(NT), lds, st, sa);                                \

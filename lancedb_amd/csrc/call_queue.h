@@ -18,8 +18,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <mutex>
-#include <string>
 #include <thread>
 #include <vector>
 
@@ -29,7 +29,7 @@ enum : uint32_t { QS_PARKED = 0, QS_SERVED = 1, QS_LEAD = 2 };
 struct QueueWaiter {
   uint32_t nq = 0;      // queries it carries (a batch is capped)
   int32_t status = 0;   // QS_SERVED: the status / message of the batch that carried it
-  std::string error;
+  char error[256] = {0};  // fixed: delivering a failure must not allocate (it may be "out of host memory")
   // QS_PARKED, QS_SERVED = another caller's batch carried it (status / error are final), QS_LEAD = handed the device:
   // this caller runs the next batch.  Written last by the thread that decides, read without the queue lock by the owner.
   std::atomic<uint32_t> state{QS_PARKED};
@@ -99,6 +99,15 @@ struct CallQueue {
         if (now - t_last > std::chrono::microseconds(15) || now - t0 > cap || seen >= (size_t)last_batch_calls * 2u) break;
       }
     }
+    // (the only allocation of an owner: made before anything is taken off the queue, so that running out of host
+    //  memory here hands the device on — leave() with nothing served — instead of stranding the parked callers)
+    try {
+      served.reserve(served.size() + queue.size());
+    } catch (...) {
+      ql.unlock();
+      leave(std::vector<W*>(), 0, nullptr);
+      throw;
+    }
     ++collect_gen;
     uint32_t total = me.nq;
     for (auto it = queue.begin(); it != queue.end();) {
@@ -116,7 +125,7 @@ struct CallQueue {
 
   // The owner's batch is done: deliver its status to the requests it carried, then hand the device to the oldest
   // parked request (directly: busy stays set) or release it.
-  void leave(const std::vector<W*>& served, int32_t status, const std::string& err) {
+  void leave(const std::vector<W*>& served, int32_t status, const char* err) noexcept {
     uint32_t wake_mask = 0;
     {
       std::lock_guard<std::mutex> ql(mu);
@@ -130,7 +139,7 @@ struct CallQueue {
       }
       for (W* f : served) {
         f->status = status;
-        f->error = err;
+        snprintf(f->error, sizeof f->error, "%s", err ? err : "");
         wake_mask |= 1u << f->cohort;
         f->state.store(QS_SERVED, std::memory_order_release);
       }

@@ -605,8 +605,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
   SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
   PassFloor* s_floor = (PassFloor*)(s_rec + 2);                          // [1] (MULTI)
-  // the gather address is (code << 9) | column bytes: the table must start at LDS address 0
-  if ((uint32_t)(size_t)smem != 0u) __builtin_trap();
+  // the gather address is (code << 9) | column bytes: the table must start at LDS address 0, i.e. the kernel must own
+  // no static __shared__ in front of its dynamic block — a compile-time property the launcher checks on the host
+  // (launch_scan_skew_m: hipFuncGetAttributes().sharedSizeBytes == 0, else MI355_ERR_NOT_SUPPORTED; nothing traps here)
   const uint32_t lb = 4u * (32u - lm);  // this lane's column origin (bytes)
 #ifdef SK_DUAL
   const uint32_t slab_bit = 0x10000u;

@@ -192,3 +192,53 @@ def test_flat_gemm_tile_walk_visits_every_tile_once():
                         assert b % 8 == rt % 8
                     vb += grid
             assert len(seen) == n_rtiles * n_qtiles
+
+
+_OOM_CHILD = r"""
+import ctypes as C, resource, sys
+L = C.CDLL(sys.argv[1])          # (libamdhip64 is mapped before the limit goes down)
+L.mi355_shard_plan.restype = C.c_int32
+L.mi355_last_error.restype = C.c_int32
+po = (C.c_uint64 * 8)()
+out = (C.c_uint32 * 8)()
+soft = 1 << 30
+used = int(open('/proc/self/statm').read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (used + soft, used + soft))
+# nlist = 2^30 partitions: the plan's first container is 4 GiB > the limit -> std::bad_alloc inside the library,
+# thrown before any of the (too short) arrays is read
+st = L.mi355_shard_plan(po, C.c_uint32(1 << 30), C.c_uint32(2), out)
+buf = C.create_string_buffer(512)
+L.mi355_last_error(buf, C.c_size_t(512))
+print(st, buf.value.decode())
+"""
+
+
+def test_out_of_host_memory_is_a_status_not_a_crash(L):
+    """include/mi355_ann.h: "no exception or abort crosses the ABI" — every entry point is a function-try-block
+    (MI355_ABI_GUARD, csrc/ann_internal.h).  A host allocation that fails inside the library must come back as
+    MI355_ERR_RUNTIME (rust/lancedb/src/error.rs: Runtime) with a message, not as std::terminate."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _OOM_CHILD, _lib.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    status, _, msg = r.stdout.strip().partition(" ")
+    assert int(status) == 2 and "mi355_shard_plan" in msg and "out of host memory" in msg, r.stdout
+
+
+def test_every_entry_point_has_the_exception_barrier():
+    """Source check: each `extern "C"` definition that can allocate is a function-try-block closed by MI355_ABI_GUARD
+    naming itself (mi355_abi_version returns a constant)."""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(__file__)), "lancedb_amd", "csrc")
+    seen = set()
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".hip"):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        defs = re.findall(r'extern "C" (?:int32_t|uint32_t) (mi355_\w+)\(', src)
+        guards = re.findall(r'MI355_ABI_GUARD\("(mi355_\w+)"\)', src)
+        assert sorted(d for d in defs if d != "mi355_abi_version") == sorted(guards), f
+        for d in defs:
+            if d != "mi355_abi_version":
+                assert re.search(r'extern "C" (?:int32_t|uint32_t) ' + d + r"\([^{;]*\) try \{", src), (f, d)
+        seen.update(defs)
+    assert seen - {"mi355_dev_counters"} == set(_abi.EXPORTED_SYMBOLS)  # (dev_counters: developer builds only, not in the header)

@@ -5,6 +5,7 @@
 //
 //   g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -I lancedb_amd/csrc tests/tools/queue_stress.cpp -o queue_stress
 //   ./queue_stress [threads] [calls per thread]      -> "ok ..." and exit code 0
+#include <cstring>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -58,7 +59,7 @@ int main(int argc, char** argv) {
           q.leave(served, status, status ? "boom" : "");
         } else {
           status = me.status;
-          if (status != 0 && me.error != "boom") errors.fetch_add(1);
+          if (status != 0 && strcmp(me.error, "boom") != 0) errors.fetch_add(1);
         }
         if (status == 0) {
           if (me.result != me.payload * 3 + 1) errors.fetch_add(1);

@@ -150,6 +150,14 @@ int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, ui
   return MI355_OK;
 }
 
+bool lat_front_applies(const mi355_index* ix, uint32_t nq, const SearchPlan& pl) {
+  const size_t small_lds = ((size_t)nq * (((size_t)ix->dim + 3) & ~(size_t)3) + nq) * sizeof(float);
+  return ix->layout == MI355_SCAN_SKEW && !pl.ext_probes && !pl.act.n && nq >= 1 && nq <= CS_MAXQ && small_lds <= 96u * 1024 &&
+         ix->metric != MI355_METRIC_COSINE && (ix->dim & 3u) == 0 && ix->nlist <= SELPLAN_MAX_NLIST && pl.nprobe <= ix->nlist &&
+         (uint64_t)nq * pl.nprobe <= PLAN_SPARSE_MAX_PAIRS && !dev_knob("MI355_COARSE_VALU", 0) && dev_knob("MI355_LAT_SMALL_FRONT", 1) &&
+         dev_knob("MI355_LAT_FRONT", 1);
+}
+
 // one pass of the pipeline over `nq` queries already resident at d_q;
 // results land in d_ids/d_dist/d_cnt (device, [nq,k])
 // d_cnt_ann [nq]: rows the ANN stage found per query, BEFORE the refine re-rank (what
@@ -254,7 +262,76 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       }
       HIP_TRY(hipEventRecord(es.ev[0], st));
     }
-    // latency mode: a handful of queries run prep + coarse as one launch of single-wave workgroups
+    // latency mode, L2 / dot on the production scan: k_coarse_lat (dot chains; arms the control word) + k_select_plan
+    // (scores, probe selection, work list) — two launches where k_arm_deadline, k_coarse_split, k_select_probes and
+    // k_plan_sparse were four
+    const bool lat_front = n == nq && lat_front_applies(ix, nq, pl);
+    if (pl.arm_in_front && !(lat_front && q0 == 0) && q0 == 0) {  // (cannot happen: the caller asked the same predicate)
+      hipLaunchKernelGGL(k_arm_deadline, dim3(1), dim3(1), 0, st, d_ctl, pl.arm_ticks, pl.arm_reset);
+      HIP_TRY(hipGetLastError());
+    }
+    PlanArgs pa{};
+    if (skew) {
+      pa.probes = ix->w_probes.as<uint32_t>();
+      pa.n_pairs = n * nprobe;
+      pa.nlist = ix->nlist;
+      pa.plen = view.plen;
+      pa.order = ix->order.as<uint32_t>();
+      pa.opos = ix->order.as<uint32_t>() + ix->nlist;
+      pa.xcd_first = ix->xcd_first.as<uint32_t>();
+      pa.cnt = ix->p_cnt.as<uint32_t>();
+      pa.off = ix->p_off.as<uint32_t>();
+      pa.fill = ix->p_fill.as<uint32_t>();
+      pa.q_start = ix->q_start.as<uint32_t>();
+      pa.heads = ix->heads.as<uint32_t>();
+      pa.items = ix->items.as<SkewItem>();
+      pa.lrow0 = view.lrow0;
+      pa.grow0 = view.grow0;
+      pa.code_off = view.code_off;
+      pa.cand_cnt = ix->w_ccnt.as<uint32_t>();
+      pa.kk = pl.kk;
+      pa.nprobe = nprobe;
+      // every query's nearest partition first: its kk-th best bounds the other partitions' admissions
+      // (measured: scan -3 % at kk = 10, -5 % at kk = 64, -38 % at kk = 250 together with the block merge,
+      // profiles/r03_g_*); an external probe list has its nearest partition at rank 0 when it comes from the
+      // sharded coarse merge, otherwise rank 0 is just the caller's first probe
+      pa.best_first = (pl.kk >= dev_knob("MI355_BEST_FIRST_MIN_KK", 1) && nprobe > 1u) ? 1u : 0u;
+      pa.n_slices = n_slices;
+      pa.act = act;
+    }
+    if (lat_front) {
+      int lpc = 4;
+      while (lpc < 16 && (uint64_t)ix->nlist * lpc < 2ull * 64 * ix->n_cus) lpc *= 2;
+      auto go = [&](auto kern, size_t lds, uint32_t cpw) -> int {
+        if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((ix->nlist + cpw - 1) / cpw + 1u), dim3(64), lds, st, q, n, ix->dim, view.centroids, ix->nlist,
+                           ix->w_qp.as<float>(), ix->w_qq.as<float>(), ix->w_coarse.as<float>(), pl.arm_in_front ? d_ctl : (DevCtl*)nullptr,
+                           pl.arm_ticks, pl.arm_reset);
+        return MI355_OK;
+      };
+      const int rc = lpc == 4    ? go(k_coarse_lat<4, 24>, coarse_lat_lds<4, 24>(n, ix->dim), 16u)
+                     : lpc == 8 ? go(k_coarse_lat<8, 24>, coarse_lat_lds<8, 24>(n, ix->dim), 8u)
+                                : go(k_coarse_lat<16, 12>, coarse_lat_lds<16, 12>(n, ix->dim), 4u);
+      if (rc != MI355_OK) return rc;
+      HIP_TRY(hipGetLastError());
+      if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
+      SelectPlanArgs sp;
+      sp.raw = ix->w_coarse.as<float>();
+      sp.qq = ix->w_qq.as<float>();
+      sp.cnorm = view.cnorm;
+      sp.metric = ix->metric;
+      sp.nlist = ix->nlist;
+      sp.nprobe = nprobe;
+      sp.plen = view.plen;
+      sp.probes = ix->w_probes.as<uint32_t>();
+      sp.stat_rows = d_stat;
+      sp.qthr = ix->qthr.as<uint32_t>();
+      sp.coarse_out = nullptr;
+      sp.ticket = ix->heads.as<uint32_t>() + 8 * SK_HEAD_STRIDE;
+      sp.plan = pa;
+      hipLaunchKernelGGL(k_select_plan, dim3(n), dim3(SELPLAN_NT), (size_t)ix->nlist * 4u, st, sp);
+      HIP_TRY(hipGetLastError());
+    } else {
     const size_t small_lds = ((size_t)n * (((size_t)ix->dim + 3) & ~(size_t)3) + n) * sizeof(float);
     const bool small_front = !pl.ext_probes && !pl.act.n && n <= CS_MAXQ && small_lds <= 96u * 1024 && !dev_knob("MI355_COARSE_VALU", 0) &&
                              dev_knob("MI355_LAT_SMALL_FRONT", 1);
@@ -310,39 +387,15 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
                        skew ? ix->qthr.as<uint32_t>() : (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     }
+    }  // !lat_front
     if (prof) HIP_TRY(hipEventRecord(es.ev[2], st));
 
     if (skew) {
-      PlanArgs pa;
-      pa.probes = ix->w_probes.as<uint32_t>();
-      pa.n_pairs = n * nprobe;
-      pa.nlist = ix->nlist;
-      pa.plen = view.plen;
-      pa.order = ix->order.as<uint32_t>();
-      pa.opos = ix->order.as<uint32_t>() + ix->nlist;
-      pa.xcd_first = ix->xcd_first.as<uint32_t>();
-      pa.cnt = ix->p_cnt.as<uint32_t>();
-      pa.off = ix->p_off.as<uint32_t>();
-      pa.fill = ix->p_fill.as<uint32_t>();
-      pa.q_start = ix->q_start.as<uint32_t>();
-      pa.heads = ix->heads.as<uint32_t>();
-      pa.items = ix->items.as<SkewItem>();
-      pa.lrow0 = view.lrow0;
-      pa.grow0 = view.grow0;
-      pa.code_off = view.code_off;
-      pa.cand_cnt = ix->w_ccnt.as<uint32_t>();
-      pa.kk = pl.kk;
-      pa.nprobe = nprobe;
-      // every query's nearest partition first: its kk-th best bounds the other partitions' admissions
-      // (measured: scan -3 % at kk = 10, -5 % at kk = 64, -38 % at kk = 250 together with the block merge,
-      // profiles/r03_g_*); an external probe list has its nearest partition at rank 0 when it comes from the
-      // sharded coarse merge, otherwise rank 0 is just the caller's first probe
-      pa.best_first = (pl.kk >= dev_knob("MI355_BEST_FIRST_MIN_KK", 1) && nprobe > 1u) ? 1u : 0u;
-      pa.n_slices = n_slices;
-      pa.act = act;
       const uint32_t pb = (pa.n_pairs + 255) / 256;
       // (qthr, the queries' running distance bounds, was reset by k_select_probes / k_take_probes)
-      if (pa.n_pairs <= PLAN_SPARSE_MAX_PAIRS && dev_knob("MI355_PLAN_SPARSE", 1)) {
+      if (lat_front) {
+        // (k_select_plan's last workgroup wrote the work list)
+      } else if (pa.n_pairs <= PLAN_SPARSE_MAX_PAIRS && dev_knob("MI355_PLAN_SPARSE", 1)) {
         hipLaunchKernelGGL(k_plan_sparse, dim3(1), dim3(PLAN_SPARSE_MAX_PAIRS), 0, st, pa);
       } else if (pa.n_pairs <= PLAN_FUSED_MAX_PAIRS && dev_knob("MI355_PLAN_FUSED", 1)) {
         hipLaunchKernelGGL(k_plan_fused, dim3(1), dim3(1024), 0, st, pa);
@@ -378,6 +431,36 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ka.res_floats = ix->sk_res_floats;
       ka.partial = nullptr;
       ka.partial_stride = 0;
+      ka.lut_pre = nullptr;
+      if (n_slices > 1 && ix->sk_slabs == 1 && dev_knob("MI355_LAT_LUT_PRE", 1)) {
+        // sliced pairs: every pair's distance table once (k_lut_build), the slices copy the image
+        const uint32_t table_dwords = sk_table_bytes(ix->sk_M) / 4u;
+        const uint32_t n_pairs = n * nprobe;
+        ST_TRY(ix->w_lut.ensure((size_t)n_pairs * table_dwords * 4u));
+        LutBuildArgs la;
+        la.ix = view;
+        la.cbT = ix->cbT.as<float>();
+        la.qp = ix->w_qp.as<float>();
+        la.probes = ix->w_probes.as<uint32_t>();
+        la.nprobe = nprobe;
+        la.M = ix->sk_M;
+        la.table_dwords = table_dwords;
+        la.out = ix->w_lut.as<float>();
+        la.act = act;
+        // four workgroups per CU when the pairs are few: a thread then loads all its codebook entries in one round
+        uint32_t g = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, (4ull * ix->n_cus + n_pairs - 1) / n_pairs));
+        const size_t lds = (size_t)ix->sk_M * ix->dsub * sizeof(float);
+        if (lds > 64u * 1024) return fail(MI355_ERR_NOT_SUPPORTED, "residual of %zu B does not fit the table builder", lds);
+        auto go = [&](auto kern) -> int {
+          if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(kern, dim3(g, n_pairs), dim3(256), lds, st, la);
+          return MI355_OK;
+        };
+        const int rc = ix->dsub == 8 ? go(k_lut_build<8>) : ix->dsub == 16 ? go(k_lut_build<16>) : ix->dsub == 4 ? go(k_lut_build<4>) : go(k_lut_build<0>);
+        if (rc != MI355_OK) return rc;
+        HIP_TRY(hipGetLastError());
+        ka.lut_pre = ix->w_lut.as<float>();
+      }
       if (ix->sk_slabs > 1) {
         // partial row sums between the slabs of a work item: 8 B per (tile position, unit, lane) of the longest partition,
         // per workgroup (persistent: one work item at a time)

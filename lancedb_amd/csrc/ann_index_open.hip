@@ -154,7 +154,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
                     &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt,
-                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b};
+                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b,  &ix->w_lut};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -193,7 +193,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   const uint32_t nlist = d->nlist, m = d->m, mb = ix->mb, cb_entries = 1u << d->nbits;
   for (DevBuf* b : {&ix->w_q, &ix->w_qp, &ix->w_qq, &ix->w_coarse, &ix->w_probes, &ix->w_cand, &ix->w_ids, &ix->w_dist,
                     &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr, &ix->w_ccnt,
-                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial, &ix->w_cand2b, &ix->w_cnt2b})
+                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial, &ix->w_cand2b, &ix->w_cnt2b, &ix->w_lut})
     b->gen = &ix->ws_gen;  // a re-allocation of any of these invalidates the cached hipGraphs
 
   // -- ownership + local layout
@@ -397,7 +397,8 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     ST_TRY(ix->p_off.ensure(sizeof(uint32_t) * 2 * nlist));
     ST_TRY(ix->p_fill.ensure(sizeof(uint32_t) * 2 * nlist));
     ST_TRY(ix->q_start.ensure(sizeof(uint32_t) * 16));
-    ST_TRY(ix->heads.ensure(sizeof(uint32_t) * 8 * SK_HEAD_STRIDE));
+    ST_TRY(ix->heads.ensure(sizeof(uint32_t) * 9 * SK_HEAD_STRIDE));  // 8 queue heads + the ticket word of k_select_plan (a line of its own)
+    HIP_TRY(hipMemsetAsync(ix->heads.p, 0, sizeof(uint32_t) * 9 * SK_HEAD_STRIDE, st));
     HIP_TRY(hipMemcpyAsync(ix->order.p, order.data(), sizeof(uint32_t) * 2 * nlist, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ix->xcd_first.p, xcd_first.data(), sizeof(uint32_t) * 9, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(ix->p_cnt.p, 0, sizeof(uint32_t) * 2 * nlist, st));

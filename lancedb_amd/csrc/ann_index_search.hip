@@ -16,8 +16,16 @@ static int32_t launch_sequence(mi355_index* ix, const float* d_q, uint32_t nq, c
   hipStream_t st = ix->stream;
   DevCtl* ctl = ix->w_ctl.as<DevCtl>();
   // (profile 2 = cumulative: the row counter runs until the next configure())
-  hipLaunchKernelGGL(k_arm_deadline, dim3(1), dim3(1), 0, st, ctl, (unsigned long long)timeout_ms * ix->wall_khz,
-                     (ix->profile & MI355_PROFILE_MASK) != 2 ? 1u : 0u);
+  const unsigned long long ticks = (unsigned long long)timeout_ms * ix->wall_khz;
+  const uint32_t reset = (ix->profile & MI355_PROFILE_MASK) != 2 ? 1u : 0u;
+  if (lat_front_applies(ix, nq, pl)) {  // a handful of queries: the pipeline's first kernel arms the word (one launch less)
+    SearchPlan pl2 = pl;
+    pl2.arm_in_front = true;
+    pl2.arm_ticks = ticks;
+    pl2.arm_reset = reset;
+    return run_ivfpq(ix, d_q, nq, pl2, d_ids, d_dist, d_cnt, d_cnt_ann);
+  }
+  hipLaunchKernelGGL(k_arm_deadline, dim3(1), dim3(1), 0, st, ctl, ticks, reset);
   HIP_TRY(hipGetLastError());
   return run_ivfpq(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann);
 }

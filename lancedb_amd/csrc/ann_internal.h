@@ -207,6 +207,7 @@ struct mi355_index {
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
   // SkewShape of the packed codes (MI355_SCAN_SKEW): columns per slab, slabs per row, generalised kernel or not
   uint32_t sk_M = 0, sk_slabs = 1, sk_slabbed = 0, sk_res_floats = 0;
+  DevBuf w_lut;      // distance-table images of a small batch's pairs (SkewArgs::lut_pre, k_lut_build)
   DevBuf w_partial;  // per-workgroup partial row sums between the slabs of a work item (sk_slabs > 1)
   DevBuf w_cand2b, w_cnt2b;  // the second buffer set of the deferred refine (each set has its own allocations)
   bool defer_cfg = false;    // MI355_CFG_DEFER_REFINE
@@ -282,7 +283,13 @@ struct SearchPlan {
   uint32_t ws_mb = 0;  // workspace budget of this pass in MiB (0 = the default)
   bool defer_refine = false;  // run refine + final merge on the handle's refine stream (results complete at mi355_index_sync)
   uint32_t rset = 0;          // which of the two refine buffer sets this call uses (deferred calls alternate)
+  // the call's control word is armed by the pipeline's first kernel (k_coarse_lat) instead of a k_arm_deadline launch
+  bool arm_in_front = false;
+  unsigned long long arm_ticks = 0;
+  uint32_t arm_reset = 0;
 };
+// the latency front (k_coarse_lat + k_select_plan) applies to this pass: a handful of queries on the production scan
+bool lat_front_applies(const mi355_index* ix, uint32_t nq, const SearchPlan& pl);
 int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl, uint64_t* d_ids,
                   float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann);
 int32_t validate_params(const mi355_search_params* p);

@@ -494,6 +494,133 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
     }
   }
 }
+// ---- latency front, first half (L2 / dot; dim % 4 == 0): the dot chains alone ---------------------------------------
+// k_coarse_split makes every workgroup run the queries' |q|^2 chains before it touches a centroid — 768 dependent fmas
+// fed by dependent LDS reads, ~13 us of the 39 us a single query's coarse stage took on the C3 index — although only
+// the LAST step of a score, fma(-2, dot, |q|^2 + |c|^2), needs them.  Here the centroid workgroups write the raw dot
+// chains (the same d-ascending chains, LPC lanes sharing a centroid's loads, one round of PF pieces per lane in flight),
+// ONE extra workgroup runs the queries' own chains beside them — eight 16-B LDS reads ahead of 32 fmas, per query lane —
+// writes qp / qq for the scan and arms the call's deadline word (what k_arm_deadline did in a launch of its own), and
+// k_select_plan applies the last step when it builds its keys.
+template <int LPC, int PF>
+static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restrict__ q, uint32_t nq, uint32_t dim,
+                                                          const float* __restrict__ cen, uint32_t nlist,
+                                                          float* __restrict__ qp, float* __restrict__ qq_out,
+                                                          float* __restrict__ out /*[nq, nlist] raw dot chains*/,
+                                                          DevCtl* ctl, unsigned long long arm_ticks, uint32_t arm_reset) {
+  constexpr int CPW = 64 / LPC;                      // centroids per wave
+  constexpr int RP = PF * LPC;                       // pieces of a row per round
+  constexpr int JPL = (CS_MAXQ + LPC - 1) / LPC;     // queries per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t dimq = dim + 4u;                    // the pad staggers the queries' banks
+  float* sq = (float*)smem;                          // [nq][dimq]
+  float4* stage = (float4*)(sq + (size_t)nq * dimq); // [CPW][RP + 1]
+  const int lane = threadIdx.x;
+  const uint32_t np = dim / 4u;
+  for (uint32_t j = 0; j < nq; ++j)
+    for (uint32_t d4 = lane; d4 < np; d4 += 64) *(float4*)(sq + (size_t)j * dimq + 4u * d4) = *(const float4*)(q + (size_t)j * dim + 4u * d4);
+  __syncthreads();
+  if (blockIdx.x == gridDim.x - 1u) {  // the queries' own workgroup
+    if (lane == 0 && ctl) {
+      ctl->deadline = arm_ticks ? (unsigned long long)wall_clock64() + arm_ticks : 0ull;
+      ctl->timed_out = 0;
+      if (arm_reset) {
+        ctl->rows_scanned = 0ull;
+        ctl->short_queries = 0u;
+      }
+    }
+    for (uint32_t j = 0; j < nq; ++j)
+      for (uint32_t d4 = lane; d4 < np; d4 += 64) *(float4*)(qp + (size_t)j * dim + 4u * d4) = *(const float4*)(sq + (size_t)j * dimq + 4u * d4);
+    if ((uint32_t)lane < nq) {
+      const float4* v = (const float4*)(sq + (size_t)lane * dimq);
+      float acc = 0.f;
+      for (uint32_t p0 = 0; p0 < np; p0 += 8) {
+        float4 x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (p0 + e < np) x[e] = v[p0 + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (p0 + e >= np) break;
+          acc = __fmaf_rn(x[e].x, x[e].x, acc);
+          acc = __fmaf_rn(x[e].y, x[e].y, acc);
+          acc = __fmaf_rn(x[e].z, x[e].z, acc);
+          acc = __fmaf_rn(x[e].w, x[e].w, acc);
+        }
+      }
+      qq_out[lane] = acc;
+    }
+    return;
+  }
+  const uint32_t cl = (uint32_t)lane / LPC, sub = (uint32_t)lane % LPC;
+  const uint32_t c = blockIdx.x * CPW + cl;
+  const float4* row = (const float4*)(cen + (size_t)min(c, nlist - 1u) * dim);
+  float4* mine = stage + (size_t)cl * (RP + 1);
+  float acc[JPL];
+  const float* qv[JPL];
+  bool on[JPL];
+#pragma unroll
+  for (int i = 0; i < JPL; ++i) {
+    const uint32_t j = sub + (uint32_t)i * LPC;
+    acc[i] = 0.f;
+    on[i] = j < nq;
+    qv[i] = sq + (size_t)(on[i] ? j : 0u) * dimq;
+  }
+  for (uint32_t p0 = 0; p0 < np; p0 += RP) {
+    float4 r[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
+      if (pc < np) r[u] = row[pc];
+    }
+    if (p0) __syncthreads();  // the previous round has been read
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
+      if (pc < np) mine[u * LPC + sub] = r[u];
+    }
+    __syncthreads();
+    const uint32_t lim = min((uint32_t)RP, np - p0);
+    if (on[0]) {
+      // Eight pieces per step: the row's and the queries' LDS reads of a step are all issued before its 32 fmas per
+      // query — read inside the chain, every fma group waited for an LDS round trip of its own (this loop was ~18 of
+      // the kernel's 35 us at one query).
+      for (uint32_t pp = 0; pp < lim; pp += 8) {
+        float4 v[8], x[JPL][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (pp + e < lim) {
+            v[e] = mine[pp + e];
+#pragma unroll
+            for (int i = 0; i < JPL; ++i)
+              if (on[i]) x[i][e] = *(const float4*)(qv[i] + 4u * (p0 + pp + e));
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (pp + e >= lim) break;
+#pragma unroll
+          for (int i = 0; i < JPL; ++i) {
+            if (on[i]) {
+              acc[i] = __fmaf_rn(x[i][e].x, v[e].x, acc[i]);
+              acc[i] = __fmaf_rn(x[i][e].y, v[e].y, acc[i]);
+              acc[i] = __fmaf_rn(x[i][e].z, v[e].z, acc[i]);
+              acc[i] = __fmaf_rn(x[i][e].w, v[e].w, acc[i]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (c >= nlist) return;
+#pragma unroll
+  for (int i = 0; i < JPL; ++i)
+    if (on[i]) out[(size_t)(sub + (uint32_t)i * LPC) * nlist + c] = acc[i];
+}
+template <int LPC, int PF>
+static inline size_t coarse_lat_lds(uint32_t nq, uint32_t dim) {
+  return (size_t)nq * (dim + 4u) * sizeof(float) + (size_t)(64 / LPC) * (PF * LPC + 1) * 16;
+}
 static inline size_t coarse_split_lds(uint32_t nq, uint32_t dim, int lpc) {
   return ((size_t)nq * (dim + 4u) + CS_MAXQ) * sizeof(float) + (size_t)(64 / lpc) * (16 * lpc + 1) * 16;
 }

@@ -430,9 +430,11 @@ static __global__ __launch_bounds__(1024) void k_plan_fused(PlanArgs a) {
 // Items of one partition and class land in pair-index order (the counting planner leaves that order to its atomics;
 // placement affects speed only).  cnt / off / fill are not touched (cnt stays zeroed for the counting planner).
 #define PLAN_SPARSE_MAX_PAIRS 512u
-static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(PlanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
-  __shared__ uint32_t s_xf[9], s_q[9];
+// (the body runs inside any workgroup of >= PLAN_SPARSE_MAX_PAIRS threads: k_plan_sparse alone, or the last workgroup of
+//  k_select_plan.  FRESH: the probe lists were written by OTHER workgroups of the same launch — read them at L2.)
+template <bool FRESH>
+__device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_key /*[PLAN_SPARSE_MAX_PAIRS]*/, uint32_t* s_xf /*[9]*/,
+                                                 uint32_t* s_q /*[9]*/) {
   const uint32_t i = threadIdx.x, lane = i & 63u;
   const uint32_t ncls = a.best_first ? 2u : 1u;
   if (i < 9) {
@@ -443,7 +445,7 @@ static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(Pl
   uint32_t key = 0xFFFFFFFFu, p = 0xFFFFFFFFu, len = 0;
   if (i < a.n_pairs && a.act.on(i / a.nprobe)) {
     for (uint32_t sl = 0; sl < a.n_slices; ++sl) a.cand_cnt[(size_t)i * a.n_slices + sl] = 0u;
-    p = a.probes[i];
+    p = FRESH ? __hip_atomic_load(a.probes + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.probes[i];
     len = p < a.nlist ? a.plen[p] : 0u;
     if (len) {
       const uint32_t at = a.opos[p];
@@ -453,7 +455,7 @@ static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(Pl
       key = ncls * s_xf[x] + ((ncls == 2u && plan_class(a, i) == 0u) ? qlen : 0u) + idx;
     }
   }
-  s_key[i] = key;
+  if (i < PLAN_SPARSE_MAX_PAIRS) s_key[i] = key;
   // queue x starts behind the items whose place is below its first virtual index
 #pragma unroll
   for (uint32_t x = 0; x < 9; ++x) {
@@ -483,8 +485,222 @@ static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(Pl
   if (i < 9) a.q_start[i] = s_q[i] * a.n_slices;
   if (i < 8) a.heads[i * SK_HEAD_STRIDE] = 0;
 }
+static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(PlanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ uint32_t s_xf[9], s_q[9];
+  plan_sparse_body<false>(a, s_key, s_xf, s_q);
+}
+
+// ---- latency front, second half: probe selection of every query + the work list, ONE launch ----------------------
+// A single query spent 24 us in k_select_probes (its byte-radix passes put all 4096 keys of the top bytes into one LDS
+// bin: distances to centroids share sign and exponent) and 6 us in k_plan_sparse, each behind its own launch.  Here:
+// one 1024-thread workgroup per query finishes the coarse scores (k_coarse_lat leaves the raw dot chains; the
+// contract's `fma(-2, dot, |q|^2 + |c|^2)` / `1 - dot` is applied here, bit for bit what k_coarse_small writes), keeps
+// their sort keys in LDS, radix-selects over the key bits that actually DIFFER (block AND / OR of the keys), emits the
+// probe list exactly like k_select_probes (ties at the threshold by ascending partition id, the nearest partition at
+// rank 0), and the last workgroup to finish lays out the scan's work list (plan_sparse_body).
+#define SELPLAN_NT 1024
+#define SELPLAN_MAX_NLIST 8192u
+struct SelectPlanArgs {
+  const float* raw;        // [nq, nlist] dot chains of k_coarse_lat
+  const float* qq;         // [nq] |q|^2 chains
+  const float* cnorm;      // [nlist]
+  uint32_t metric;
+  uint32_t nlist, nprobe;
+  const uint32_t* plen;
+  uint32_t* probes;        // [nq, nprobe]
+  unsigned long long* stat_rows;
+  uint32_t* qthr;          // [nq] reset to "no bound"
+  float* coarse_out;       // [nq, nlist] finished scores (what k_coarse_small would have written), or nullptr
+  uint32_t* ticket;        // one word, zero between launches
+  PlanArgs plan;
+};
+static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  uint32_t* s_keys = (uint32_t*)sp_smem;  // [nlist]
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_and, s_or, s_prefix, s_need, s_less, s_wave_cnt[SELPLAN_NT / 64], s_running, s_best_at, s_eq_all, s_last;
+  __shared__ unsigned long long s_rows, s_best;
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ uint32_t s_xf[9], s_q[9];
+  constexpr int NT = SELPLAN_NT, NW = NT / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t b = blockIdx.x, nlist = a.nlist, nprobe = a.nprobe;
+  uint32_t* out = a.probes + (size_t)b * nprobe;
+  if (tid == 0) {
+    a.qthr[b] = 0xFFFFFFFFu;
+    s_and = 0xFFFFFFFFu;
+    s_or = 0;
+    s_need = nprobe;
+    s_less = 0;
+    s_running = 0;
+    s_rows = 0;
+    s_best = ~0ull;
+    s_best_at = 0;
+    s_eq_all = 0;
+  }
+  __syncthreads();
+  {
+    const float* src = a.raw + (size_t)b * nlist;
+    const float qq = a.metric == MI355_METRIC_DOT ? 0.f : a.qq[b];
+    uint32_t k_and = 0xFFFFFFFFu, k_or = 0;
+    for (uint32_t p = tid; p < nlist; p += NT) {
+      const float acc = src[p];
+      const float v = a.metric == MI355_METRIC_DOT ? 1.0f - acc : __fmaf_rn(-2.0f, acc, qq + a.cnorm[p]);
+      if (a.coarse_out) a.coarse_out[(size_t)b * nlist + p] = v;
+      const uint32_t key = f32_sort_key(v);
+      s_keys[p] = key;
+      k_and &= key;
+      k_or |= key;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      k_and &= (uint32_t)__shfl_xor((int)k_and, off);
+      k_or |= (uint32_t)__shfl_xor((int)k_or, off);
+    }
+    if (lane == 0) {
+      atomicAnd(&s_and, k_and);
+      atomicOr(&s_or, k_or);
+    }
+  }
+  __syncthreads();
+  const uint32_t diff = s_and ^ s_or;
+  // bits above `top` are the same in every key: they are the threshold's too
+  uint32_t top = diff ? 32u - (uint32_t)__clz(diff) : 0u;
+  uint32_t prefix = top >= 32u ? 0u : (s_and & ~((1u << top) - 1u));
+  uint32_t need = nprobe;
+  bool eq_all = !diff && nlist == nprobe;  // (no window at all: every key is the threshold)
+  while (top > 0u) {  // workgroup-uniform
+    const uint32_t w = top < 8u ? top : 8u, shift = top - w;
+    const uint32_t himask = top >= 32u ? 0u : ~((1u << top) - 1u);
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t p = tid; p < nlist; p += NT) {
+      const uint32_t key = s_keys[p];
+      if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & ((1u << w) - 1u)], 1u);
+    }
+    __syncthreads();
+    uint32_t h = 0, inc = 0;
+    if (tid < 256) {  // inclusive scan of the 256 counts over four waves (whole waves: tid < 256 is wave-uniform)
+      h = hist[tid];
+      inc = h;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += v;
+      }
+      if (lane == 63) s_wave_cnt[wid] = inc;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t base = 0;
+      for (int w2 = 0; w2 < wid; ++w2) base += s_wave_cnt[w2];
+      inc += base;
+      if (inc >= need && inc - h < need) {  // exactly one thread: the bin holding the need-th smallest key
+        s_need = need - (inc - h);
+        s_prefix = prefix | ((uint32_t)tid << shift);
+        s_eq_all = (shift == 0u && h == need - (inc - h)) ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    need = s_need;
+    prefix = s_prefix;
+    eq_all = s_eq_all != 0u;
+    top = shift;
+    __syncthreads();  // (s_need / s_prefix are rewritten by the next window)
+  }
+  const uint32_t T = prefix;
+  const uint32_t need_eq = need;             // rows with key == T to take (>= 1)
+  const uint32_t n_less = nprobe - need_eq;  // rows with key < T
+  unsigned long long rows = 0;
+  if (eq_all) {  // no tie is cut at the threshold: every key <= T, any order
+    for (uint32_t p = tid; p < nlist; p += NT) {
+      const uint32_t key = s_keys[p];
+      if (key <= T) {
+        out[atomicAdd(&s_less, 1u)] = p;
+        rows += a.plen[p];
+        atomicMin(&s_best, ((unsigned long long)key << 32) | p);
+      }
+    }
+  } else {
+    for (uint32_t p0 = 0; p0 < nlist; p0 += NT) {
+      const uint32_t p = p0 + tid;
+      const uint32_t key = p < nlist ? s_keys[p] : 0xFFFFFFFFu;
+      const bool less = p < nlist && key < T;
+      const bool eq = p < nlist && key == T;
+      if (less) {
+        out[atomicAdd(&s_less, 1u)] = p;
+        rows += a.plen[p];
+        atomicMin(&s_best, ((unsigned long long)key << 32) | p);
+      }
+      // ordered rank among the equal keys (ascending partition id)
+      const uint64_t bal = __ballot(eq);
+      if (lane == 0) s_wave_cnt[wid] = (uint32_t)__popcll((unsigned long long)bal);
+      __syncthreads();
+      uint32_t base = s_running, all = 0;
+      for (int w2 = 0; w2 < NW; ++w2) {
+        const uint32_t c = s_wave_cnt[w2];
+        if (w2 < wid) base += c;
+        all += c;
+      }
+      const uint32_t rank = base + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
+      if (eq && rank < need_eq) {
+        out[n_less + rank] = p;
+        rows += a.plen[p];
+        atomicMin(&s_best, ((unsigned long long)key << 32) | p);
+      }
+      __syncthreads();
+      if (tid == 0) s_running += all;
+      __syncthreads();
+    }
+  }
+  if (rows) atomicAdd(&s_rows, rows);
+  __threadfence();  // this query's probe list is at L2 before the ticket is taken
+  __syncthreads();
+  if (tid == 0 && a.stat_rows) atomicAdd(a.stat_rows, s_rows);
+  if (nprobe > 1) {  // the nearest partition (ties: lowest id) moves to rank 0
+    const uint32_t best = (uint32_t)s_best;
+    for (uint32_t i = tid; i < nprobe; i += NT)
+      if (__hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == best) s_best_at = i;
+    __syncthreads();
+    if (tid == 0 && s_best_at != 0) {
+      const uint32_t first = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[s_best_at] = first;
+      out[0] = best;
+      __threadfence();
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const uint32_t t = atomicAdd(a.ticket, 1u);
+    s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+    if (s_last) {
+      atomicExch(a.ticket, 0u);  // ready for the next launch
+      __threadfence();
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q);
+}
 
 // ------------------------------------------------------------------- scan ----
+// Where entry (code c, column j) of a distance table of M columns lives, in dwords from the table base: `at` always,
+// `dup` (SK_NONE: none) for the columns stored twice.  ONE definition for the table a work item builds in LDS and the
+// image k_lut_build writes to global memory for the sliced items of a small batch.
+__device__ __forceinline__ void sk_lut_slots(uint32_t c, uint32_t j, uint32_t M, uint32_t& at, uint32_t& dup) {
+#ifdef SK_DUAL
+  // two slabs of 256-B rows; byte address slab*65536 + c*256 + 4u (u >= 64 spills one row on)
+  const uint32_t u = j + 32u;
+  at = (u >= 64u ? 16384u : 0u) + c * 64u + u;
+  dup = j >= M - 31u ? c * 64u + j - (M - 32u) : SK_NONE;
+#else
+  at = c * 128u + j + 32u;
+  dup = j >= M - 31u ? c * 128u + j - (M - 32u) : SK_NONE;
+#endif
+}
+
 struct SkewArgs {
   IndexView ix;
   const float* cbT;         // [256][m][dsub]
@@ -511,12 +727,153 @@ struct SkewArgs {
   uint32_t res_floats;      // LDS floats of the residual: dim, or one slab's M * dsub (SLABBED)
   float2* partial;          // [grid][partial_stride]: per-workgroup partial row sums between slabs (n_slabs > 1)
   uint32_t partial_stride;  // float2 elements per workgroup: (tile positions of the longest unit) * 16 units * 64 lanes
+  // Sliced pairs (n_slices > 1, one slab): the pairs' distance tables as LDS images [pair][sk_table_bytes(M) / 4], built
+  // ONCE per pair by k_lut_build — a work item copies its pair's image (L2 -> LDS) instead of running the 0.59 MFLOP /
+  // 786 KB-of-codebook build again in every slice.  NULL: every item builds its own table.
+  const float* lut_pre;
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
   uint32_t v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 7u;
+}
+
+// The distance tables of a small batch's pairs, once per pair (SkewArgs::lut_pre).  grid = (G, pairs): workgroup g of a
+// pair computes entries e = c * M + j in [g, g+1) * 256 * M / G — whole codes when G divides 256 — from the pair's
+// residual; the arithmetic is build_lut's (same residual subtraction, same element-order fmaf chain, same `1 - acc`
+// for dot, same zero padding columns), so the image equals the table a work item would have built, bit for bit.
+struct LutBuildArgs {
+  IndexView ix;
+  const float* cbT;         // [256][m][dsub]
+  const float* qp;          // [nq, dim]
+  const uint32_t* probes;   // [n_pairs]
+  uint32_t nprobe;
+  uint32_t M;               // columns of the table (SkewShape::M, one slab)
+  uint32_t table_dwords;    // sk_table_bytes(M) / 4: pitch of the images
+  float* out;               // [n_pairs][table_dwords]
+  ActiveMask act;
+};
+// DS: sub-vector length the codebook loads are unrolled for (4 / 8 / 16: the reference's dim / m), 0 = any.
+template <int DS>
+static __global__ __launch_bounds__(256) void k_lut_build(LutBuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
+  float* res = (float*)lb_smem;  // [M * dsub]
+  const IndexView& ix = a.ix;
+  const uint32_t pair = blockIdx.y, tid = threadIdx.x;
+  const uint32_t b = pair / a.nprobe;
+  if (!a.act.on(b)) return;
+  const uint32_t dsub = DS ? (uint32_t)DS : ix.dsub, M = a.M;
+  const bool dotm = ix.metric == MI355_METRIC_DOT;
+  const uint32_t n_codes = ix.nbits == 4 ? 16u : 256u;
+  const uint32_t total = n_codes * M;
+  const uint32_t e_lo = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), e_hi = (uint32_t)((uint64_t)total * (blockIdx.x + 1u) / gridDim.x);
+  float* img = a.out + (size_t)pair * a.table_dwords;
+  auto put = [&](uint32_t e, float acc, bool valid) {
+    if (valid && dotm) acc = 1.0f - acc;
+    uint32_t at, dup;
+    sk_lut_slots(e / M, e % M, M, at, dup);
+    img[at] = acc;
+    if (dup != SK_NONE) img[dup] = acc;
+  };
+  // the residual: q - centroid of the pair's partition (a partition id outside the index makes no work item: nothing
+  // reads this pair's image).  The kernel is a chain of memory round trips — probe id -> centroid row -> LDS -> table —
+  // so the codebook loads, which depend on none of them, are issued FIRST (fast path) and wait behind them.
+  auto residual = [&]() -> bool {
+    const uint32_t p = a.probes[pair];
+    if (p >= ix.nlist) return false;
+    const float* q = a.qp + (size_t)b * ix.dim;
+    const float* cen = ix.centroids + (size_t)p * ix.dim;
+    for (uint32_t d = tid; d < M * dsub; d += 256u) {
+      float v = 0.f;
+      if (d < ix.dim) {
+        const float qv = q[d], cv = dotm ? 0.f : cen[d];
+        v = qv - cv;  // dot: q - 0 == q exactly (as in the scan's residual)
+      }
+      res[d] = v;
+    }
+    return true;
+  };
+  if constexpr (DS != 0) {
+    constexpr int V = DS / 4;        // 16-B pieces per codebook entry
+    constexpr int EPR = 16 / V;      // entries per thread per round: 16 pieces in flight
+    bool have_res = false, ok_res = false;
+    for (uint32_t r0 = e_lo; r0 < e_hi; r0 += EPR * 256u) {  // (workgroup-uniform trip count: the barrier below is inside)
+      const uint32_t e0 = r0 + tid;
+      float4 cv4[EPR][V];
+      bool ok[EPR];
+#pragma unroll
+      for (int u = 0; u < EPR; ++u) {
+        const uint32_t e = e0 + u * 256u;
+        ok[u] = false;
+        if (e < e_hi) {
+          const uint32_t c = e / M, j = e % M;
+          ok[u] = j < ix.m;
+          if (ok[u]) {
+            const float* cb = a.cbT + ((size_t)c * ix.m + j) * DS;
+#pragma unroll
+            for (int v = 0; v < V; ++v) cv4[u][v] = *(const float4*)(cb + 4 * v);
+          }
+        }
+      }
+      if (!have_res) {  // first round only
+        ok_res = residual();
+        have_res = true;
+        __syncthreads();
+        if (!ok_res) return;
+      }
+#pragma unroll
+      for (int u = 0; u < EPR; ++u) {
+        const uint32_t e = e0 + u * 256u;
+        if (e < e_hi) {
+          float acc = 0.f;
+          if (ok[u]) {
+            const float* rj = res + (e % M) * DS;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              const float4 r = *(const float4*)(rj + 4 * v);
+              const float4 c = cv4[u][v];
+              if (dotm) {
+                acc = __fmaf_rn(r.x, c.x, acc);
+                acc = __fmaf_rn(r.y, c.y, acc);
+                acc = __fmaf_rn(r.z, c.z, acc);
+                acc = __fmaf_rn(r.w, c.w, acc);
+              } else {
+                const float d0 = r.x - c.x, d1 = r.y - c.y, d2 = r.z - c.z, d3 = r.w - c.w;
+                acc = __fmaf_rn(d0, d0, acc);
+                acc = __fmaf_rn(d1, d1, acc);
+                acc = __fmaf_rn(d2, d2, acc);
+                acc = __fmaf_rn(d3, d3, acc);
+              }
+            }
+          }
+          put(e, acc, ok[u]);
+        }
+      }
+    }
+  } else {
+    const bool ok_res = residual();
+    __syncthreads();
+    if (!ok_res) return;
+    for (uint32_t e = e_lo + tid; e < e_hi; e += 256u) {
+      const uint32_t c = e / M, j = e % M;
+      const bool valid = j < ix.m;
+      float acc = 0.f;
+      if (valid) {
+        const float* cb = a.cbT + ((size_t)c * ix.m + j) * dsub;
+        const float* rj = res + j * dsub;
+        for (uint32_t t = 0; t < dsub; ++t) {
+          if (dotm) {
+            acc = __fmaf_rn(rj[t], cb[t], acc);
+          } else {
+            const float df = rj[t] - cb[t];
+            acc = __fmaf_rn(df, df, acc);
+          }
+        }
+      }
+      put(e, acc, valid);
+    }
+  }
 }
 
 // plain chunks g = G .. CPT-1 of a tile (steps >= 32)
@@ -668,7 +1025,8 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     const uint32_t b = pair / a.nprobe;
     const uint32_t n_tiles = (len + SK_TILE - 1) / SK_TILE;
     Cand* out = a.cand + (size_t)oslot * a.kk;
-    SK_DEV(const unsigned long long dv_t0 = wall_clock64(); unsigned long long dv_scan = 0, dv_merge = 0; uint32_t dv_adm = 0;)
+    SK_DEV(const unsigned long long dv_t0 = wall_clock64(); unsigned long long dv_scan = 0, dv_merge = 0; uint32_t dv_adm = 0;
+           const unsigned long long dv_c0 = clock64();)  // shader-clock ticks of the item -> dev[5] (with dev[0..2]: the clock the chip holds)
 
     // ---- pop the NEXT item now; its index arrives behind the LUT phase's loads
     uint32_t pf = SK_NONE, pf_q0 = 0, pf_n = 0;
@@ -699,15 +1057,10 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         const uint32_t c = e / (uint32_t)M, j = e % (uint32_t)M;
         if (dotm) acc = 1.0f - acc;
         if (SLABBED && !valid) acc = 0.f;  // a padding column: `+ 0.0f` is exact
-#ifdef SK_DUAL
-        // two slabs of 256-B rows; byte address slab*65536 + c*256 + 4u (u >= 64 spills one row on)
-        const uint32_t u = j + 32;
-        lut[(u >= 64u ? 16384u : 0u) + c * 64u + u] = acc;
-        if (j >= (uint32_t)(M - 31)) lut[c * 64u + j - (M - 32)] = acc;
-#else
-        lut[c * P + j + 32] = acc;
-        if (j >= (uint32_t)(M - 31)) lut[c * P + j - (M - 32)] = acc;
-#endif
+        uint32_t at, dup;
+        sk_lut_slots(c, j, (uint32_t)M, at, dup);
+        lut[at] = acc;
+        if (dup != SK_NONE) lut[dup] = acc;
       };
       // entry e = (code c, column j) -> its codebook vector [256][ix.m][dsub] and whether the column exists
       auto cb_of = [&](uint32_t e, bool& valid) -> size_t {
@@ -814,7 +1167,13 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         }
       }
     };
-    if (!(a.dbg & 1u)) build_lut(0);
+    if (a.lut_pre) {
+      // the pair's table was built once for all of its slices (k_lut_build): copy the image, 16 B per thread per step
+      const float4* img = (const float4*)(a.lut_pre + (size_t)pair * (TABLE_BYTES / 4u));
+      for (uint32_t i = tid; i < TABLE_BYTES / 16u; i += NT) ((float4*)lut)[i] = img[i];
+    } else if (!(a.dbg & 1u)) {
+      build_lut(0);
+    }
     // the next item's record: one dependent load, lands during the scan
     SkewItem nxt;
     nxt.pair = SK_NONE;
@@ -1339,7 +1698,8 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       __syncthreads();
       if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     }
-    SK_DEV(if (tid == 0) { atomicAdd(&a.ctl->dev[1], (uint32_t)dv_scan); atomicAdd(&a.ctl->dev[2], (uint32_t)dv_merge); }
+    SK_DEV(if (tid == 0 && !OPT) { atomicAdd(&a.ctl->dev[5], (uint32_t)(clock64() - dv_c0)); }
+           if (tid == 0) { atomicAdd(&a.ctl->dev[1], (uint32_t)dv_scan); atomicAdd(&a.ctl->dev[2], (uint32_t)dv_merge); }
            (void)dv_adm;)
     __syncthreads();  // LDS is rebuilt by the next item
   }

@@ -104,3 +104,45 @@ def test_block_merge_short_list_with_ties_and_overflow(oracle, dup):
         for k in (1, 10, 64, 100, 250, 1000, 1500):
             kw = dict(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
             _same(ix.search(q, **kw), o.search(q, **kw))
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_latency_front_probe_selection_with_tied_and_degenerate_scores(oracle, metric):
+    """<= 8 queries on the production scan (L2 / dot, dim % 4 == 0, nlist <= 8192): k_coarse_lat writes the raw dot chains,
+    k_select_plan finishes the scores, selects the probes over the key bits that differ and lays out the work list.
+    Duplicated centroids tie exactly at the selection threshold (ties go to the lowest partition id), identical
+    centroids leave no differing bit at all, a far-away query mixes signs (dot) — the probe sets, and therefore the
+    results, must be the oracle's; nprobe = 1, = nlist and in between."""
+    rng = np.random.default_rng(3)
+    n, dim, m, nlist = 60_000, 64, 16, 96
+    s = train.synthetic_index(n, dim, nlist, m, seed=21, skew=0.7, empty_parts=2)
+    cen = s["centroids"].copy()
+    cen[10:40] = cen[5]          # 31 partitions at exactly the same score for every query
+    cen[60:64] = cen[59]
+    for variant in ("dups", "all_equal"):
+        c = cen if variant == "dups" else np.repeat(cen[:1], nlist, axis=0)
+        ix = lancedb_amd.IvfPqIndex(c, s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
+        o = oracle.OracleIndex(c, s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
+        ix.configure(graph=False, coalesce=False)
+        for nq in (1, 2, 5, 8):
+            q = (c[rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.3, size=(nq, dim))).astype(np.float32)
+            q[0] = c[5]  # sits on the duplicated centroid: the tie is at the TOP of the list
+            if nq > 1:
+                q[1] = -40.0 * c[7]  # far away, opposite side: dot scores of both signs
+            for nprobe in (1, 7, 20, 33, 64, nlist):
+                kw = dict(k=10, nprobe_min=nprobe, nprobe_max=nprobe)
+                _same(ix.search(q, **kw), o.search(q, **kw))
+
+
+def test_latency_front_serves_concurrent_shapes_back_to_back(oracle):
+    """The ticket word of k_select_plan returns to zero after every launch: alternating batch sizes (1, 8, 3, 9 = the
+    general front, 1 ...) on one handle keep returning the oracle's results."""
+    rng = np.random.default_rng(8)
+    n, dim, m, nlist = 200_000, 128, 32, 256
+    s = train.synthetic_index(n, dim, nlist, m, seed=2, skew=0.5)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    for nq in (1, 8, 3, 9, 1, 64, 2, 1, 8):
+        q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.5, size=(nq, dim))).astype(np.float32)
+        kw = dict(k=10, nprobe_min=32, nprobe_max=32)
+        _same(ix.search(q, **kw), o.search(q, **kw))

@@ -56,6 +56,7 @@ for k in (10, 100, 250, 500):
         items = max(c[3], 1)
         tick_us = 0.01  # wall_clock64: 100 MHz
         line += (f" | per item: lut {c[0] * tick_us / items:.1f} us, scan {c[1] * tick_us / items:.1f} us, merge {c[2] * tick_us / items:.1f} us; "
-                 f"items {c[3] // reps}, in lists at merge/item {c[4] / items:.0f}, redone passes {c[5] // reps}, "
+                 f"items {c[3] // reps}, in lists at merge/item {c[4] / items:.0f}, "
+                 f"{'redone passes ' + str(c[5] // reps) if k > 128 else 'shader clock over the items ' + format(c[5] / max(c[0] + c[1] + c[2], 1) * 100, '.0f') + ' MHz'}, "
                  f"merge split: barrier->ranking {c[6] * tick_us / items:.1f} us, ranking {c[7] * tick_us / items:.1f} us (thread 0)")
     print(line, flush=True)

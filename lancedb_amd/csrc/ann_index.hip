@@ -61,12 +61,13 @@ extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) try {
   // queries re-searched over maximum_nprobes partitions were counted on the device
   out->n_queries += h_ctl.short_queries;
   out->partitions_probed += (uint64_t)h_ctl.short_queries * ix->second_np;
+  out->work_items += h_ctl.lat_items;  // (work items the sparse planner cut by rows are counted where they are made)
   out->struct_size = sizeof(mi355_stats);
   return MI355_OK;
 } MI355_ABI_GUARD("mi355_last_stats")
 
-#ifdef MI355_DEV_COUNTERS
-// dev builds only (never in the product library): the scan's phase ticks and selection counters
+#if defined(MI355_DEV_COUNTERS) || defined(MI355_DEV_FRONT)
+// dev builds only (never in the product library): the scan's phase ticks and selection counters (or the front kernels' stage ticks)
 extern "C" int32_t mi355_dev_counters(mi355_index* ix, uint32_t* out8, int32_t reset) try {
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -191,7 +192,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   slice = (slice + 15u) & ~15u;
   // the production scan slices by tile positions instead (SkewArgs::n_slices): only when the batch cannot
   // give every CU a work item, and never below ~2 k rows per slice (each slice rebuilds the distance table)
-  uint32_t sk_slices = 1;
+  uint32_t sk_slices = 1, sk_target = 0;
   if (skew) {
     const uint64_t pairs = (uint64_t)nq * nprobe;
     // (round 4: up to 3 work items per CU.  A batch of 8 queries is 512 whole-partition items on 256 CUs: its scan took
@@ -199,8 +200,17 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     //  distance table, so batches that already give a CU 3 items keep whole partitions.)
     if (pairs && pairs < 3ull * ix->n_cus)
       sk_slices = (uint32_t)std::min<uint64_t>(dev_knob("MI355_LAT_SLICES_MAX", 8), (3ull * ix->n_cus + pairs - 1) / pairs);
+    // A handful of queries (the sparse planner): pairs are cut BY ROWS — about `sk_target` work items of about equal
+    // length (one per CU for a single query: a work item's fixed costs, its distance table first, are paid once per CU
+    // and no CU waits for the longest partition's slice); sk_slices is then the most slices one pair can get.
+    if (pairs && pairs <= PLAN_SPARSE_MAX_PAIRS && pairs < 3ull * ix->n_cus && dev_knob("MI355_LAT_BY_ROWS", 0) && dev_knob("MI355_PLAN_SPARSE", 1)) {
+      const uint32_t per_cu = dev_knob("MI355_LAT_ITEMS_PER_CU", 0);
+      sk_target = per_cu ? per_cu * ix->n_cus : pairs <= ix->n_cus / 2 ? ix->n_cus : pairs <= ix->n_cus ? 2 * ix->n_cus : 3 * ix->n_cus;
+      sk_slices = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, (7ull * sk_target / 2 + pairs - 1) / pairs));
+    }
     sk_slices = std::max(1u, std::min(sk_slices, ix->max_len / 2048u));
     if (pl.kk > 256u) sk_slices = 1;  // (multi-pass selection re-scans per pass: keep whole partitions)
+    if (sk_slices <= 1u) sk_target = 0;
   }
   const uint32_t n_slices = skew ? sk_slices : std::max(1u, (ix->max_len + slice - 1) / slice);
 
@@ -297,6 +307,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       // sharded coarse merge, otherwise rank 0 is just the caller's first probe
       pa.best_first = (pl.kk >= dev_knob("MI355_BEST_FIRST_MIN_KK", 1) && nprobe > 1u) ? 1u : 0u;
       pa.n_slices = n_slices;
+      pa.target_items = (pa.n_pairs <= PLAN_SPARSE_MAX_PAIRS) ? sk_target : 0u;
+      pa.items_made = pa.target_items ? &d_ctl->lat_items : (uint32_t*)nullptr;
       pa.act = act;
     }
     if (lat_front) {
@@ -329,7 +341,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       sp.coarse_out = nullptr;
       sp.ticket = ix->heads.as<uint32_t>() + 8 * SK_HEAD_STRIDE;
       sp.plan = pa;
-      hipLaunchKernelGGL(k_select_plan, dim3(n), dim3(SELPLAN_NT), (size_t)ix->nlist * 4u, st, sp);
+      hipLaunchKernelGGL(k_select_plan, dim3(n), dim3(SELPLAN_NT), ((size_t)ix->nlist + nprobe) * 4u, st, sp);
       HIP_TRY(hipGetLastError());
     } else {
     const size_t small_lds = ((size_t)n * (((size_t)ix->dim + 3) & ~(size_t)3) + n) * sizeof(float);
@@ -431,47 +443,6 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ka.res_floats = ix->sk_res_floats;
       ka.partial = nullptr;
       ka.partial_stride = 0;
-      ka.lut_pre = nullptr;
-      if (n_slices > 1 && ix->sk_slabs == 1 && dev_knob("MI355_LAT_LUT_PRE", 1)) {
-        // sliced pairs: every pair's distance table once (k_lut_build), the slices copy the image
-        const uint32_t table_dwords = sk_table_bytes(ix->sk_M) / 4u;
-        const uint32_t n_pairs = n * nprobe;
-        ST_TRY(ix->w_lut.ensure((size_t)n_pairs * table_dwords * 4u));
-        LutBuildArgs la;
-        la.ix = view;
-        la.cbT = ix->cbT.as<float>();
-        la.qp = ix->w_qp.as<float>();
-        la.probes = ix->w_probes.as<uint32_t>();
-        la.nprobe = nprobe;
-        la.M = ix->sk_M;
-        la.table_dwords = table_dwords;
-        la.out = ix->w_lut.as<float>();
-        la.act = act;
-        // four workgroups per CU when the pairs are few: a thread then loads all its codebook entries in one round
-        uint32_t g = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, (4ull * ix->n_cus + n_pairs - 1) / n_pairs));
-        const size_t lds = (size_t)ix->sk_M * ix->dsub * sizeof(float);
-        if (lds > 64u * 1024) return fail(MI355_ERR_NOT_SUPPORTED, "residual of %zu B does not fit the table builder", lds);
-        auto go = [&](auto kern) -> int {
-          if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(kern, dim3(g, n_pairs), dim3(256), lds, st, la);
-          return MI355_OK;
-        };
-        const int rc = ix->dsub == 8 ? go(k_lut_build<8>) : ix->dsub == 16 ? go(k_lut_build<16>) : ix->dsub == 4 ? go(k_lut_build<4>) : go(k_lut_build<0>);
-        if (rc != MI355_OK) return rc;
-        HIP_TRY(hipGetLastError());
-        ka.lut_pre = ix->w_lut.as<float>();
-      }
-      if (ix->sk_slabs > 1) {
-        // partial row sums between the slabs of a work item: 8 B per (tile position, unit, lane) of the longest partition,
-        // per workgroup (persistent: one work item at a time)
-        const uint64_t n_tiles = ((uint64_t)ix->max_len + SK_TILE - 1) / SK_TILE;
-        const uint64_t stride = ((n_tiles + SK_STREAMS - 1) / SK_STREAMS + 1) * SK_UNITS * MI355_WAVE;
-        if (stride >= (1ull << 31)) return fail(MI355_ERR_NOT_SUPPORTED, "a partition of %u rows is too long for the multi-slab scan", ix->max_len);
-        while (n_blocks > 8 && stride * 8 * n_blocks > (2ull << 30)) n_blocks /= 2;  // (very long partitions: fewer workgroups)
-        ST_TRY(ix->w_partial.ensure((size_t)stride * 8 * n_blocks));
-        ka.partial = ix->w_partial.as<float2>();
-        ka.partial_stride = (uint32_t)stride;
-      }
       ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
     } else {
       ScanArgs sa;
@@ -578,7 +549,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ix->ev_pending.push_back(es);
     }
   }
-  ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
+  if (!(skew && sk_target && (uint64_t)std::min(chunk, nq) * nprobe <= PLAN_SPARSE_MAX_PAIRS))  // (cut by rows: counted on the device, DevCtl::lat_items)
+    ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
   return MI355_OK;
 }
 

@@ -248,6 +248,7 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   const size_t q_bytes = sizeof(float) * (size_t)n_queries * ix->dim;
   const size_t r_bytes = (size_t)n_queries * k * (sizeof(uint64_t) + sizeof(float)) + sizeof(uint32_t) * (size_t)n_queries;
   const bool pinned = host_io && q_bytes + r_bytes <= ((size_t)4 << 20);
+  bool zero_copy_out = false;
   unsigned char* h_pin = nullptr;
   if (host_io) {
     ST_TRY(ix->w_q.ensure(q_bytes));
@@ -268,7 +269,11 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
         off += sizeof(float) * (size_t)c.nq * ix->dim;
       }
       HIP_TRY(hipMemcpyAsync(ix->w_q.p, h_pin, q_bytes, hipMemcpyHostToDevice, st));
-      d_ids = ix->w_ids.as<uint64_t>();
+      // The result arrays of a small batch are the page-locked block itself: the last kernel of the call stores its
+      // (k ids + k distances + count) per query straight into host memory (posted PCIe writes, complete at the stream
+      // synchronisation below) — the copy kernel that used to follow it was 4 us and a launch per call.
+      zero_copy_out = n_queries <= 64 && dev_knob("MI355_LAT_ZERO_COPY_OUT", 1);
+      d_ids = zero_copy_out ? (uint64_t*)(h_pin + q_bytes) : ix->w_ids.as<uint64_t>();
       d_dist = (float*)(d_ids + (size_t)n_queries * k);
       d_cnt = (uint32_t*)(d_dist + (size_t)n_queries * k);
     } else {
@@ -332,10 +337,12 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
     if (pinned) {
       unsigned char* h_res = h_pin + q_bytes;
       DevCtl* h_c = (DevCtl*)(h_pin + ((q_bytes + r_bytes + 63) & ~(size_t)63));
-      HIP_TRY(hipMemcpyAsync(h_res, d_ids, r_bytes, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(h_c, ix->w_ctl.p, sizeof(DevCtl), hipMemcpyDeviceToHost, st));
+      if (!zero_copy_out) HIP_TRY(hipMemcpyAsync(h_res, d_ids, r_bytes, hipMemcpyDeviceToHost, st));
+      // the control word only says something for calls with a deadline or an external probe list
+      const bool want_ctl = p->timeout_ms != 0 || ext_probes != nullptr;
+      if (want_ctl) HIP_TRY(hipMemcpyAsync(h_c, ix->w_ctl.p, sizeof(DevCtl), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      h_ctl = *h_c;
+      if (want_ctl) h_ctl = *h_c; else memset(&h_ctl, 0, sizeof h_ctl);
       const uint64_t* r_ids = (const uint64_t*)h_res;
       const float* r_dist = (const float*)(r_ids + (size_t)n_queries * k);
       const uint32_t* r_cnt = (const uint32_t*)(r_dist + (size_t)n_queries * k);

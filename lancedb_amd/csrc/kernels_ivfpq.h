@@ -336,8 +336,7 @@ static __global__ __launch_bounds__(64) void k_coarse_small(const float* __restr
     for (uint32_t d0 = 0; d0 < dim; d0 += 4 * PF) {
       float4 r[PF];
 #pragma unroll
-      for (int u = 0; u < PF; ++u)
-        if (d0 + 4 * u < dim) r[u] = *(const float4*)(row + d0 + 4 * u);
+      for (int u = 0; u < PF; ++u) r[u] = *(const float4*)(row + min(d0 + 4u * u, dim - 4u));  // (clamped, unconditional: see k_coarse_lat)
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         if (d0 + 4 * u >= dim) break;
@@ -381,6 +380,10 @@ static __global__ __launch_bounds__(64) void k_coarse_small(const float* __restr
 // round of PF * LPC pieces in LDS and each lane then walks the whole round in d order for ITS queries (query j is
 // lane j % LPC's), so every accumulator is still the one d-ascending chain.  LPC times the waves = LPC times the
 // bytes in flight; the chains themselves take what they took.
+// (register arrays of the small-batch coarse kernels are clang ext-vectors, not HIP's float4 struct: an array of 12+
+//  float4 stays in SCRATCH — hipcc then waits for every global load on its own to store it there: 24 serial HBM round
+//  trips, 16 of k_coarse_lat's 27 us; scripts/check_scratch.py lists the kernels that use scratch)
+typedef __attribute__((ext_vector_type(4))) float cl_f32x4;
 template <int LPC>
 static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restrict__ q, uint32_t nq, uint32_t dim, uint32_t metric,
                                                             const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist,
@@ -394,7 +397,7 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
   const uint32_t dimq = dim + 4u;                    // dim % 4 == 0 here; the pad staggers the queries' banks
   float* sq = (float*)smem;                          // [nq][dimq]
   float* sqq = sq + (size_t)nq * dimq;               // [CS_MAXQ]
-  float4* stage = (float4*)(sqq + CS_MAXQ);          // [CPW][RP + 1]
+  cl_f32x4* stage = (cl_f32x4*)(sqq + CS_MAXQ);          // [CPW][RP + 1]
   const int lane = threadIdx.x;
   for (uint32_t j = 0; j < nq; ++j)
     for (uint32_t d = lane; d < dim; d += 64) sq[(size_t)j * dimq + d] = q[(size_t)j * dim + d];
@@ -402,7 +405,7 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
   auto chain_sq = [&](const float* v) -> float {
     float acc = 0.f;
     for (uint32_t d = 0; d < dim; d += 4) {
-      const float4 x = *(const float4*)(v + d);
+      const cl_f32x4 x = *(const cl_f32x4*)(v + d);
       acc = __fmaf_rn(x.x, x.x, acc);
       acc = __fmaf_rn(x.y, x.y, acc);
       acc = __fmaf_rn(x.z, x.z, acc);
@@ -428,8 +431,8 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
   }
   const uint32_t cl = (uint32_t)lane / LPC, sub = (uint32_t)lane % LPC;
   const uint32_t c = blockIdx.x * CPW + cl;
-  const float4* row = (const float4*)(cen + (size_t)min(c, nlist - 1u) * dim);
-  float4* mine = stage + (size_t)cl * (RP + 1);
+  const cl_f32x4* row = (const cl_f32x4*)(cen + (size_t)min(c, nlist - 1u) * dim);
+  cl_f32x4* mine = stage + (size_t)cl * (RP + 1);
   const uint32_t np = dim / 4u;
   float acc[JPL];
   const float* qv[JPL];
@@ -442,23 +445,19 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
     qv[i] = sq + (size_t)(on[i] ? j : 0u) * dimq;
   }
   for (uint32_t p0 = 0; p0 < np; p0 += RP) {
-    float4 r[PF];
+    // (unconditional loads at a clamped piece: guarded per array element, hipcc waits for every load on its own —
+    //  see k_coarse_lat; the pieces past the row's end land in stage slots the chain never reads)
+    cl_f32x4 r[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
-      if (pc < np) r[u] = row[pc];
-    }
+    for (int u = 0; u < PF; ++u) r[u] = row[min(p0 + (uint32_t)u * LPC + sub, np - 1u)];
     __syncthreads();  // the previous round has been read
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
-      if (pc < np) mine[u * LPC + sub] = r[u];
-    }
+    for (int u = 0; u < PF; ++u) mine[u * LPC + sub] = r[u];
     __syncthreads();
     const uint32_t lim = min((uint32_t)RP, np - p0);
     if (on[0]) {
       for (uint32_t pp = 0; pp < lim; pp += 4) {  // np % 4 need not be 0: the inner bound is checked
-        float4 v[4];
+        cl_f32x4 v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (pp + e < lim) v[e] = mine[pp + e];
@@ -468,7 +467,7 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
 #pragma unroll
           for (int i = 0; i < JPL; ++i) {
             if (on[i]) {
-              const float4 x = *(const float4*)(qv[i] + 4u * (p0 + pp + e));
+              const cl_f32x4 x = *(const cl_f32x4*)(qv[i] + 4u * (p0 + pp + e));
               acc[i] = __fmaf_rn(x.x, v[e].x, acc[i]);
               acc[i] = __fmaf_rn(x.y, v[e].y, acc[i]);
               acc[i] = __fmaf_rn(x.z, v[e].z, acc[i]);
@@ -502,6 +501,9 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
 // ONE extra workgroup runs the queries' own chains beside them — eight 16-B LDS reads ahead of 32 fmas, per query lane —
 // writes qp / qq for the scan and arms the call's deadline word (what k_arm_deadline did in a launch of its own), and
 // k_select_plan applies the last step when it builds its keys.
+// (register arrays of this kernel are clang ext-vectors, not HIP's cl_f32x4 struct: an array of 12+ cl_f32x4 stays in SCRATCH —
+//  hipcc then waits for every global load on its own to store it there: 24 serial HBM round trips, 16 of the kernel's 27 us)
+typedef __attribute__((ext_vector_type(4))) float cl_f32x4;
 template <int LPC, int PF>
 static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restrict__ q, uint32_t nq, uint32_t dim,
                                                           const float* __restrict__ cen, uint32_t nlist,
@@ -514,11 +516,14 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t dimq = dim + 4u;                    // the pad staggers the queries' banks
   float* sq = (float*)smem;                          // [nq][dimq]
-  float4* stage = (float4*)(sq + (size_t)nq * dimq); // [CPW][RP + 1]
+  cl_f32x4* stage = (cl_f32x4*)(sq + (size_t)nq * dimq); // [CPW][RP + 1]
   const int lane = threadIdx.x;
   const uint32_t np = dim / 4u;
+#ifdef MI355_DEV_FRONT  // dev: block 0's stage times -> DevCtl::dev[0..3] (query to LDS / row loads + staging / chains / store)
+  const unsigned long long cf_t0 = wall_clock64();
+#endif
   for (uint32_t j = 0; j < nq; ++j)
-    for (uint32_t d4 = lane; d4 < np; d4 += 64) *(float4*)(sq + (size_t)j * dimq + 4u * d4) = *(const float4*)(q + (size_t)j * dim + 4u * d4);
+    for (uint32_t d4 = lane; d4 < np; d4 += 64) *(cl_f32x4*)(sq + (size_t)j * dimq + 4u * d4) = *(const cl_f32x4*)(q + (size_t)j * dim + 4u * d4);
   __syncthreads();
   if (blockIdx.x == gridDim.x - 1u) {  // the queries' own workgroup
     if (lane == 0 && ctl) {
@@ -527,35 +532,48 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
       if (arm_reset) {
         ctl->rows_scanned = 0ull;
         ctl->short_queries = 0u;
+        ctl->lat_items = 0u;
       }
     }
     for (uint32_t j = 0; j < nq; ++j)
-      for (uint32_t d4 = lane; d4 < np; d4 += 64) *(float4*)(qp + (size_t)j * dim + 4u * d4) = *(const float4*)(sq + (size_t)j * dimq + 4u * d4);
+      for (uint32_t d4 = lane; d4 < np; d4 += 64) *(cl_f32x4*)(qp + (size_t)j * dim + 4u * d4) = *(const cl_f32x4*)(sq + (size_t)j * dimq + 4u * d4);
     if ((uint32_t)lane < nq) {
-      const float4* v = (const float4*)(sq + (size_t)lane * dimq);
+      const cl_f32x4* v = (const cl_f32x4*)(sq + (size_t)lane * dimq);
       float acc = 0.f;
-      for (uint32_t p0 = 0; p0 < np; p0 += 8) {
-        float4 x[8];
+      // (loads are UNCONDITIONAL, index clamped: a load guarded by `if (i < n)` into an array element makes hipcc
+      //  wait for each one on its own — the disassembly of this file's first version showed 24 serial HBM round trips)
+      uint32_t p0 = 0;
+      for (; p0 + 8 <= np; p0 += 8) {
+        cl_f32x4 x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (p0 + e < np) x[e] = v[p0 + e];
+        for (int e = 0; e < 8; ++e) x[e] = v[p0 + e];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          if (p0 + e >= np) break;
           acc = __fmaf_rn(x[e].x, x[e].x, acc);
           acc = __fmaf_rn(x[e].y, x[e].y, acc);
           acc = __fmaf_rn(x[e].z, x[e].z, acc);
           acc = __fmaf_rn(x[e].w, x[e].w, acc);
         }
       }
+      for (; p0 < np; ++p0) {
+        const cl_f32x4 x = v[p0];
+        acc = __fmaf_rn(x.x, x.x, acc);
+        acc = __fmaf_rn(x.y, x.y, acc);
+        acc = __fmaf_rn(x.z, x.z, acc);
+        acc = __fmaf_rn(x.w, x.w, acc);
+      }
       qq_out[lane] = acc;
     }
     return;
   }
+#ifdef MI355_DEV_FRONT
+  const unsigned long long cf_t1 = wall_clock64();
+  unsigned long long cf_t2 = 0;
+#endif
   const uint32_t cl = (uint32_t)lane / LPC, sub = (uint32_t)lane % LPC;
   const uint32_t c = blockIdx.x * CPW + cl;
-  const float4* row = (const float4*)(cen + (size_t)min(c, nlist - 1u) * dim);
-  float4* mine = stage + (size_t)cl * (RP + 1);
+  const cl_f32x4* row = (const cl_f32x4*)(cen + (size_t)min(c, nlist - 1u) * dim);
+  cl_f32x4* mine = stage + (size_t)cl * (RP + 1);
   float acc[JPL];
   const float* qv[JPL];
   bool on[JPL];
@@ -567,55 +585,70 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
     qv[i] = sq + (size_t)(on[i] ? j : 0u) * dimq;
   }
   for (uint32_t p0 = 0; p0 < np; p0 += RP) {
-    float4 r[PF];
+    // one round: PF pieces per lane, all in flight at once — unconditional loads at a clamped index (see above); the
+    // pieces past the row's end land in stage slots the chain never reads
+    cl_f32x4 r[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
-      if (pc < np) r[u] = row[pc];
-    }
+    for (int u = 0; u < PF; ++u) r[u] = row[min(p0 + (uint32_t)u * LPC + sub, np - 1u)];
     if (p0) __syncthreads();  // the previous round has been read
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const uint32_t pc = p0 + (uint32_t)u * LPC + sub;
-      if (pc < np) mine[u * LPC + sub] = r[u];
-    }
+    for (int u = 0; u < PF; ++u) mine[u * LPC + sub] = r[u];
     __syncthreads();
+#ifdef MI355_DEV_FRONT
+    if (p0 == 0) cf_t2 = wall_clock64();
+#endif
     const uint32_t lim = min((uint32_t)RP, np - p0);
     if (on[0]) {
       // Eight pieces per step: the row's and the queries' LDS reads of a step are all issued before its 32 fmas per
-      // query — read inside the chain, every fma group waited for an LDS round trip of its own (this loop was ~18 of
-      // the kernel's 35 us at one query).
-      for (uint32_t pp = 0; pp < lim; pp += 8) {
-        float4 v[8], x[JPL][8];
+      // query — read inside the chain, every fma group waited for an LDS round trip of its own.
+      uint32_t pp = 0;
+      for (; pp + 8 <= lim; pp += 8) {
+        cl_f32x4 v[8], x[JPL][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          if (pp + e < lim) {
-            v[e] = mine[pp + e];
+          v[e] = mine[pp + e];
 #pragma unroll
-            for (int i = 0; i < JPL; ++i)
-              if (on[i]) x[i][e] = *(const float4*)(qv[i] + 4u * (p0 + pp + e));
-          }
+          for (int i = 0; i < JPL; ++i) x[i][e] = *(const cl_f32x4*)(qv[i] + 4u * (p0 + pp + e));  // (an idle slot reads query 0)
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          if (pp + e >= lim) break;
 #pragma unroll
           for (int i = 0; i < JPL; ++i) {
-            if (on[i]) {
-              acc[i] = __fmaf_rn(x[i][e].x, v[e].x, acc[i]);
-              acc[i] = __fmaf_rn(x[i][e].y, v[e].y, acc[i]);
-              acc[i] = __fmaf_rn(x[i][e].z, v[e].z, acc[i]);
-              acc[i] = __fmaf_rn(x[i][e].w, v[e].w, acc[i]);
-            }
+            acc[i] = __fmaf_rn(x[i][e].x, v[e].x, acc[i]);
+            acc[i] = __fmaf_rn(x[i][e].y, v[e].y, acc[i]);
+            acc[i] = __fmaf_rn(x[i][e].z, v[e].z, acc[i]);
+            acc[i] = __fmaf_rn(x[i][e].w, v[e].w, acc[i]);
           }
+        }
+      }
+      for (; pp < lim; ++pp) {
+        const cl_f32x4 v = mine[pp];
+#pragma unroll
+        for (int i = 0; i < JPL; ++i) {
+          const cl_f32x4 x = *(const cl_f32x4*)(qv[i] + 4u * (p0 + pp));
+          acc[i] = __fmaf_rn(x.x, v.x, acc[i]);
+          acc[i] = __fmaf_rn(x.y, v.y, acc[i]);
+          acc[i] = __fmaf_rn(x.z, v.z, acc[i]);
+          acc[i] = __fmaf_rn(x.w, v.w, acc[i]);
         }
       }
     }
   }
+#ifdef MI355_DEV_FRONT
+  const unsigned long long cf_t3 = wall_clock64();
+#endif
   if (c >= nlist) return;
 #pragma unroll
   for (int i = 0; i < JPL; ++i)
     if (on[i]) out[(size_t)(sub + (uint32_t)i * LPC) * nlist + c] = acc[i];
+#ifdef MI355_DEV_FRONT
+  if (ctl && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && lane == 0) {
+    atomicAdd(&ctl->dev[0], (uint32_t)(cf_t1 - cf_t0));
+    atomicAdd(&ctl->dev[1], (uint32_t)(cf_t2 - cf_t1));
+    atomicAdd(&ctl->dev[2], (uint32_t)(cf_t3 - cf_t2));
+    atomicAdd(&ctl->dev[3], 1u);
+  }
+#endif
 }
 template <int LPC, int PF>
 static inline size_t coarse_lat_lds(uint32_t nq, uint32_t dim) {
@@ -1351,9 +1384,11 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
         bool in[G];
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-          const uint32_t t = t0 + (uint32_t)u * NT + tid;
-          in[u] = t < n && t % a.kk_in < s_pre[t / a.kk_in];
-          if (in[u]) c[u] = src[(size_t)(t / a.kk_in) * a.src_stride + t % a.kk_in];
+          // (unconditional load at a clamped slot: guarded, hipcc waits for each of the G records on its own — the
+          //  eight serial round trips were most of a single query's 12 us merge)
+          const uint32_t t = t0 + (uint32_t)u * NT + tid, tc = t < n ? t : n - 1u;
+          in[u] = t < n && t % a.kk_in < s_pre[tc / a.kk_in];
+          c[u] = src[(size_t)(tc / a.kk_in) * a.src_stride + tc % a.kk_in];
         }
 #pragma unroll
         for (int u = 0; u < G; ++u) {

@@ -44,6 +44,7 @@
 
 #include "kernels_ivfpq.h"
 #include "skew_chunks.inc"  // generated inner blocks; defines SK_ADDR_* / SK_SPLIT_*
+typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
 
 #ifndef SK_LUT_INFLIGHT
 #define SK_LUT_INFLIGHT 8  // 16-B codebook loads in flight per thread while the distance table is built
@@ -75,6 +76,14 @@ struct __attribute__((aligned(32))) SkewItem {
 };
 
 __host__ __device__ __forceinline__ uint32_t sk_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// SkewItem::pair of a SLICED batch (SkewArgs::n_slices > 1): [31:26] slices of this pair - 1, [25:20] this item's
+// slice, [19:0] the pair.  The pairs of one batch may be cut into different numbers of slices (the sparse planner cuts
+// by rows, so that a single query's ~n_cus work items are about equally long).
+#define SK_MAX_SLICES 64u
+__host__ __device__ __forceinline__ uint32_t sk_pack_pair(uint32_t pair, uint32_t slice, uint32_t n_sl) {
+  return pair | (slice << 20) | ((n_sl - 1u) << 26);
+}
 
 // phase (steps of delay) of lane l: distinct inside each 32-lane bank group
 __host__ __device__ __forceinline__ uint32_t sk_phase(uint32_t l) {
@@ -307,7 +316,11 @@ struct PlanArgs {
   // candidate lists cost is selection, and selection work follows the rows admitted.  The price is one
   // extra, un-shared read of ~one partition per query (+13 % L2 fills at C3, HBM is 15 % busy).
   uint32_t best_first;
-  uint32_t n_slices;        // work items per pair (SkewArgs::n_slices)
+  uint32_t n_slices;        // work items per pair (SkewArgs::n_slices); the sparse planner: at most this many
+  // Sparse planner only, n_slices > 1: cut every pair into round(len / target) slices, target = probed rows of the batch /
+  // target_items — about target_items work items of about equal length (0 = n_slices slices for every pair).
+  uint32_t target_items;
+  uint32_t* items_made;     // device counter of the work items the sparse planner made (DevCtl::lat_items), or nullptr
   ActiveMask act;           // device-side batch size: pairs of inactive queries make no item, no slot writes
 };
 
@@ -399,7 +412,7 @@ __device__ __forceinline__ void plan_fill_pair(const PlanArgs& a, uint32_t i) {
   const uint32_t key = p + plan_class(a, i) * a.nlist;
   const uint32_t at = a.off[key] + atomicAdd(&a.fill[key], a.n_slices);
   for (uint32_t sl = 0; sl < a.n_slices; ++sl) {
-    it.pair = a.n_slices > 1u ? (i | (sl << 24)) : i;
+    it.pair = a.n_slices > 1u ? sk_pack_pair(i, sl, a.n_slices) : i;
     a.items[at + sl] = it;
   }
 }
@@ -434,21 +447,30 @@ static __global__ __launch_bounds__(1024) void k_plan_fused(PlanArgs a) {
 //  k_select_plan.  FRESH: the probe lists were written by OTHER workgroups of the same launch — read them at L2.)
 template <bool FRESH>
 __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_key /*[PLAN_SPARSE_MAX_PAIRS]*/, uint32_t* s_xf /*[9]*/,
-                                                 uint32_t* s_q /*[9]*/) {
+                                                 uint32_t* s_q /*[10]*/, uint32_t* s_nsl /*[PLAN_SPARSE_MAX_PAIRS]*/,
+                                                 const uint32_t* lds_probes = nullptr /*[n_pairs] in LDS: skip the global read*/,
+                                                 unsigned long long* stat_rows = nullptr /*+= probed rows of the batch*/) {
   const uint32_t i = threadIdx.x, lane = i & 63u;
   const uint32_t ncls = a.best_first ? 2u : 1u;
-  if (i < 9) {
-    s_xf[i] = a.xcd_first[i];
-    s_q[i] = 0;
-  }
+  if (i < 9) s_xf[i] = a.xcd_first[i];
+  if (i < 10) s_q[i] = 0;  // [0..8] items before each queue boundary, [9] probed rows of the batch
   __syncthreads();
+  // (every thread loads unconditionally at clamped indices — its probe, then the five per-partition words side by side:
+  //  guarded, each load is a memory round trip of its own and the item records waited for three more at the end)
   uint32_t key = 0xFFFFFFFFu, p = 0xFFFFFFFFu, len = 0;
-  if (i < a.n_pairs && a.act.on(i / a.nprobe)) {
+  const bool mine = i < a.n_pairs && a.act.on(i / a.nprobe);
+  const uint32_t ic = i < a.n_pairs ? i : a.n_pairs - 1u;
+  const uint32_t p_ld = lds_probes ? lds_probes[ic]
+                        : FRESH  ? __hip_atomic_load(a.probes + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : a.probes[ic];
+  const uint32_t pc = p_ld < a.nlist ? p_ld : 0u;
+  const uint32_t len_ld = a.plen[pc], at = a.opos[pc], it_lrow0 = a.lrow0[pc];
+  const uint64_t it_grow0 = a.grow0[pc], it_code_off = a.code_off[pc];
+  if (mine) {
     for (uint32_t sl = 0; sl < a.n_slices; ++sl) a.cand_cnt[(size_t)i * a.n_slices + sl] = 0u;
-    p = FRESH ? __hip_atomic_load(a.probes + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.probes[i];
-    len = p < a.nlist ? a.plen[p] : 0u;
+    p = p_ld;
+    len = p < a.nlist ? len_ld : 0u;
     if (len) {
-      const uint32_t at = a.opos[p];
       uint32_t x = 0;
       for (uint32_t y = 1; y < 8; ++y) x += (at >= s_xf[y]) ? 1u : 0u;  // queue of the partition (empty queues are skipped over)
       const uint32_t qlen = s_xf[x + 1] - s_xf[x], idx = at - s_xf[x];
@@ -456,39 +478,64 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
     }
   }
   if (i < PLAN_SPARSE_MAX_PAIRS) s_key[i] = key;
+  // slices of this pair: by rows when the batch asks for it (a single query's partitions differ 3 x in length: cut
+  // evenly, the longest slice decided the kernel's time; cut by rows, ~target_items items of about equal length)
+  const bool by_rows = a.target_items && a.n_slices > 1u;
+  if (by_rows || stat_rows) {  // probed rows of the batch: wave sums, one LDS atomic per wave
+    uint32_t v = key != 0xFFFFFFFFu ? len : 0u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += (uint32_t)__shfl_xor((int)v, off);
+    if (lane == 0 && v) atomicAdd(&s_q[9], v);
+    __syncthreads();
+    if (i == 0 && stat_rows && s_q[9]) atomicAdd(stat_rows, (unsigned long long)s_q[9]);
+  }
+  uint32_t n_sl = key != 0xFFFFFFFFu ? a.n_slices : 0u;
+  if (by_rows && key != 0xFFFFFFFFu) {
+    const uint32_t target = max(1u, (s_q[9] + a.target_items - 1u) / a.target_items);
+    const uint32_t unit_tiles = max(1u, ((len + SK_TILE - 1u) / SK_TILE) / SK_STREAMS);  // tile positions of a stream: a slice needs one
+    n_sl = min(min(max(1u, (len + target / 2u) / target), a.n_slices), unit_tiles);
+  }
+  if (i < PLAN_SPARSE_MAX_PAIRS) s_nsl[i] = n_sl;
   // queue x starts behind the items whose place is below its first virtual index
 #pragma unroll
   for (uint32_t x = 0; x < 9; ++x) {
-    const uint64_t m = __ballot(key != 0xFFFFFFFFu && key < ncls * s_xf[x]);
-    if (lane == 0 && m) atomicAdd(&s_q[x], (uint32_t)__popcll((unsigned long long)m));
+    const bool below = key != 0xFFFFFFFFu && key < ncls * s_xf[x];
+    if (by_rows) {
+      if (below) atomicAdd(&s_q[x], n_sl);
+    } else {  // the same number of slices for every pair: count lanes
+      const uint64_t m = __ballot(below);
+      if (lane == 0 && m) atomicAdd(&s_q[x], (uint32_t)__popcll((unsigned long long)m) * a.n_slices);
+    }
   }
   __syncthreads();
   if (key != 0xFFFFFFFFu) {
-    uint32_t rank = 0;
+    uint32_t start = 0;  // items of the pairs placed before this one
     for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {  // (s_key beyond n_pairs holds 0xFFFFFFFF: never below a real key)
       const uint4 kj = *(const uint4*)&s_key[j0];
-      const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w};
+      const uint4 nj = *(const uint4*)&s_nsl[j0];
+      const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w}, nv[4] = {nj.x, nj.y, nj.z, nj.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) rank += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? 1u : 0u;
+      for (int e = 0; e < 4; ++e) start += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? nv[e] : 0u;
     }
     SkewItem it;
     it.part = p;
     it.len = len;
-    it.lrow0 = a.lrow0[p];
-    it.grow0 = a.grow0[p];
-    it.code_off = a.code_off[p];
-    for (uint32_t sl = 0; sl < a.n_slices; ++sl) {
-      it.pair = a.n_slices > 1u ? (i | (sl << 24)) : i;
-      a.items[(size_t)rank * a.n_slices + sl] = it;
+    it.lrow0 = it_lrow0;
+    it.grow0 = it_grow0;
+    it.code_off = it_code_off;
+    for (uint32_t sl = 0; sl < n_sl; ++sl) {
+      it.pair = a.n_slices > 1u ? sk_pack_pair(i, sl, n_sl) : i;
+      a.items[(size_t)start + sl] = it;
     }
   }
-  if (i < 9) a.q_start[i] = s_q[i] * a.n_slices;
+  if (i < 9) a.q_start[i] = s_q[i];
+  if (i == 8 && a.items_made) atomicAdd(a.items_made, s_q[8]);
   if (i < 8) a.heads[i * SK_HEAD_STRIDE] = 0;
 }
 static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(PlanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
-  __shared__ uint32_t s_xf[9], s_q[9];
-  plan_sparse_body<false>(a, s_key, s_xf, s_q);
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ uint32_t s_xf[9], s_q[10];
+  plan_sparse_body<false>(a, s_key, s_xf, s_q, s_nsl);
 }
 
 // ---- latency front, second half: probe selection of every query + the work list, ONE launch ----------------------
@@ -520,13 +567,16 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   uint32_t* s_keys = (uint32_t*)sp_smem;  // [nlist]
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_and, s_or, s_prefix, s_need, s_less, s_wave_cnt[SELPLAN_NT / 64], s_running, s_best_at, s_eq_all, s_last;
-  __shared__ unsigned long long s_rows, s_best;
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
-  __shared__ uint32_t s_xf[9], s_q[9];
+  __shared__ unsigned long long s_best;
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ uint32_t s_xf[9], s_q[10];
   constexpr int NT = SELPLAN_NT, NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t b = blockIdx.x, nlist = a.nlist, nprobe = a.nprobe;
   uint32_t* out = a.probes + (size_t)b * nprobe;
+#ifdef MI355_DEV_FRONT  // dev: query 0's stage times -> DevCtl::dev[4..7] (keys / radix windows / emit + ticket / plan)
+  const unsigned long long sp_t0 = wall_clock64();
+#endif
   if (tid == 0) {
     a.qthr[b] = 0xFFFFFFFFu;
     s_and = 0xFFFFFFFFu;
@@ -534,7 +584,6 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
     s_need = nprobe;
     s_less = 0;
     s_running = 0;
-    s_rows = 0;
     s_best = ~0ull;
     s_best_at = 0;
     s_eq_all = 0;
@@ -544,14 +593,25 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
     const float* src = a.raw + (size_t)b * nlist;
     const float qq = a.metric == MI355_METRIC_DOT ? 0.f : a.qq[b];
     uint32_t k_and = 0xFFFFFFFFu, k_or = 0;
-    for (uint32_t p = tid; p < nlist; p += NT) {
-      const float acc = src[p];
-      const float v = a.metric == MI355_METRIC_DOT ? 1.0f - acc : __fmaf_rn(-2.0f, acc, qq + a.cnorm[p]);
-      if (a.coarse_out) a.coarse_out[(size_t)b * nlist + p] = v;
-      const uint32_t key = f32_sort_key(v);
-      s_keys[p] = key;
-      k_and &= key;
-      k_or |= key;
+    constexpr int KPT = (int)(SELPLAN_MAX_NLIST / SELPLAN_NT);  // scores per thread: all loaded before the first is used
+    float s_acc[KPT], s_cn[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const uint32_t pc = min((uint32_t)tid + (uint32_t)i * NT, nlist - 1u);
+      s_acc[i] = src[pc];
+      s_cn[i] = a.cnorm[pc];
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const uint32_t p = (uint32_t)tid + (uint32_t)i * NT;
+      if (p < nlist) {
+        const float v = a.metric == MI355_METRIC_DOT ? 1.0f - s_acc[i] : __fmaf_rn(-2.0f, s_acc[i], qq + s_cn[i]);
+        if (a.coarse_out) a.coarse_out[(size_t)b * nlist + p] = v;
+        const uint32_t key = f32_sort_key(v);
+        s_keys[p] = key;
+        k_and &= key;
+        k_or |= key;
+      }
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -564,6 +624,9 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
     }
   }
   __syncthreads();
+#ifdef MI355_DEV_FRONT
+  const unsigned long long sp_t1 = wall_clock64();
+#endif
   const uint32_t diff = s_and ^ s_or;
   // bits above `top` are the same in every key: they are the threshold's too
   uint32_t top = diff ? 32u - (uint32_t)__clz(diff) : 0u;
@@ -609,16 +672,21 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
     top = shift;
     __syncthreads();  // (s_need / s_prefix are rewritten by the next window)
   }
+#ifdef MI355_DEV_FRONT
+  const unsigned long long sp_t2 = wall_clock64();
+#endif
   const uint32_t T = prefix;
   const uint32_t need_eq = need;             // rows with key == T to take (>= 1)
   const uint32_t n_less = nprobe - need_eq;  // rows with key < T
-  unsigned long long rows = 0;
+  // The list is assembled in LDS: the nearest partition moves to rank 0 there, the list goes to global memory once,
+  // and a single query's planner reads it where it is — every global round trip this kernel waits for costs ~1.5 us
+  // (the first version read its own list back from L2 twice and waited behind three fences: 22 of its 30 us).
+  uint32_t* s_out = s_keys + nlist;  // [nprobe]
   if (eq_all) {  // no tie is cut at the threshold: every key <= T, any order
     for (uint32_t p = tid; p < nlist; p += NT) {
       const uint32_t key = s_keys[p];
       if (key <= T) {
-        out[atomicAdd(&s_less, 1u)] = p;
-        rows += a.plen[p];
+        s_out[atomicAdd(&s_less, 1u)] = p;
         atomicMin(&s_best, ((unsigned long long)key << 32) | p);
       }
     }
@@ -629,8 +697,7 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
       const bool less = p < nlist && key < T;
       const bool eq = p < nlist && key == T;
       if (less) {
-        out[atomicAdd(&s_less, 1u)] = p;
-        rows += a.plen[p];
+        s_out[atomicAdd(&s_less, 1u)] = p;
         atomicMin(&s_best, ((unsigned long long)key << 32) | p);
       }
       // ordered rank among the equal keys (ascending partition id)
@@ -645,8 +712,7 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
       }
       const uint32_t rank = base + (uint32_t)__popcll((unsigned long long)(bal & ((1ull << lane) - 1ull)));
       if (eq && rank < need_eq) {
-        out[n_less + rank] = p;
-        rows += a.plen[p];
+        s_out[n_less + rank] = p;
         atomicMin(&s_best, ((unsigned long long)key << 32) | p);
       }
       __syncthreads();
@@ -654,41 +720,50 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
       __syncthreads();
     }
   }
-  if (rows) atomicAdd(&s_rows, rows);
-  __threadfence();  // this query's probe list is at L2 before the ticket is taken
   __syncthreads();
-  if (tid == 0 && a.stat_rows) atomicAdd(a.stat_rows, s_rows);
   if (nprobe > 1) {  // the nearest partition (ties: lowest id) moves to rank 0
     const uint32_t best = (uint32_t)s_best;
     for (uint32_t i = tid; i < nprobe; i += NT)
-      if (__hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == best) s_best_at = i;
+      if (s_out[i] == best) s_best_at = i;
     __syncthreads();
     if (tid == 0 && s_best_at != 0) {
-      const uint32_t first = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out[s_best_at] = first;
-      out[0] = best;
-      __threadfence();
+      s_out[s_best_at] = s_out[0];
+      s_out[0] = best;
     }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    const uint32_t t = atomicAdd(a.ticket, 1u);
-    s_last = (t == gridDim.x - 1u) ? 1u : 0u;
-    if (s_last) {
-      atomicExch(a.ticket, 0u);  // ready for the next launch
-      __threadfence();
+  for (uint32_t i = tid; i < nprobe; i += NT) out[i] = s_out[i];
+  const bool alone = gridDim.x == 1u;  // a single query: this workgroup plans from its own LDS copy, no ticket, no fence
+  if (!alone) {
+    __threadfence();  // this query's probe list is at L2 before the ticket is taken
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t t = atomicAdd(a.ticket, 1u);
+      s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+      if (s_last) atomicExch(a.ticket, 0u);  // ready for the next launch
     }
+    __syncthreads();
   }
+#ifdef MI355_DEV_FRONT
+  const unsigned long long sp_t3 = wall_clock64();
+#endif
+  if (!alone && !s_last) return;
+  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q, s_nsl, alone ? s_out : (const uint32_t*)nullptr, a.stat_rows);
+#ifdef MI355_DEV_FRONT
   __syncthreads();
-  if (!s_last) return;
-  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q);
+  if (tid == 0 && a.stat_rows) {  // (stat_rows = &DevCtl::rows_scanned, the first member: the counters follow it)
+    uint32_t* dev = (uint32_t*)a.stat_rows + 8;  // rows_scanned(2), short_queries, lat_items, deadline(2), timed_out, bad_probes, dev[0]
+    atomicAdd(dev + 4, (uint32_t)(sp_t1 - sp_t0));
+    atomicAdd(dev + 5, (uint32_t)(sp_t2 - sp_t1));
+    atomicAdd(dev + 6, (uint32_t)(sp_t3 - sp_t2));
+    atomicAdd(dev + 7, (uint32_t)(wall_clock64() - sp_t3));
+  }
+#endif
 }
 
 // ------------------------------------------------------------------- scan ----
 // Where entry (code c, column j) of a distance table of M columns lives, in dwords from the table base: `at` always,
-// `dup` (SK_NONE: none) for the columns stored twice.  ONE definition for the table a work item builds in LDS and the
-// image k_lut_build writes to global memory for the sliced items of a small batch.
+// `dup` (SK_NONE: none) for the columns stored twice.
 __device__ __forceinline__ void sk_lut_slots(uint32_t c, uint32_t j, uint32_t M, uint32_t& at, uint32_t& dup) {
 #ifdef SK_DUAL
   // two slabs of 256-B rows; byte address slab*65536 + c*256 + 4u (u >= 64 spills one row on)
@@ -727,153 +802,12 @@ struct SkewArgs {
   uint32_t res_floats;      // LDS floats of the residual: dim, or one slab's M * dsub (SLABBED)
   float2* partial;          // [grid][partial_stride]: per-workgroup partial row sums between slabs (n_slabs > 1)
   uint32_t partial_stride;  // float2 elements per workgroup: (tile positions of the longest unit) * 16 units * 64 lanes
-  // Sliced pairs (n_slices > 1, one slab): the pairs' distance tables as LDS images [pair][sk_table_bytes(M) / 4], built
-  // ONCE per pair by k_lut_build — a work item copies its pair's image (L2 -> LDS) instead of running the 0.59 MFLOP /
-  // 786 KB-of-codebook build again in every slice.  NULL: every item builds its own table.
-  const float* lut_pre;
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
   uint32_t v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 7u;
-}
-
-// The distance tables of a small batch's pairs, once per pair (SkewArgs::lut_pre).  grid = (G, pairs): workgroup g of a
-// pair computes entries e = c * M + j in [g, g+1) * 256 * M / G — whole codes when G divides 256 — from the pair's
-// residual; the arithmetic is build_lut's (same residual subtraction, same element-order fmaf chain, same `1 - acc`
-// for dot, same zero padding columns), so the image equals the table a work item would have built, bit for bit.
-struct LutBuildArgs {
-  IndexView ix;
-  const float* cbT;         // [256][m][dsub]
-  const float* qp;          // [nq, dim]
-  const uint32_t* probes;   // [n_pairs]
-  uint32_t nprobe;
-  uint32_t M;               // columns of the table (SkewShape::M, one slab)
-  uint32_t table_dwords;    // sk_table_bytes(M) / 4: pitch of the images
-  float* out;               // [n_pairs][table_dwords]
-  ActiveMask act;
-};
-// DS: sub-vector length the codebook loads are unrolled for (4 / 8 / 16: the reference's dim / m), 0 = any.
-template <int DS>
-static __global__ __launch_bounds__(256) void k_lut_build(LutBuildArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
-  float* res = (float*)lb_smem;  // [M * dsub]
-  const IndexView& ix = a.ix;
-  const uint32_t pair = blockIdx.y, tid = threadIdx.x;
-  const uint32_t b = pair / a.nprobe;
-  if (!a.act.on(b)) return;
-  const uint32_t dsub = DS ? (uint32_t)DS : ix.dsub, M = a.M;
-  const bool dotm = ix.metric == MI355_METRIC_DOT;
-  const uint32_t n_codes = ix.nbits == 4 ? 16u : 256u;
-  const uint32_t total = n_codes * M;
-  const uint32_t e_lo = (uint32_t)((uint64_t)total * blockIdx.x / gridDim.x), e_hi = (uint32_t)((uint64_t)total * (blockIdx.x + 1u) / gridDim.x);
-  float* img = a.out + (size_t)pair * a.table_dwords;
-  auto put = [&](uint32_t e, float acc, bool valid) {
-    if (valid && dotm) acc = 1.0f - acc;
-    uint32_t at, dup;
-    sk_lut_slots(e / M, e % M, M, at, dup);
-    img[at] = acc;
-    if (dup != SK_NONE) img[dup] = acc;
-  };
-  // the residual: q - centroid of the pair's partition (a partition id outside the index makes no work item: nothing
-  // reads this pair's image).  The kernel is a chain of memory round trips — probe id -> centroid row -> LDS -> table —
-  // so the codebook loads, which depend on none of them, are issued FIRST (fast path) and wait behind them.
-  auto residual = [&]() -> bool {
-    const uint32_t p = a.probes[pair];
-    if (p >= ix.nlist) return false;
-    const float* q = a.qp + (size_t)b * ix.dim;
-    const float* cen = ix.centroids + (size_t)p * ix.dim;
-    for (uint32_t d = tid; d < M * dsub; d += 256u) {
-      float v = 0.f;
-      if (d < ix.dim) {
-        const float qv = q[d], cv = dotm ? 0.f : cen[d];
-        v = qv - cv;  // dot: q - 0 == q exactly (as in the scan's residual)
-      }
-      res[d] = v;
-    }
-    return true;
-  };
-  if constexpr (DS != 0) {
-    constexpr int V = DS / 4;        // 16-B pieces per codebook entry
-    constexpr int EPR = 16 / V;      // entries per thread per round: 16 pieces in flight
-    bool have_res = false, ok_res = false;
-    for (uint32_t r0 = e_lo; r0 < e_hi; r0 += EPR * 256u) {  // (workgroup-uniform trip count: the barrier below is inside)
-      const uint32_t e0 = r0 + tid;
-      float4 cv4[EPR][V];
-      bool ok[EPR];
-#pragma unroll
-      for (int u = 0; u < EPR; ++u) {
-        const uint32_t e = e0 + u * 256u;
-        ok[u] = false;
-        if (e < e_hi) {
-          const uint32_t c = e / M, j = e % M;
-          ok[u] = j < ix.m;
-          if (ok[u]) {
-            const float* cb = a.cbT + ((size_t)c * ix.m + j) * DS;
-#pragma unroll
-            for (int v = 0; v < V; ++v) cv4[u][v] = *(const float4*)(cb + 4 * v);
-          }
-        }
-      }
-      if (!have_res) {  // first round only
-        ok_res = residual();
-        have_res = true;
-        __syncthreads();
-        if (!ok_res) return;
-      }
-#pragma unroll
-      for (int u = 0; u < EPR; ++u) {
-        const uint32_t e = e0 + u * 256u;
-        if (e < e_hi) {
-          float acc = 0.f;
-          if (ok[u]) {
-            const float* rj = res + (e % M) * DS;
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-              const float4 r = *(const float4*)(rj + 4 * v);
-              const float4 c = cv4[u][v];
-              if (dotm) {
-                acc = __fmaf_rn(r.x, c.x, acc);
-                acc = __fmaf_rn(r.y, c.y, acc);
-                acc = __fmaf_rn(r.z, c.z, acc);
-                acc = __fmaf_rn(r.w, c.w, acc);
-              } else {
-                const float d0 = r.x - c.x, d1 = r.y - c.y, d2 = r.z - c.z, d3 = r.w - c.w;
-                acc = __fmaf_rn(d0, d0, acc);
-                acc = __fmaf_rn(d1, d1, acc);
-                acc = __fmaf_rn(d2, d2, acc);
-                acc = __fmaf_rn(d3, d3, acc);
-              }
-            }
-          }
-          put(e, acc, ok[u]);
-        }
-      }
-    }
-  } else {
-    const bool ok_res = residual();
-    __syncthreads();
-    if (!ok_res) return;
-    for (uint32_t e = e_lo + tid; e < e_hi; e += 256u) {
-      const uint32_t c = e / M, j = e % M;
-      const bool valid = j < ix.m;
-      float acc = 0.f;
-      if (valid) {
-        const float* cb = a.cbT + ((size_t)c * ix.m + j) * dsub;
-        const float* rj = res + j * dsub;
-        for (uint32_t t = 0; t < dsub; ++t) {
-          if (dotm) {
-            acc = __fmaf_rn(rj[t], cb[t], acc);
-          } else {
-            const float df = rj[t] - cb[t];
-            acc = __fmaf_rn(df, df, acc);
-          }
-        }
-      }
-      put(e, acc, valid);
-    }
-  }
 }
 
 // plain chunks g = G .. CPT-1 of a tile (steps >= 32)
@@ -992,7 +926,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   // every thread's share of the first residual
   float pre_q[4], pre_c[4];  // up to 4 elements per thread (dim <= 4 * NT, checked at open)
   auto prefetch_res = [&](const SkewItem& it) {
-    const uint32_t pr = a.n_slices > 1u ? (it.pair & 0xFFFFFFu) : it.pair;  // (sliced pairs carry the slice on top)
+    const uint32_t pr = a.n_slices > 1u ? (it.pair & 0xFFFFFu) : it.pair;  // (sliced pairs carry the slice on top: sk_pack_pair)
     const float* q = a.qp + (size_t)(pr / a.nprobe) * ix.dim;
     const float* c = ix.centroids + (size_t)it.part * ix.dim;
 #pragma unroll
@@ -1015,8 +949,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     auto uni64 = [&](uint64_t v) -> uint64_t { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | (uint64_t)uni32((uint32_t)v); };
     const uint32_t pair_f = uni32(rec->pair);
     if (pair_f == SK_NONE) break;
-    const uint32_t pair = a.n_slices > 1u ? (pair_f & 0xFFFFFFu) : pair_f;
-    const uint32_t slice = a.n_slices > 1u ? (pair_f >> 24) : 0u;
+    const uint32_t pair = a.n_slices > 1u ? (pair_f & 0xFFFFFu) : pair_f;
+    const uint32_t slice = a.n_slices > 1u ? ((pair_f >> 20) & 63u) : 0u;
+    const uint32_t n_sl = a.n_slices > 1u ? (pair_f >> 26) + 1u : 1u;  // slices THIS pair was cut into (<= a.n_slices, the slot stride)
     const uint32_t oslot = pair * a.n_slices + slice;  // candidate slots / count of this work item
     const uint32_t len = uni32(rec->len);
     const uint32_t lrow0 = uni32(rec->lrow0);
@@ -1083,22 +1018,19 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         constexpr int EPR = (SK_LUT_INFLIGHT / V) > 0 ? (SK_LUT_INFLIGHT / V) : 1;  // entries per thread per round
         constexpr uint32_t TOTAL = KSUB * (uint32_t)M;
         for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
-          float4 cv4[EPR][V];
+          // (ext-vector registers and unconditional loads at a clamped entry: an array of more than eight HIP float4
+          //  structs stays in scratch and a load guarded per element is waited for on its own — scripts/check_scratch.py)
+          sk_f32x4 cv4[EPR][V];
           bool ok[EPR];
 #pragma unroll
           for (int u = 0; u < EPR; ++u) {
             const uint32_t e = e0 + u * NT;
-            ok[u] = false;
-            if (e < TOTAL) {
-              const size_t at = cb_of(e, ok[u]);
-              if (ok[u]) {
+            bool valid;
+            const size_t at = cb_of(e < TOTAL ? e : TOTAL - 1u, valid);
+            ok[u] = valid && e < TOTAL;
+            const float* src = a.cbT + (SLABBED && !valid ? (size_t)0 : at) * DS;
 #pragma unroll
-                for (int v = 0; v < V; ++v) cv4[u][v] = *(const float4*)(a.cbT + at * DS + 4 * v);
-              } else {
-#pragma unroll
-                for (int v = 0; v < V; ++v) cv4[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-              }
-            }
+            for (int v = 0; v < V; ++v) cv4[u][v] = *(const sk_f32x4*)(src + 4 * v);
           }
 #pragma unroll
           for (int u = 0; u < EPR; ++u) {
@@ -1110,7 +1042,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                   const float4 r = *(const float4*)(rj + 4 * v);
-                  const float4 c = cv4[u][v];
+                  const sk_f32x4 c = cv4[u][v];
                   if (dotm) {
                     acc = __fmaf_rn(r.x, c.x, acc);
                     acc = __fmaf_rn(r.y, c.y, acc);
@@ -1167,13 +1099,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         }
       }
     };
-    if (a.lut_pre) {
-      // the pair's table was built once for all of its slices (k_lut_build): copy the image, 16 B per thread per step
-      const float4* img = (const float4*)(a.lut_pre + (size_t)pair * (TABLE_BYTES / 4u));
-      for (uint32_t i = tid; i < TABLE_BYTES / 16u; i += NT) ((float4*)lut)[i] = img[i];
-    } else if (!(a.dbg & 1u)) {
-      build_lut(0);
-    }
+    if (!(a.dbg & 1u)) build_lut(0);
     // the next item's record: one dependent load, lands during the scan
     SkewItem nxt;
     nxt.pair = SK_NONE;
@@ -1349,7 +1275,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       // starts inside the stream meets the tails of tile n0 - 1 in its first steps (they only feed Y, which the
       // n > n0 test below never consumes) and ends like the stream does: the first two chunks of position n1
       // hold the tails of tile n1 - 1 (their tile-n1 bytes go to a dummy accumulator)
-      const uint32_t n0 = (uint32_t)((uint64_t)nt * slice / a.n_slices), n1 = (uint32_t)((uint64_t)nt * (slice + 1u) / a.n_slices);
+      const uint32_t n0 = (uint32_t)((uint64_t)nt * slice / n_sl), n1 = (uint32_t)((uint64_t)nt * (slice + 1u) / n_sl);
       if (n0 == n1) continue;
       // partial row sums of the slabs before this one: [tile position][unit][lane] float2 (chains A, B), parked by this
       // very lane in the previous slab.  The load of position n + 1 is issued at the top of position n — before that
@@ -1365,8 +1291,15 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       auto park = [&](const sk_f32x2& v, uint32_t tp) {  // (not the last slab) this lane's two rows of position tp
         ppart[(size_t)tp * (SK_UNITS * MI355_WAVE)] = make_float2(v.x, v.y);
       };
+#ifdef MI355_DEV_SCANSPLIT  // dev: where wave 0's scan phase goes — first chunk's latency / the positions / the tail (dev[4], [6], [7])
+      const unsigned long long ss_t0 = wall_clock64();
+#endif
 #pragma unroll
       for (int g = 0; g < RING; ++g) fetch(g, n0 * CPT + g);
+#ifdef MI355_DEV_SCANSPLIT
+      sk_wait_codes<2 * (RING - 1)>(ra[0], rb[0]);
+      const unsigned long long ss_t1 = wall_clock64();
+#endif
       sk_f32x2 x = {0.f, 0.f}, y = {0.f, 0.f};
       uint32_t r = lb, r2 = lb;  // [bit 16: slab][byte 1: code][byte 0: column origin]; r2: chain B's copy (nreg=2)
       const uint32_t sa = u * SK_CHAINS, sb = sa + 1;
@@ -1417,6 +1350,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         r &= 0xffffu;  // every lane is back in slab 0 at step 0
         r2 &= 0xffffu;
       }
+#ifdef MI355_DEV_SCANSPLIT
+      const unsigned long long ss_t2 = wall_clock64();
+#endif
       {  // 31 more steps finish the last tile's rows (CPT % RING == 0: the tail sits in slots 0, 1)
         sk_f32x2 dummy = {0.f, 0.f};
         sk_wait_codes<0>(ra[0], rb[0]);  // also drains the clamped prefetches: the ring registers die here
@@ -1430,6 +1366,14 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
           park(y, n1 - 1);
         }
       }
+#ifdef MI355_DEV_SCANSPLIT
+      if (tid == 0) {
+        const unsigned long long ss_t3 = wall_clock64();
+        atomicAdd(&a.ctl->dev[4], (uint32_t)(ss_t1 - ss_t0));
+        atomicAdd(&a.ctl->dev[6], (uint32_t)(ss_t2 - ss_t1));
+        atomicAdd(&a.ctl->dev[7], (uint32_t)(ss_t3 - ss_t2));
+      }
+#endif
     }
     }  // slabs
 #else
@@ -1599,7 +1543,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     for (int w2 = 0; w2 < NW; ++w2) pre[w2 + 1] = pre[w2] + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cnt[w2]);
     const uint32_t total = pre[NW];
     const uint32_t n_out = min(total, kk_pass);
+#ifndef MI355_DEV_SCANSPLIT
     SK_DEV(if (tid == 0) atomicAdd(&a.ctl->dev[4], total);)
+#endif
     auto locate = [&](uint32_t c, uint32_t& w2, uint32_t& j2) {  // flat position -> (list, entry)
       w2 = 0;
 #pragma unroll
@@ -1669,7 +1615,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     }
     SK_DEV(const unsigned long long dv_m1 = wall_clock64();)
     if (parked) flush();
+#ifndef MI355_DEV_SCANSPLIT
     SK_DEV(if (tid == 0) { atomicAdd(&a.ctl->dev[6], (uint32_t)(dv_m0 - dv_p1)); atomicAdd(&a.ctl->dev[7], (uint32_t)(dv_m1 - dv_m0)); })
+#endif
     const bool more = MULTI && total >= kk_pass && pass_base + kk_pass < a.kk;
     SK_DEV(__syncthreads(); dv_merge += wall_clock64() - dv_p1;)
     if (!more) {

@@ -59,4 +59,8 @@ for k in (10, 100, 250, 500):
                  f"items {c[3] // reps}, in lists at merge/item {c[4] / items:.0f}, "
                  f"{'redone passes ' + str(c[5] // reps) if k > 128 else 'shader clock over the items ' + format(c[5] / max(c[0] + c[1] + c[2], 1) * 100, '.0f') + ' MHz'}, "
                  f"merge split: barrier->ranking {c[6] * tick_us / items:.1f} us, ranking {c[7] * tick_us / items:.1f} us (thread 0)")
+        import os
+        if os.environ.get("SCANSPLIT"):
+            line += (f" || SCANSPLIT build, wave 0 per item: first chunk {c[4] * tick_us / items:.2f} us, positions {c[6] * tick_us / items:.2f} us, "
+                     f"tail {c[7] * tick_us / items:.2f} us (the three numbers after 'in lists' / 'merge split' are these)")
     print(line, flush=True)

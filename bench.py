@@ -29,8 +29,8 @@ index is the same for every N.  The index size is fixed: scaling is "strong".
 One JSON line on rank 0, with `roofline` (dominant kernel = the ADC scan, HIP
 events recorded on the search stream inside the timed region) and, at N = 1,
 `cpu_baseline` (the C oracle on a bounded sample of the same queries, also used
-as a full-size parity check), `recall_at_10` (a trained 2 M-row index, engine and
-oracle), and `secondary`: single-query latency and 64-thread throughput of host callers,
+as a full-size parity check), `recall_at_10` (a trained 10 M-row index with its bf16 raw column in HBM: QPS AND recall@10 of
+every operating point on that one index, engine and oracle; `qps_vs_recall_at_10` lists them), and `secondary`: single-query latency and 64-thread throughput of host callers,
 the same 100 M index with refine_factor 10 / 25 over resident bf16 raw vectors, and flat C2
 (BASELINE.json configs[1]: 10 M x 768 bf16, 1024 queries, L2 and cosine) with the
 GEMM kernel's own roofline and a full-size parity check each.
@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--skew", type=float, default=0.5, help="sigma of the log-normal partition-length skew")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline (0 = skip)")
-    ap.add_argument("--recall-rows", type=int, default=2_000_000,
+    ap.add_argument("--recall-rows", type=int, default=10_000_000,
                     help="rows of the TRAINED index recall@10 is measured on (0 = skip); the 100 M throughput "
                          "index has random codes, so recall is only meaningful on a trained one")
     ap.add_argument("--recall-queries", type=int, default=10_000)
@@ -387,12 +387,10 @@ def main():
         result["secondary"]["c1_flat"] = legs.c1_flat(a, np)
         for metric in ("l2", "cosine"):
             result["secondary"]["flat_c2_" + metric] = flat_c2(a, metric, cpu_queries=32 if metric == "l2" else 16)
-    if rank == 0 and "secondary" in result and "recall_at_10" in result:
-        rec, sec = result["recall_at_10"], result["secondary"]
-        result["qps_vs_recall_at_10"] = [
-            {"refine_factor": 0, "queries_per_s": result["value"], "recall_at_10_mixture_2M": rec.get("nprobe64")},
-            {"refine_factor": 10, "queries_per_s": sec.get("c3_refine10", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine10")},
-            {"refine_factor": 25, "queries_per_s": sec.get("c3_refine25", {}).get("value"), "recall_at_10_mixture_2M": rec.get("nprobe64_refine25")}]
+    if rank == 0 and "recall_at_10" in result:
+        # every row names ONE index: QPS and recall@10 measured on the same trained index (recall_at_10.points); the headline
+        # line above stays the 100 M synthetic index (uniform random codes: its recall is meaningless)
+        result["qps_vs_recall_at_10"] = result["recall_at_10"].get("points", [])
     if rank == 0:
         result["summary"] = legs.summary_of(result)
         legs.emit(result)  # full document -> bench_detail.json; stdout gets ONE line of < 4 KB (contract keys + roofline + cpu_baseline + summary)
@@ -866,12 +864,17 @@ def flat_c2(a, metric, cpu_queries):
     return res
 
 
+def recall_nlist(a):
+    """IVF partitions of the trained index: the C3 value (4096) from 8 M rows on, 1024 below (toy runs)."""
+    return 4096 if a.recall_rows >= 8_000_000 else 1024
+
+
 def recall_index(a, dim, m):
     """The trained index of the recall leg (also used by tests/tools/parity_exposure.py): a Gaussian-mixture column,
     IVF + residual PQ trained and the rows encoded by the engine's build entry points; everything stays on the device."""
     import torch
     import lancedb_amd
-    n, nlist, nq, dsub = a.recall_rows, 1024, a.recall_queries, dim // m
+    n, nlist, nq, dsub = a.recall_rows, recall_nlist(a), a.recall_queries, dim // m
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(SEED)
@@ -904,7 +907,10 @@ def recall_index(a, dim, m):
     part_offsets, codes, order = lancedb_amd.ivfpq_encode(x, cen, codebook)
     torch.cuda.synchronize()
     t_enc = time.perf_counter() - t_enc
-    xs = x[order].contiguous()
+    # the raw column the re-rank reads: bf16 in index order, resident in HBM (what a 100 M x 768 column has to be: 154 GB)
+    xs = torch.empty((n, dim), dtype=torch.bfloat16, device=dev)
+    for r0 in range(0, n, 1_000_000):
+        xs[r0:r0 + 1_000_000] = x[order[r0:r0 + 1_000_000].to(torch.int64)].to(torch.bfloat16)
     torch.cuda.synchronize()
     return {"x": x, "q": q, "cen": cen, "codebook": codebook, "part_offsets": part_offsets, "codes": codes, "order": order,
             "xs": xs, "n_comp": n_comp, "t_train": t_train, "t_enc": t_enc}
@@ -924,43 +930,72 @@ def recall_at_10(a, np, dim, m):
     import lancedb_amd
     from lancedb_amd import _abi
     t0 = time.perf_counter()
-    n, nlist, nq = a.recall_rows, 1024, a.recall_queries
+    n, nlist, nq = a.recall_rows, recall_nlist(a), a.recall_queries
     R = recall_index(a, dim, m)
     x, q, cen, codebook, part_offsets, codes, order, xs = (R[k2] for k2 in ("x", "q", "cen", "codebook", "part_offsets", "codes", "order", "xs"))
     iters, n_comp, t_train, t_enc = a.recall_iters, R["n_comp"], R["t_train"], R["t_enc"]
-    ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes, order, raw_vectors=xs)
+    dev = x.device
+    ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes, order,
+                                raw_vectors=xs.view(torch.int16), raw_dtype=_abi.DTYPE_BF16)
     fl = lancedb_amd.FlatIndex(x.contiguous())
     torch.cuda.synchronize()
     hq = q.cpu().numpy()
     truth = fl.search(hq, k=10).rowids
     del fl
-    out = {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "queries": nq, "truth": "exact flat search (engine flat path)",
+    torch.cuda.empty_cache()
+    out = {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "queries": nq, "truth": "exact flat search over the f32 column (engine flat path)",
+           "raw_column": "bf16, index order, in HBM (the refine points re-rank on it)",
            "data": f"{n_comp}-component Gaussian mixture; IVF (sample_rate 256) + residual PQ trained by {iters} Lloyd "
                    "iterations on the GPU (mi355_kmeans_train / mi355_pq_train), rows encoded by mi355_ivfpq_encode",
            "train_seconds": round(t_train, 2), "encode_rows_per_s": round(n / t_enc)}
 
-    def rec(ids):
-        return round(float(np.mean([len(set(truth[i].tolist()) & set(ids[i].tolist())) / 10.0 for i in range(nq)])), 4)
+    def rec(ids, upto):
+        return round(float(np.mean([len(set(truth[i].tolist()) & set(ids[i].tolist())) / 10.0 for i in range(upto)])), 4)
 
     ox = None
     if a.cpu_seconds > 0:
         from oracle import oracle as orc
         orc.build()
         ox = orc.OracleIndex(cen.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
-                             order.cpu().numpy().astype(np.uint64), raw_vectors=xs.cpu().numpy())
+                             order.cpu().numpy().astype(np.uint64), raw_vectors=xs.view(torch.int16).cpu().numpy().view(np.uint16),
+                             raw_dtype=_abi.DTYPE_BF16)
     # the oracle answers the first `n_or` queries of every operating point (row for row against the engine; its recall is
     # over those queries) — all 10 k on the host were 110 s of a 190 s bench run
     n_or = min(nq, 2048)
     out["cpu_oracle_queries"] = n_or
+    # QPS of every operating point ON THIS INDEX: device-resident batches of the held-out queries, results in HBM
+    B = min(a.batch, nq)
+    qb = [q[i:i + B].contiguous() for i in range(0, nq - B + 1, B)][:4]
+    dout = (torch.empty((B, 10), dtype=torch.int64, device=dev), torch.empty((B, 10), dtype=torch.float32, device=dev),
+            torch.empty((B,), dtype=torch.int32, device=dev))
+    ix.set_stream(torch.cuda.current_stream().cuda_stream)
+    points = []
     for nprobe, rf in ((64, 0), (64, 10), (64, 25), (64, 50), (16, 0)):
         key = f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")
         got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf).rowids
-        out[key] = rec(got)
+        out[key] = rec(got, nq)
+        params = _abi.make_params(k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+        for i in range(2):
+            ix.search(qb[i % len(qb)], params, out=dout)
+        torch.cuda.synchronize()
+        steps = max(4, a.steps // 2)
+        t1 = time.perf_counter()
+        for i in range(steps):
+            ix.search(qb[i % len(qb)], params, out=dout)
+        torch.cuda.synchronize()
+        qps = B * steps / (time.perf_counter() - t1)
+        out[key + "_queries_per_s"] = round(qps, 1)
+        pt = {"index": f"trained {n}x{dim} nlist{nlist} m{m} (this leg)", "nprobe": nprobe, "refine_factor": rf, "batch_queries": B,
+              "queries_per_s": round(qps, 1), "recall_at_10": out[key]}
         if ox is not None:
             o_ids, _, _, _ = ox.search(hq[:n_or], k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
-            out[key + "_cpu_oracle"] = round(float(np.mean([len(set(truth[i].tolist()) & set(o_ids[i].tolist())) / 10.0 for i in range(n_or)])), 4)
-            out[key + "_engine_same_queries"] = round(float(np.mean([len(set(truth[i].tolist()) & set(got[i].tolist())) / 10.0 for i in range(n_or)])), 4)
+            out[key + "_cpu_oracle"] = rec(o_ids, n_or)
+            out[key + "_engine_same_queries"] = rec(got, n_or)
             out[key + "_rowids_bit_exact"] = bool((o_ids == got[:n_or]).all())
+            pt.update({"recall_at_10_cpu_oracle": out[key + "_cpu_oracle"], "recall_at_10_engine_same_queries": out[key + "_engine_same_queries"],
+                       "rowids_bit_exact_vs_oracle": out[key + "_rowids_bit_exact"]})
+        points.append(pt)
+    out["points"] = points
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 

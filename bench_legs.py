@@ -620,7 +620,10 @@ def summary_of(result):
          "flat_cos_qps": v(sec, "flat_c2_cosine", "value"), "flat_cos_gemm_frac": v(sec, "flat_c2_cosine", "roofline", "frac"),
          "lat_p50_us": v(sec, "latency_c3", "single_query_us_eager", "p50"), "lat_p99_us": v(sec, "latency_c3", "single_query_us_eager", "p99"),
          "c1_engine_us": v(sec, "c1_flat", "engine_single_query_us", "p50"), "c1_cpu_us": v(sec, "c1_flat", "cpu_baseline", "us_per_query"),
-         "recall10": v(result, "recall_at_10", "nprobe64"), "recall10_rf25": v(result, "recall_at_10", "nprobe64_refine25")}
+         "recall10": v(result, "recall_at_10", "nprobe64"), "recall10_rf25": v(result, "recall_at_10", "nprobe64_refine25"),
+         "trained_index_rows": v(result, "recall_at_10", "n_rows"),
+         "trained_qps_rf0": v(result, "recall_at_10", "nprobe64_queries_per_s"), "trained_qps_rf10": v(result, "recall_at_10", "nprobe64_refine10_queries_per_s"),
+         "trained_qps_rf25": v(result, "recall_at_10", "nprobe64_refine25_queries_per_s"), "recall10_rf10": v(result, "recall_at_10", "nprobe64_refine10")}
     cc = sec.get("concurrent_callers_c3", {})
     s["callers_qps"] = {k2.replace("_threads", ""): round(v2["queries_per_s"]) for k2, v2 in cc.items()}
     for key, line in sec.items():

@@ -154,7 +154,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
                     &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt,
-                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b};
+                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b,  &ix->w_rqq};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -193,7 +193,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   const uint32_t nlist = d->nlist, m = d->m, mb = ix->mb, cb_entries = 1u << d->nbits;
   for (DevBuf* b : {&ix->w_q, &ix->w_qp, &ix->w_qq, &ix->w_coarse, &ix->w_probes, &ix->w_cand, &ix->w_ids, &ix->w_dist,
                     &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr, &ix->w_ccnt,
-                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial, &ix->w_cand2b, &ix->w_cnt2b})
+                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial, &ix->w_cand2b, &ix->w_cnt2b, &ix->w_rqq})
     b->gen = &ix->ws_gen;  // a re-allocation of any of these invalidates the cached hipGraphs
 
   // -- ownership + local layout
@@ -215,7 +215,12 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     ix->layout = MI355_SCAN_PAIR;
     if (!force_pair && sk_shape(m, &shp)) {  // (4-bit codes are expanded to one byte per column at pack time)
       const uint32_t res_floats = shp.n_slabs > 1 ? shp.M * ix->dsub : d->dim;
-      if (res_floats <= 2048 && sk_scan_lds(shp.M, res_floats, 8, 5) <= 160u * 1024) {
+      // what the packed streams cost against the source rows: padding to a 32-column tile, nibbles expanded to bytes
+      // (m = 8 at 4 bits streams 8 x its code bytes, m = 1 thirty-two times) — past 8 x the generic layout is the
+      // better index: it fits where this one may not and scans fewer bytes (8 x keeps every width from m = 4 up,
+      // i.e. everything the reference's dim / 16 and dim / 8 rules produce, on the production scan)
+      const uint64_t packed_row = (uint64_t)shp.M * shp.n_slabs, source_row = std::max<uint64_t>(1, ((uint64_t)m * d->nbits + 7) / 8);
+      if (res_floats <= 2048 && sk_scan_lds(shp.M, res_floats, 8, 5) <= 160u * 1024 && packed_row <= 8 * source_row) {
         ix->layout = MI355_SCAN_SKEW;
         ix->sk_M = shp.M;
         ix->sk_slabs = shp.n_slabs;
@@ -489,16 +494,30 @@ extern "C" int32_t mi355_index_close(mi355_index* index) try { return index_free
 extern "C" int32_t mi355_index_set_stream(mi355_index* ix, void* hip_stream) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   std::lock_guard<std::mutex> lk(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  // a deferred re-rank / overlapped exchange may still run on another stream: BOTH the old and the new search stream
+  // wait for it (the next call on the new stream may reuse its buffers, and the caller's outputs must stay ordered
+  // before later work on the stream the handle moves to — ADVICE round 4)
+  const bool pending = ix->xpending;
+  hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
+  if (pending && next != ix->stream) HIP_TRY(hipStreamWaitEvent(next, ix->xdone, 0));
   ST_TRY(join_exchange(ix));
-  ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
+  ix->stream = next;
   return MI355_OK;
 } MI355_ABI_GUARD("mi355_index_set_stream")
 
 extern "C" int32_t mi355_index_sync(mi355_index* ix) try {
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   HIP_TRY(hipSetDevice(ix->device));
-  HIP_TRY(hipStreamSynchronize(ix->stream));
-  if (ix->xdone) HIP_TRY(hipEventSynchronize(ix->xdone));  // an overlapped sharded search finishes on the communicator's stream
+  hipStream_t st;
+  hipEvent_t xdone;
+  {  // (the handle's stream and event are read under its lock: set_stream / a concurrent search may change them)
+    std::lock_guard<std::mutex> lk(ix->mu);
+    st = ix->stream;
+    xdone = ix->xdone;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (xdone) HIP_TRY(hipEventSynchronize(xdone));  // an overlapped sharded search finishes on the communicator's stream
   // device-I/O calls cannot return their timeout: it is reported here (and in mi355_last_stats)
   uint32_t timed_out = 0;
   HIP_TRY(hipMemcpy(&timed_out, &ix->w_ctl.as<DevCtl>()->timed_out, 4, hipMemcpyDeviceToHost));
@@ -518,19 +537,20 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
                 "scan variant %u does not match the code layout this index was packed for (%u)",
                 scan_variant, ix->layout);
   std::lock_guard<std::mutex> lk(ix->mu);
-  ix->scan_variant = scan_variant;
-  ix->slice_rows = (slice_rows + 15u) & ~15u;
-  ix->profile = profile & MI355_PROFILE_MASK;
-  ix->use_graph = (profile & MI355_CFG_GRAPH) != 0;
-  ix->coalesce = (profile & MI355_CFG_COALESCE) != 0;
-  ix->defer_cfg = (profile & MI355_CFG_DEFER_REFINE) != 0;
-  ++ix->ws_gen;  // captured graphs bake in the slicing
+  // quiesce first, commit the new mode only when that worked (a failing call leaves the handle as it was)
   HIP_TRY(hipSetDevice(ix->device));
   ST_TRY(join_exchange(ix));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ST_TRY(drain_events(ix, true));
-  reset_stats(ix);
   HIP_TRY(hipMemset(ix->w_ctl.p, 0, sizeof(DevCtl)));
+  reset_stats(ix);
+  ix->scan_variant = scan_variant;
+  ix->slice_rows = (slice_rows + 15u) & ~15u;
+  ix->profile = profile & MI355_PROFILE_MASK;
+  ix->use_graph = (profile & MI355_CFG_GRAPH) != 0;
+  ix->coalesce.store((profile & MI355_CFG_COALESCE) != 0, std::memory_order_relaxed);
+  ix->defer_cfg = (profile & MI355_CFG_DEFER_REFINE) != 0;
+  ++ix->ws_gen;  // captured graphs bake in the slicing
   return MI355_OK;
 } MI355_ABI_GUARD("mi355_index_configure")
 

@@ -101,6 +101,9 @@ struct SearchCall {  // one caller's buffers (host or device, per params->io_mem
   uint64_t* out_rowids;
   float* out_dist;
   uint32_t* out_counts;
+  // when the call ENTERED the library: QueryExecutionOptions.timeout (query.rs:641) covers the whole call, the time it
+  // waits in the coalescing queue and its batching window included
+  std::chrono::steady_clock::time_point t0;
 };
 
 // host-side checks of a call (no device work); fills the derived numbers
@@ -225,7 +228,16 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
                      (ix->profile & MI355_PROFILE_MASK) != 1 && calls.size() == 1 && ix->raw_is_host && ix->defer_cfg;
   if (!defer) ST_TRY(join_exchange(ix));
   hipStream_t st = ix->stream;
-  auto t_start = std::chrono::steady_clock::now();
+  // the deadline of a coalesced batch is its OLDEST call's: the device is armed with what is left of that budget
+  auto t_start = calls[0].t0;
+  for (const SearchCall& c : calls) t_start = std::min(t_start, c.t0);
+  uint32_t timeout_left = p->timeout_ms;
+  if (p->timeout_ms) {
+    const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
+    if (waited >= (long long)p->timeout_ms)
+      return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms (before the device was reached)", waited, p->timeout_ms);
+    timeout_left = p->timeout_ms - (uint32_t)waited;
+  }
   const uint32_t k = sh.k;
   uint32_t n_queries = 0;
   for (const SearchCall& c : calls) n_queries += c.nq;
@@ -325,9 +337,9 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
                          !ext_probes && pl.filter.mode == MI355_FILTER_NONE;
   bool used_graph = false;
   if (graphable)
-    ST_TRY(run_graphed(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt, d_cnt_ann, p->timeout_ms, &used_graph));
+    ST_TRY(run_graphed(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt, d_cnt_ann, timeout_left, &used_graph));
   else
-    ST_TRY(launch_sequence(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt, d_cnt_ann, p->timeout_ms));
+    ST_TRY(launch_sequence(ix, d_q, n_queries, pl, d_ids, d_dist, d_cnt, d_cnt_ann, timeout_left));
   account(ix, n_queries, pl.nprobe);
 
   if (sh.np_max > sh.np_min) ST_TRY(expand_short_queries(ix, d_q, n_queries, pl, sh.np_max, d_ids, d_dist, d_cnt, d_cnt_ann, host_io));
@@ -391,6 +403,7 @@ static bool same_search(const mi355_search_params* a, const mi355_search_params*
 static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_queries,
                            const mi355_search_params* p, const uint64_t* ext_probes, uint32_t ext_nprobe,
                            uint64_t* out_rowids, float* out_dist, uint32_t* out_counts) {
+  const auto t_entry = std::chrono::steady_clock::now();
   SearchShape sh;
   ST_TRY(check_search(ix, queries, n_queries, p, ext_probes, ext_nprobe, out_rowids, out_dist, out_counts, &sh, false));
   if (n_queries == 0) return MI355_OK;
@@ -403,7 +416,7 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
     }
     return MI355_OK;
   }
-  std::vector<SearchCall> calls{{queries, n_queries, out_rowids, out_dist, out_counts}};
+  std::vector<SearchCall> calls{{queries, n_queries, out_rowids, out_dist, out_counts, t_entry}};
   const bool queued = ix->coalesce && p->io_mem == MI355_MEM_HOST && !ext_probes && n_queries <= 256 &&
                       p->filter_mode == MI355_FILTER_NONE;
   if (!queued) {
@@ -418,6 +431,7 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
   me.out_rowids = out_rowids;
   me.out_dist = out_dist;
   me.out_counts = out_counts;
+  me.t0 = t_entry;
   std::vector<PendingSearch*> served;
   if (!ix->cq.enter(me, [&](const PendingSearch& o) { return same_search(p, o.params); }, 4096u, served)) {
     if (me.status != MI355_OK) return fail(me.status, "%s", me.error);  // (the batch that carried it failed)
@@ -433,7 +447,7 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
     char err[256] = "the batch that carried this call failed with a C++ exception in its leading call";
     ~LeaveGuard() { ix->cq.leave(served, status, err); }
   } guard{ix, served};
-  for (PendingSearch* o : served) calls.push_back({o->queries, o->nq, o->out_rowids, o->out_dist, o->out_counts});
+  for (PendingSearch* o : served) calls.push_back({o->queries, o->nq, o->out_rowids, o->out_dist, o->out_counts, o->t0});
   int32_t status;
   {
     std::lock_guard<std::mutex> lk(ix->mu);

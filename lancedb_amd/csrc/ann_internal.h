@@ -177,6 +177,7 @@ struct PendingSearch : QueueWaiter {
   uint64_t* out_rowids;
   float* out_dist;
   uint32_t* out_counts;
+  std::chrono::steady_clock::time_point t0;  // when the call entered the library (its timeout starts there)
 };
 
 struct mi355_index {
@@ -207,6 +208,7 @@ struct mi355_index {
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
   // SkewShape of the packed codes (MI355_SCAN_SKEW): columns per slab, slabs per row, generalised kernel or not
   uint32_t sk_M = 0, sk_slabs = 1, sk_slabbed = 0, sk_res_floats = 0;
+  DevBuf w_rqq;      // |q|^2 of the original queries for the host-column re-rank (k_refine_gather, cosine)
   DevBuf w_partial;  // per-workgroup partial row sums between the slabs of a work item (sk_slabs > 1)
   DevBuf w_cand2b, w_cnt2b;  // the second buffer set of the deferred refine (each set has its own allocations)
   bool defer_cfg = false;    // MI355_CFG_DEFER_REFINE
@@ -230,7 +232,8 @@ struct mi355_index {
   uint64_t r_seq = 0;
   // config
   uint32_t scan_variant = MI355_SCAN_AUTO, slice_rows = 0, profile = 0;
-  bool use_graph = false, coalesce = true;  // graph replay measured slower than eager launches
+  bool use_graph = false;  // graph replay measured slower than eager launches
+  std::atomic<bool> coalesce{true};  // read without the handle's lock by every host-I/O call
   mi355_stats stats{};
   std::vector<EventSet> ev_free, ev_pending;
   std::map<GraphKey, GraphEntry> graphs;

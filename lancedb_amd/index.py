@@ -39,6 +39,8 @@ def _host(a, dtype):
     return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 
 
+_KEEP = object()  # "argument not given": FlatIndex.configure keeps the handle's current value
+
 class SearchResult:
     """Per query: `counts[q]` rows sorted by (_distance, _rowid); padded with
     UINT64_MAX / +inf (python/python/lancedb/query.py:1365-1370)."""
@@ -282,14 +284,27 @@ class FlatIndex(_Handle):
     def sync(self):
         check(lib().mi355_flat_sync(self._h))
 
-    def configure(self, gemm_variant=_abi.FLAT_GEMM_AUTO, grid_workgroups=0, checksum=False, profile=False, path=None):
+    def configure(self, gemm_variant=_KEEP, grid_workgroups=_KEEP, checksum=_KEEP, profile=False, path=_KEEP):
         """Tuning of the GEMM filter (include/mi355_ann.h mi355_flat_configure).  `path`: None = the cheaper exact path
-        per call, "filter" = MFMA filter + exact re-rank whenever the call allows it, "sweep" = the exact sweep."""
-        flags = (_abi.FLAT_CHECKSUM if checksum else 0) | (_abi.FLAT_PROFILE if profile else 0)
-        if path not in (None, "filter", "sweep"):
-            raise ValueError("path must be None, 'filter' or 'sweep'")
+        per call, "filter" = MFMA filter + exact re-rank whenever the call allows it, "sweep" = the exact sweep.
+        An argument that is NOT given keeps the handle's current value (after open: automatic schedule / grid / path, no
+        checksum), so a profile-only call — analyze_plan() — does not undo a pinned A/B configuration (ADVICE round 4);
+        `profile` is per call like IvfPqIndex.configure's."""
+        if gemm_variant is not _KEEP:
+            self._gemm_variant = int(gemm_variant)
+        if grid_workgroups is not _KEEP:
+            self._grid = int(grid_workgroups)
+        if checksum is not _KEEP:
+            self._checksum = bool(checksum)
+        if path is not _KEEP:
+            if path not in (None, "filter", "sweep"):
+                raise ValueError("path must be None, 'filter' or 'sweep'")
+            self._path = path
+        path = getattr(self, "_path", None)
+        flags = (_abi.FLAT_CHECKSUM if getattr(self, "_checksum", False) else 0) | (_abi.FLAT_PROFILE if profile else 0)
         flags |= _abi.FLAT_FORCE_FILTER if path == "filter" else _abi.FLAT_FORCE_SWEEP if path == "sweep" else 0
-        check(lib().mi355_flat_configure(self._h, C.c_uint32(gemm_variant), C.c_uint32(grid_workgroups), C.c_uint32(flags)))
+        check(lib().mi355_flat_configure(self._h, C.c_uint32(getattr(self, "_gemm_variant", _abi.FLAT_GEMM_AUTO)),
+                                         C.c_uint32(getattr(self, "_grid", 0)), C.c_uint32(flags)))
 
     def stats(self):
         """GEMM kernel time accumulated since configure(profile=True) (mi355_flat_last_stats)."""

@@ -164,6 +164,37 @@ def test_refine_from_host_mapped_raw_vectors(oracle):
         assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()
 
 
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_host_column_gather_stages_rows_through_lds_for_every_dtype_and_ragged_shape(oracle, metric):
+    """k_refine_gather (csrc/kernels_ivfpq.h): eight lanes fetch 128 contiguous bytes of a candidate row per instruction,
+    256 bytes of each of a wave's 64 rows per round, staged in LDS; every lane then runs its candidate's chain.  Rows
+    whose byte length is not a multiple of the round (dim 72 f32 = 288 B, dim 40 bf16 = 80 B), candidate counts that do
+    not fill a wave (k * refine_factor = 77, 130) and a wave that serves two queries must give exactly the oracle's
+    distances; a row length that is not a multiple of 16 B (dim 50 f16) takes the one-row-per-lane kernel."""
+    rng = np.random.default_rng(5)
+    for dim, m in ((72, 9), (40, 8), (50, 10), (256, 32)):
+        n = 40000
+        s = train.synthetic_index(n, dim, 24, m, seed=dim, skew=0.6, empty_parts=1)
+        rawf = rng.normal(size=(n, dim)).astype(np.float32)
+        cols = [(rawf, _abi.DTYPE_F32), (rawf.astype(np.float16).view(np.uint16), _abi.DTYPE_F16)]
+        # bf16 bits: round-to-nearest-even of the f32 pattern
+        u = rawf.view(np.uint32).astype(np.uint64)
+        bf = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+        cols.append((bf, _abi.DTYPE_BF16))
+        for raw_bits, code in cols:
+            o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                                   raw_vectors=raw_bits, metric=metric, raw_dtype=code)
+            g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"],
+                                       raw_vectors=raw_bits, metric=metric, raw_dtype=code, raw_host_mapped=True)
+            q = rng.normal(size=(5, dim)).astype(np.float32)
+            for kw in (dict(k=7, refine_factor=11), dict(k=10, refine_factor=13), dict(k=1, refine_factor=3)):
+                kw = dict(nprobe_min=8, nprobe_max=8, **kw)
+                got = g.search(q, **kw)
+                ids, dist, cnt, _ = o.search(q, **kw)
+                assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all(), (dim, code, kw)
+            g.close()
+
+
 def test_deferred_refine_overlaps_the_next_call_and_stays_exact(oracle):
     """Device-I/O refine calls leave their exact re-rank on the handle's refine stream (two buffer sets): several
     calls in flight, results complete at sync(), every batch == the oracle; other entry points join first."""

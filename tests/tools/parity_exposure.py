@@ -28,14 +28,14 @@ R = bench.recall_index(a, dim, m)
 import torch  # noqa: E402
 import lancedb_amd  # noqa: E402
 
-ix = lancedb_amd.IvfPqIndex(R["cen"].contiguous(), R["codebook"].contiguous(), R["part_offsets"], R["codes"], R["order"], raw_vectors=R["xs"])
+ix = lancedb_amd.IvfPqIndex(R["cen"].contiguous(), R["codebook"].contiguous(), R["part_offsets"], R["codes"], R["order"], raw_vectors=R["xs"].float())
 q = R["q"].cpu().numpy()
 cen = R["cen"].cpu().numpy()
 cb = R["codebook"].cpu().numpy()            # [m, 256, dsub]
 po = np.asarray(R["part_offsets"]).astype(np.int64)
 codes = R["codes"].cpu().numpy().reshape(-1, m)  # index order
 order = R["order"].cpu().numpy().astype(np.int64)  # index position -> row id
-xs = R["xs"].cpu().numpy()                  # raw rows in index order
+xs = R["xs"].float().cpu().numpy()                  # raw rows in index order
 pos_of = np.empty(len(order), np.int64)
 pos_of[order] = np.arange(len(order))
 

@@ -103,6 +103,7 @@ def parse():
                     help="N > 1: queries per step = this x N (the batch grows with the ranks) instead of --batch")
     ap.add_argument("--widths", type=int, default=1, help="secondary lines at the reference's default PQ widths m = dim / 16 (384-d, 3072-d); 0 = skip")
     ap.add_argument("--gist-rows", type=int, default=1_000_000, help="rows of the GIST1M-shaped recall@1 / latency line; 0 = skip")
+    ap.add_argument("--c5-hugepages", type=int, default=0, help="back the C5 host column with MADV_HUGEPAGE memory (A/B of the PCIe gather)")
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--slice-rows", type=int, default=0)
     return ap.parse_args()
@@ -605,6 +606,22 @@ def loopback_world(a, torch, np, ix, centroids, codebook, part_offsets, codes, r
     return res
 
 
+def host_column(np, n, dim, hugepages):
+    """The caller's raw column of the C5 leg ([n, dim] bf16 bit patterns in host memory).  hugepages: anonymous memory
+    advised MADV_HUGEPAGE before it is touched — the GPU reaches a registered host range through the IOMMU / its own
+    page tables, and a random 3-KiB row per candidate is a translation miss per row with 4-KiB pages."""
+    if not hugepages:
+        return np.empty((n, dim), dtype=np.uint16)
+    import mmap
+    nbytes = n * dim * 2
+    mm = mmap.mmap(-1, (nbytes + (2 << 20) - 1) & ~((2 << 20) - 1), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    try:
+        mm.madvise(mmap.MADV_HUGEPAGE)
+    except (AttributeError, OSError):
+        pass
+    return np.frombuffer(mm, dtype=np.uint16, count=n * dim).reshape(n, dim)
+
+
 def c5_refine10(a, torch, np, dev):
     """BASELINE.json configs[4] (query.rs:1302-1332, table/query.rs:311-313): IVF-PQ + refine, 100 M x 1536, cosine,
     nprobe 64, refine_factor 10; nlist 4096 and m = 96 = dim / 16 are the reference's default rules
@@ -672,7 +689,7 @@ def c5_refine10(a, torch, np, dev):
     # depend on the values); host: filled by 64 threads from one random block
     t_raw = time.perf_counter()
     if host_mapped:
-        raw = np.empty((n, dim), dtype=np.uint16)
+        raw = host_column(np, n, dim, a.c5_hugepages)
         flat = raw.reshape(-1)
         blk = np.random.default_rng(SEED + 6).integers(0, 0x4000, size=1 << 27, dtype=np.uint16)  # 256 MB
 

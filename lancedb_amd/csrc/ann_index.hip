@@ -130,32 +130,6 @@ int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, ui
   ra.ctl = ix->w_ctl.as<DevCtl>();
   ra.n_rows = (uint32_t)ix->n_local;
   ra.act = act;
-  ra.qq = nullptr;
-  // a raw column in host memory (MI355_INDEX_RAW_HOST_MAPPED): the coalesced PCIe gather (k_refine_gather)
-  const uint32_t esz = view.raw_dtype == MI355_DTYPE_F32 ? 4u : 2u;
-  if (ix->raw_is_host && view.raw && ((size_t)ix->dim * esz) % 16u == 0 && ((size_t)view.raw & 15u) == 0 && (uint64_t)nq * kk < (1ull << 40) &&
-      dev_knob("MI355_REFINE_GATHER", 1)) {
-    if (ix->metric == MI355_METRIC_COSINE) {
-      ST_TRY(ix->w_rqq.ensure(sizeof(float) * nq));
-      hipLaunchKernelGGL(k_queries_sq, dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, ix->dim, ix->w_rqq.as<float>());
-      ra.qq = ix->w_rqq.as<float>();
-    }
-    ra.nq = nq;
-    const uint64_t total = (uint64_t)nq * kk;
-    // beside a scan (max_blocks_y != 0): two workgroups on each of the CUs the scan leaves free; alone: two per CU
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2ull * (max_blocks_y ? MI355_REFINE_SIDE_CUS : ix->n_cus));
-    const size_t lds = (size_t)4 * 64 * RG_PITCH;
-    auto go = [&](auto kern) -> int {
-      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3(std::max(1u, blocks)), dim3(256), lds, st, ra);
-      return MI355_OK;
-    };
-    const int rc = view.raw_dtype == MI355_DTYPE_F32 ? go(k_refine_gather<MI355_DTYPE_F32>)
-                   : view.raw_dtype == MI355_DTYPE_BF16 ? go(k_refine_gather<MI355_DTYPE_BF16>) : go(k_refine_gather<MI355_DTYPE_F16>);
-    if (rc != MI355_OK) return rc;
-    HIP_TRY(hipGetLastError());
-    return MI355_OK;
-  }
   const size_t rl = ((size_t)ix->dim * 4 + 15) & ~(size_t)15;
   for (uint32_t q0 = 0; q0 < nq; q0 += 65535u) {  // grid.y limit
     const uint32_t n = std::min(65535u, nq - q0);

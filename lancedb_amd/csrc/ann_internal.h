@@ -208,7 +208,6 @@ struct mi355_index {
   DevBuf cbT, order, xcd_first, p_cnt, p_off, p_fill, q_start, heads, items, qthr, w_filter, w_probes64;
   // SkewShape of the packed codes (MI355_SCAN_SKEW): columns per slab, slabs per row, generalised kernel or not
   uint32_t sk_M = 0, sk_slabs = 1, sk_slabbed = 0, sk_res_floats = 0;
-  DevBuf w_rqq;      // |q|^2 of the original queries for the host-column re-rank (k_refine_gather, cosine)
   DevBuf w_partial;  // per-workgroup partial row sums between the slabs of a work item (sk_slabs > 1)
   DevBuf w_cand2b, w_cnt2b;  // the second buffer set of the deferred refine (each set has its own allocations)
   bool defer_cfg = false;    // MI355_CFG_DEFER_REFINE

@@ -1731,137 +1731,13 @@ struct RefineArgs {
                            // that a timed-out scan left unwritten must not become an address)
   uint32_t nq;             // queries of this launch (grid.y may be smaller: the workgroups stride over them)
   uint32_t side_slots;     // SIDE kernel: threads per query, a multiple of 64 that divides 256 (256 when kk > 128)
-  const float* qq;         // k_refine_gather, cosine: |q|^2 chains of the ORIGINAL queries [nq] (k_queries_sq)
   ActiveMask act;
 };
 
-// ---- refine over a raw column in HOST memory (MI355_INDEX_RAW_HOST_MAPPED; C5: 100 M x 1536 does not fit HBM) ----------
-// k_refine_dist gives every lane a candidate row and lets it read the row 16 B at a time: a wave instruction is then 64
-// separate 16-B reads of 64 different rows, and over PCIe every one of them is a read request of its own (the link moves
-// 64-B payloads at least): the round-4 re-rank ran at 20.6 GB/s, 0.32 of the link.  Here EIGHT lanes read 128 contiguous
-// bytes of one row per instruction (8 x 16 B: one request), a wave fetches RG_CH bytes of each of its 64 candidate rows
-// per round — sixteen instructions in flight per lane — stages them in LDS and then every lane runs ITS candidate's chain
-// over the staged bytes: the same per-element chain as exact_distance (d ascending; bf16 / f16 widened exactly), so the
-// distances are bit-identical.  Candidates are numbered flat over the launch's (query, slot) pairs: a wave's 64 lanes may
-// serve two queries, and only the last wave of a launch has idle lanes.
-#define RG_CH 256u              // bytes of a row staged per round
-#define RG_PITCH (RG_CH + 16u)  // LDS pitch of a staged row: the lanes' 16-B reads of their own rows fall into distinct bank groups
-typedef __attribute__((ext_vector_type(4))) uint32_t rg_u32x4;
-static __global__ __launch_bounds__(256) void k_queries_sq(const float* __restrict__ q, uint32_t nq, uint32_t dim, float* __restrict__ out) {
-  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-  if (b >= nq) return;
-  const float* v = q + (size_t)b * dim;
-  float acc = 0.f;
-  for (uint32_t d = 0; d < dim; ++d) acc = __fmaf_rn(v[d], v[d], acc);
-  out[b] = acc;
-}
-template <int DT>  // MI355_DTYPE_* of the column (compile time: the widening is in the inner loop)
-static __global__ __launch_bounds__(256) void k_refine_gather(RefineArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [4 waves][64 rows][RG_PITCH]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (a.ctl && a.ctl->timed_out) return;
-  unsigned char* st = smem + (size_t)wid * 64u * RG_PITCH;
-  constexpr uint32_t ESZ = DT == MI355_DTYPE_F32 ? 4u : 2u, PER = 16u / ESZ;  // elements per 16-B piece
-  const uint32_t dim = a.ix.dim, metric = a.ix.metric;
-  const uint32_t row_bytes = dim * ESZ;  // a multiple of 16 (checked by the launcher)
-  const uint32_t n_rounds = (row_bytes + RG_CH - 1u) / RG_CH;
-  const uint64_t total = (uint64_t)a.nq * a.kk;
-  const unsigned char* raw = (const unsigned char*)a.ix.raw;
-  const uint32_t g = (uint32_t)lane >> 3, sgrp = (uint32_t)lane & 7u;
-  for (uint64_t f0 = ((uint64_t)blockIdx.x * 4u + (uint32_t)wid) * 64u; f0 < total; f0 += (uint64_t)gridDim.x * 256u) {
-    const uint64_t f = f0 + (uint32_t)lane;
-    const bool inside = f < total;
-    const uint32_t b = inside ? (uint32_t)(f / a.kk) : 0u, c = inside ? (uint32_t)(f % a.kk) : 0u;
-    bool valid = inside && a.act.on(b);
-    Cand in;
-    in.d = 0.f;
-    in.pos = CAND_EMPTY_POS;
-    in.id = ~0ull;
-    if (valid) {
-      valid = c < min(a.in_cnt[b], a.kk) && (!a.in_owner || a.in_owner[(size_t)b * a.kk + c] == a.my_rank);
-      if (valid) in = a.in[(size_t)b * a.kk + c];
-      valid = valid && in.pos != CAND_EMPTY_POS && in.pos < a.n_rows;
-    }
-    const uint64_t rrow = !valid ? 0ull : a.ix.raw_by_global ? global_pos_of(a.ix, in.pos) : (uint64_t)in.pos;
-    // (an idle lane reads row 0: its bytes are never used)
-    const unsigned long long rp = (unsigned long long)(raw + rrow * row_bytes);
-    const float* q = a.q + (size_t)b * dim;
-    DistAcc acc = {0.f, 0.f, 0.f};
-    for (uint32_t r = 0; r < n_rounds; ++r) {
-      const uint32_t off0 = r * RG_CH;
-      const uint32_t span = min(RG_CH, row_bytes - off0);  // bytes of this round (a multiple of 16)
-      rg_u32x4 buf[16];
-#pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {
-        const int srcl = pass * 8 + (int)g;  // the lane whose candidate this group of eight lanes fetches now
-        const unsigned long long base = ((unsigned long long)(uint32_t)__shfl((int)(rp >> 32), srcl) << 32) |
-                                        (unsigned long long)(uint32_t)__shfl((int)(uint32_t)rp, srcl);
-#pragma unroll
-        for (int i = 0; i < (int)(RG_CH / 128u); ++i) {
-          const uint32_t o = min(off0 + (uint32_t)i * 128u + sgrp * 16u, row_bytes - 16u);  // (clamped: unconditional load)
-          buf[pass * 2 + i] = *(const rg_u32x4*)(base + o);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // the previous round's staged bytes have been consumed by every lane
-#pragma unroll
-      for (int pass = 0; pass < 8; ++pass)
-#pragma unroll
-        for (int i = 0; i < (int)(RG_CH / 128u); ++i)
-          *(rg_u32x4*)(st + (size_t)(pass * 8 + (int)g) * RG_PITCH + (uint32_t)i * 128u + sgrp * 16u) = buf[pass * 2 + i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // this lane's candidate: `span` staged bytes, elements d0 .. in order
-      const unsigned char* mine = st + (size_t)lane * RG_PITCH;
-      const uint32_t d0 = off0 / ESZ;
-      for (uint32_t k0 = 0; k0 < span; k0 += 64u) {  // four pieces at a time (span % 64 may be 16 .. 48 in the last step)
-        rg_u32x4 w4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = *(const rg_u32x4*)(mine + min(k0 + (uint32_t)e * 16u, span - 16u));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (k0 + (uint32_t)e * 16u >= span) break;
-          const uint32_t dd = d0 + (k0 / 16u + (uint32_t)e) * PER;
-          const uint32_t w[4] = {w4[e].x, w4[e].y, w4[e].z, w4[e].w};
-          if constexpr (DT == MI355_DTYPE_F32) {
-            const float4 qv = *(const float4*)(q + dd);
-            dist_step(acc, qv.x, __uint_as_float(w[0]), metric);
-            dist_step(acc, qv.y, __uint_as_float(w[1]), metric);
-            dist_step(acc, qv.z, __uint_as_float(w[2]), metric);
-            dist_step(acc, qv.w, __uint_as_float(w[3]), metric);
-          } else {
-            const float4 qa = *(const float4*)(q + dd), qb = *(const float4*)(q + dd + 4);
-            const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const uint16_t lo = (uint16_t)(w[t] & 0xffffu), hi = (uint16_t)(w[t] >> 16);
-              const float v0 = DT == MI355_DTYPE_BF16 ? bf16_bits_to_f32(lo) : f16_bits_to_f32(lo);
-              const float v1 = DT == MI355_DTYPE_BF16 ? bf16_bits_to_f32(hi) : f16_bits_to_f32(hi);
-              dist_step(acc, qs[2 * t], v0, metric);
-              dist_step(acc, qs[2 * t + 1], v1, metric);
-            }
-          }
-        }
-      }
-    }
-    if (inside) {
-      Cand o;
-      o.d = __builtin_huge_valf();
-      o.pos = CAND_EMPTY_POS;
-      o.id = ~0ull;
-      if (valid) {
-        const float d = dist_finish(acc, metric, metric == MI355_METRIC_COSINE ? a.qq[b] : 0.f);
-        if (in_range(d, a.range)) {
-          o.d = d;
-          o.pos = in.pos;
-          o.id = in.id;
-        }
-      }
-      a.out[f] = o;
-    }
-  }
-}
-
+// (Round 5 measured a coalesced variant of the host-column re-rank — eight lanes per 128 contiguous bytes of a row, rows
+//  staged through LDS, one chain per lane — against this one-row-per-lane kernel: 23.6 against 29.5 GB/s at a 61 GB
+//  column, 16.5 against 20.6 GB/s at 200 GB.  The rate falls with the column's footprint, not with the request shape:
+//  the gather is bound by address translation of random 3-KiB rows in host memory; profiles/r05_c5_gather_ab.txt.)
 // SIDE = false: the query and its |q|^2 live in LDS (one workgroup per query).
 // SIDE = true (the deferred re-rank that runs BESIDE the next call's scan on a few reserved CUs): no LDS at
 // all and a small grid striding over the queries — the scan's workgroups take a whole CU each (128 VGPRs x 16

@@ -1017,11 +1017,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         constexpr int V = DS / 4;    // 16-B pieces per codebook entry
         constexpr int EPR = (SK_LUT_INFLIGHT / V) > 0 ? (SK_LUT_INFLIGHT / V) : 1;  // entries per thread per round
         constexpr uint32_t TOTAL = KSUB * (uint32_t)M;
-        for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
-          // (ext-vector registers and unconditional loads at a clamped entry: an array of more than eight HIP float4
-          //  structs stays in scratch and a load guarded per element is waited for on its own — scripts/check_scratch.py)
-          sk_f32x4 cv4[EPR][V];
-          bool ok[EPR];
+        // (ext-vector registers and unconditional loads at a clamped entry: an array of more than eight HIP float4
+        //  structs stays in scratch and a load guarded per element is waited for on its own — scripts/check_scratch.py)
+        auto load_round = [&](uint32_t e0, sk_f32x4 (&cv4)[EPR][V], bool (&ok)[EPR]) {
 #pragma unroll
           for (int u = 0; u < EPR; ++u) {
             const uint32_t e = e0 + u * NT;
@@ -1032,6 +1030,8 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
 #pragma unroll
             for (int v = 0; v < V; ++v) cv4[u][v] = *(const sk_f32x4*)(src + 4 * v);
           }
+        };
+        auto compute_round = [&](uint32_t e0, const sk_f32x4 (&cv4)[EPR][V], const bool (&ok)[EPR]) {
 #pragma unroll
           for (int u = 0; u < EPR; ++u) {
             const uint32_t e = e0 + u * NT;
@@ -1060,6 +1060,15 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
               put(e, acc, ok[u]);
             }
           }
+        };
+        // (measured and not kept, round 5: a two-set software pipeline of these rounds — 27.7 -> 46.5 ms per C3 launch, the
+        //  second register set spills under the 128-VGPR cap; 12 / 16 / 24 pieces in flight per thread instead of 8:
+        //  -0.7 / -3.5 / -9 % QPS.  The build streams 786 KB of codebook per table from L2; profiles/r05_lut_build_ab.txt)
+        for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
+          sk_f32x4 cv4[EPR][V];
+          bool ok[EPR];
+          load_round(e0, cv4, ok);
+          compute_round(e0, cv4, ok);
         }
       };
       auto lut_fast = [&](auto ds_tag, auto ks_tag) {

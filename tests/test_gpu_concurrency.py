@@ -165,12 +165,10 @@ def test_refine_from_host_mapped_raw_vectors(oracle):
 
 
 @pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
-def test_host_column_gather_stages_rows_through_lds_for_every_dtype_and_ragged_shape(oracle, metric):
-    """k_refine_gather (csrc/kernels_ivfpq.h): eight lanes fetch 128 contiguous bytes of a candidate row per instruction,
-    256 bytes of each of a wave's 64 rows per round, staged in LDS; every lane then runs its candidate's chain.  Rows
-    whose byte length is not a multiple of the round (dim 72 f32 = 288 B, dim 40 bf16 = 80 B), candidate counts that do
-    not fill a wave (k * refine_factor = 77, 130) and a wave that serves two queries must give exactly the oracle's
-    distances; a row length that is not a multiple of 16 B (dim 50 f16) takes the one-row-per-lane kernel."""
+def test_host_column_refine_for_every_dtype_and_ragged_row_length(oracle, metric):
+    """Refine over a host-mapped column (MI355_INDEX_RAW_HOST_MAPPED) in all three element types: rows whose byte length is a
+    multiple of 16 (dim 72 f32 = 288 B, dim 40 bf16 = 80 B) take 16-B pieces, the others (dim 50 f16 = 100 B) scalar loads;
+    candidate counts that do not fill a wave (k * refine_factor = 77, 130) — distances must be exactly the oracle's."""
     rng = np.random.default_rng(5)
     for dim, m in ((72, 9), (40, 8), (50, 10), (256, 32)):
         n = 40000

@@ -1,7 +1,7 @@
 """Dev: where a scan work item's time goes as a function of kk = k * refine_factor, from the counters a
 -DMI355_DEV_COUNTERS build keeps (kernels_skew.h SK_DEV): per-item LUT / scan / merge time, rows admitted to the
 candidate lists, rows in the lists at the merge, optimistic passes redone, items that ran without a query bound.
-usage: MI355_ANN_LIB=lancedb_amd/variants/lib_dev.so python tests/tools/scan_dev_counters.py [rows] [batch]"""
+usage: MI355_ANN_LIB=lancedb_amd/variants/lib_dev.so python tests/tools/scan_dev_counters.py [rows] [batch] [nlist]"""
 import ctypes as C
 import sys
 
@@ -15,7 +15,7 @@ from lancedb_amd import _abi, _lib  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 dim, m, nprobe = 768, 96, 64
-nlist = max(64, n // 24_414)
+nlist = int(sys.argv[3]) if len(sys.argv) > 3 else max(64, n // 24_414)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(0x1A2CE)

@@ -154,7 +154,7 @@ int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, ui
 bool lat_front_applies(const mi355_index* ix, uint32_t nq, const SearchPlan& pl) {
   const size_t small_lds = ((size_t)nq * (((size_t)ix->dim + 3) & ~(size_t)3) + nq) * sizeof(float);
   return ix->layout == MI355_SCAN_SKEW && !pl.ext_probes && !pl.act.n && nq >= 1 && nq <= CS_MAXQ && small_lds <= 96u * 1024 &&
-         ix->metric != MI355_METRIC_COSINE && (ix->dim & 3u) == 0 && ix->nlist <= SELPLAN_MAX_NLIST && pl.nprobe <= ix->nlist &&
+         (ix->dim & 3u) == 0 && ix->nlist <= SELPLAN_MAX_NLIST && pl.nprobe <= ix->nlist &&
          (uint64_t)nq * pl.nprobe <= PLAN_SPARSE_MAX_PAIRS && !dev_knob("MI355_COARSE_VALU", 0) && dev_knob("MI355_LAT_SMALL_FRONT", 1) &&
          dev_knob("MI355_LAT_FRONT", 1);
 }
@@ -318,7 +318,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
         if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((ix->nlist + cpw - 1) / cpw + 1u), dim3(64), lds, st, q, n, ix->dim, view.centroids, ix->nlist,
                            ix->w_qp.as<float>(), ix->w_qq.as<float>(), ix->w_coarse.as<float>(), pl.arm_in_front ? d_ctl : (DevCtl*)nullptr,
-                           pl.arm_ticks, pl.arm_reset);
+                           pl.arm_ticks, pl.arm_reset, ix->metric == MI355_METRIC_COSINE ? 1u : 0u);
         return MI355_OK;
       };
       const int rc = lpc == 4    ? go(k_coarse_lat<4, 24>, coarse_lat_lds<4, 24>(n, ix->dim), 16u)

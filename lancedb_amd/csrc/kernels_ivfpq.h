@@ -493,7 +493,7 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
     }
   }
 }
-// ---- latency front, first half (L2 / dot; dim % 4 == 0): the dot chains alone ---------------------------------------
+// ---- latency front, first half (dim % 4 == 0): the dot chains alone ---------------------------------------
 // k_coarse_split makes every workgroup run the queries' |q|^2 chains before it touches a centroid — 768 dependent fmas
 // fed by dependent LDS reads, ~13 us of the 39 us a single query's coarse stage took on the C3 index — although only
 // the LAST step of a score, fma(-2, dot, |q|^2 + |c|^2), needs them.  Here the centroid workgroups write the raw dot
@@ -509,7 +509,7 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
                                                           const float* __restrict__ cen, uint32_t nlist,
                                                           float* __restrict__ qp, float* __restrict__ qq_out,
                                                           float* __restrict__ out /*[nq, nlist] raw dot chains*/,
-                                                          DevCtl* ctl, unsigned long long arm_ticks, uint32_t arm_reset) {
+                                                          DevCtl* ctl, unsigned long long arm_ticks, uint32_t arm_reset, uint32_t cosine) {
   constexpr int CPW = 64 / LPC;                      // centroids per wave
   constexpr int RP = PF * LPC;                       // pieces of a row per round
   constexpr int JPL = (CS_MAXQ + LPC - 1) / LPC;     // queries per lane
@@ -517,6 +517,7 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
   const uint32_t dimq = dim + 4u;                    // the pad staggers the queries' banks
   float* sq = (float*)smem;                          // [nq][dimq]
   cl_f32x4* stage = (cl_f32x4*)(sq + (size_t)nq * dimq); // [CPW][RP + 1]
+  float* s_n = (float*)(stage + (size_t)CPW * (RP + 1)); // [CS_MAXQ] raw |q|^2 (cosine)
   const int lane = threadIdx.x;
   const uint32_t np = dim / 4u;
 #ifdef MI355_DEV_FRONT  // dev: block 0's stage times -> DevCtl::dev[0..3] (query to LDS / row loads + staging / chains / store)
@@ -525,6 +526,40 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
   for (uint32_t j = 0; j < nq; ++j)
     for (uint32_t d4 = lane; d4 < np; d4 += 64) *(cl_f32x4*)(sq + (size_t)j * dimq + 4u * d4) = *(const cl_f32x4*)(q + (size_t)j * dim + 4u * d4);
   __syncthreads();
+  // one query lane's |v|^2 chain over an LDS row: eight 16-B reads ahead of 32 fmas
+  auto chain_sq = [&](const cl_f32x4* v) -> float {
+    float acc = 0.f;
+    uint32_t p0 = 0;
+    for (; p0 + 8 <= np; p0 += 8) {
+      cl_f32x4 x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = v[p0 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        acc = __fmaf_rn(x[e].x, x[e].x, acc);
+        acc = __fmaf_rn(x[e].y, x[e].y, acc);
+        acc = __fmaf_rn(x[e].z, x[e].z, acc);
+        acc = __fmaf_rn(x[e].w, x[e].w, acc);
+      }
+    }
+    for (; p0 < np; ++p0) {
+      const cl_f32x4 x = v[p0];
+      acc = __fmaf_rn(x.x, x.x, acc);
+      acc = __fmaf_rn(x.y, x.y, acc);
+      acc = __fmaf_rn(x.z, x.z, acc);
+      acc = __fmaf_rn(x.w, x.w, acc);
+    }
+    return acc;
+  };
+  if (cosine) {  // every workgroup normalises its own copy: q / sqrt(|q|^2), exactly k_coarse_small's arithmetic (+4 us)
+    if ((uint32_t)lane < nq) s_n[lane] = chain_sq((const cl_f32x4*)(sq + (size_t)lane * dimq));
+    __syncthreads();
+    for (uint32_t j = 0; j < nq; ++j) {
+      const float nrm = ieee_sqrtf(s_n[j]);
+      for (uint32_t d = lane; d < dim; d += 64) sq[(size_t)j * dimq + d] = ieee_divf(sq[(size_t)j * dimq + d], nrm);
+    }
+    __syncthreads();
+  }
   if (blockIdx.x == gridDim.x - 1u) {  // the queries' own workgroup
     if (lane == 0 && ctl) {
       ctl->deadline = arm_ticks ? (unsigned long long)wall_clock64() + arm_ticks : 0ull;
@@ -537,33 +572,7 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
     }
     for (uint32_t j = 0; j < nq; ++j)
       for (uint32_t d4 = lane; d4 < np; d4 += 64) *(cl_f32x4*)(qp + (size_t)j * dim + 4u * d4) = *(const cl_f32x4*)(sq + (size_t)j * dimq + 4u * d4);
-    if ((uint32_t)lane < nq) {
-      const cl_f32x4* v = (const cl_f32x4*)(sq + (size_t)lane * dimq);
-      float acc = 0.f;
-      // (loads are UNCONDITIONAL, index clamped: a load guarded by `if (i < n)` into an array element makes hipcc
-      //  wait for each one on its own — the disassembly of this file's first version showed 24 serial HBM round trips)
-      uint32_t p0 = 0;
-      for (; p0 + 8 <= np; p0 += 8) {
-        cl_f32x4 x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = v[p0 + e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          acc = __fmaf_rn(x[e].x, x[e].x, acc);
-          acc = __fmaf_rn(x[e].y, x[e].y, acc);
-          acc = __fmaf_rn(x[e].z, x[e].z, acc);
-          acc = __fmaf_rn(x[e].w, x[e].w, acc);
-        }
-      }
-      for (; p0 < np; ++p0) {
-        const cl_f32x4 x = v[p0];
-        acc = __fmaf_rn(x.x, x.x, acc);
-        acc = __fmaf_rn(x.y, x.y, acc);
-        acc = __fmaf_rn(x.z, x.z, acc);
-        acc = __fmaf_rn(x.w, x.w, acc);
-      }
-      qq_out[lane] = acc;
-    }
+    if ((uint32_t)lane < nq) qq_out[lane] = chain_sq((const cl_f32x4*)(sq + (size_t)lane * dimq));
     return;
   }
 #ifdef MI355_DEV_FRONT
@@ -652,7 +661,7 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
 }
 template <int LPC, int PF>
 static inline size_t coarse_lat_lds(uint32_t nq, uint32_t dim) {
-  return (size_t)nq * (dim + 4u) * sizeof(float) + (size_t)(64 / LPC) * (PF * LPC + 1) * 16;
+  return (size_t)nq * (dim + 4u) * sizeof(float) + (size_t)(64 / LPC) * (PF * LPC + 1) * 16 + CS_MAXQ * sizeof(float);
 }
 static inline size_t coarse_split_lds(uint32_t nq, uint32_t dim, int lpc) {
   return ((size_t)nq * (dim + 4u) + CS_MAXQ) * sizeof(float) + (size_t)(64 / lpc) * (16 * lpc + 1) * 16;

@@ -148,6 +148,33 @@ def test_rank_sharded_raw_vectors_host_mapped_and_local_arrays(oracle):
             _same(got[r], exp, f"rank {r}")
 
 
+def test_c5_shape_eight_ranks_each_holding_its_raw_shard_in_hbm(oracle):
+    """BASELINE.json configs[4] at its stated size (100 M x 1536 f32 = 614 GB) fits no single GPU, and no host this box
+    offers: the way it runs is eight ranks, each with the raw rows of ITS partitions resident in HBM (77 GB per rank at
+    full size).  Here at reduced rows, with C5's dimension, PQ width, metric and refine factor: every rank opens a shard
+    handle from local arrays only (codes, row ids and raw f32 rows of its own partitions), refines the merged candidates
+    it owns, the second gather completes the list — and every rank's result is the UNSHARDED oracle's, bit for bit."""
+    from sharded_model import shard_local
+    world, dim, m, nlist, n = 8, 1536, 96, 64, 48_000
+    rng = np.random.default_rng(55)
+    s = train.synthetic_index(n, dim, nlist, m, seed=15, skew=0.6, empty_parts=1)
+    s["raw"] = rng.normal(size=(n, dim)).astype(np.float32)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=s["raw"], metric="cosine")
+    q = (s["centroids"][rng.integers(0, nlist, size=33)] + rng.normal(0, 0.4, size=(33, dim))).astype(np.float32)
+    owner = lancedb_amd.shard_plan(s["part_offsets"], world)
+    locs = [shard_local(s, owner, r) for r in range(world)]
+    shards = [lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], locs[r]["codes"], locs[r]["row_ids"],
+                                     raw_vectors=locs[r]["raw"], metric="cosine", shard_count=world, shard_rank=r, local_arrays=True)
+              for r in range(world)]
+    assert sum(sh.info()[0] for sh in shards) == n
+    for kw in (dict(k=10, nprobe_min=16, nprobe_max=16, refine_factor=10), dict(k=10, nprobe_min=64, nprobe_max=64, refine_factor=10)):
+        exp = o.search(q, **kw)
+        comms = Comm.loopback(world)
+        got = run_ranks([lambda r=r: ShardedSearcher(shards[r], comms[r]).search(q, _abi.make_params(**kw)) for r in range(world)])
+        for r in range(world):
+            _same(got[r], exp, f"rank {r} {kw}")
+
+
 def test_flat_rows_sharded_over_three_loopback_ranks(oracle):
     world = 3
     rng = np.random.default_rng(9)

@@ -312,11 +312,15 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       pa.act = act;
     }
     if (lat_front) {
+      // (the argument block always carries the 3.5 KB slot; it holds the query only for a single host query — pl.host_q)
+      static thread_local CoarseLatQuery qarg_store;
+      CoarseLatQuery* qarg = &qarg_store;
+      if (pl.host_q) memcpy(qarg->v, pl.host_q, sizeof(float) * ix->dim);
       int lpc = 4;
       while (lpc < 16 && (uint64_t)ix->nlist * lpc < 2ull * 64 * ix->n_cus) lpc *= 2;
       auto go = [&](auto kern, size_t lds, uint32_t cpw) -> int {
         if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((ix->nlist + cpw - 1) / cpw + 1u), dim3(64), lds, st, q, n, ix->dim, view.centroids, ix->nlist,
+        hipLaunchKernelGGL(kern, dim3((ix->nlist + cpw - 1) / cpw + 1u), dim3(64), lds, st, *qarg, pl.host_q ? 1u : 0u, q, n, ix->dim, view.centroids, ix->nlist,
                            ix->w_qp.as<float>(), ix->w_qq.as<float>(), ix->w_coarse.as<float>(), pl.arm_in_front ? d_ctl : (DevCtl*)nullptr,
                            pl.arm_ticks, pl.arm_reset, ix->metric == MI355_METRIC_COSINE ? 1u : 0u);
         return MI355_OK;

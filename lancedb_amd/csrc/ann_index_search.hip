@@ -260,7 +260,7 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   const size_t q_bytes = sizeof(float) * (size_t)n_queries * ix->dim;
   const size_t r_bytes = (size_t)n_queries * k * (sizeof(uint64_t) + sizeof(float)) + sizeof(uint32_t) * (size_t)n_queries;
   const bool pinned = host_io && q_bytes + r_bytes <= ((size_t)4 << 20);
-  bool zero_copy_out = false;
+  bool zero_copy_out = false, q_by_arg = false;
   unsigned char* h_pin = nullptr;
   if (host_io) {
     ST_TRY(ix->w_q.ensure(q_bytes));
@@ -280,7 +280,10 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
         memcpy(h_pin + off, c.queries, sizeof(float) * (size_t)c.nq * ix->dim);
         off += sizeof(float) * (size_t)c.nq * ix->dim;
       }
-      HIP_TRY(hipMemcpyAsync(ix->w_q.p, h_pin, q_bytes, hipMemcpyHostToDevice, st));
+      // one query of a plain search: it rides in the first kernel's argument block (k_coarse_lat) — no staging copy
+      q_by_arg = n_queries == 1 && calls.size() == 1 && ix->dim <= CL_ARG_FLOATS && p->refine_factor == 0 && sh.np_max == sh.np_min && !ext_probes &&
+                 !ix->use_graph && (ix->profile & MI355_PROFILE_MASK) == 0 && p->filter_mode == MI355_FILTER_NONE && dev_knob("MI355_LAT_Q_IN_ARG", 1);
+      if (!q_by_arg) HIP_TRY(hipMemcpyAsync(ix->w_q.p, h_pin, q_bytes, hipMemcpyHostToDevice, st));
       // The result arrays of a small batch are the page-locked block itself: the last kernel of the call stores its
       // (k ids + k distances + count) per query straight into host memory (posted PCIe writes, complete at the stream
       // synchronisation below) — the copy kernel that used to follow it was 4 us and a launch per call.
@@ -314,6 +317,13 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   pl.range.lower = p->lower_bound;
   pl.range.upper = p->upper_bound;
   ST_TRY(make_row_filter(p, ix->w_filter, st, &pl.filter));
+  if (q_by_arg) {
+    pl.host_q = calls[0].queries;
+    if (!lat_front_applies(ix, n_queries, pl)) {  // (the shape does not take the latency front after all: stage the query as usual)
+      pl.host_q = nullptr;
+      HIP_TRY(hipMemcpyAsync(ix->w_q.p, h_pin, q_bytes, hipMemcpyHostToDevice, st));
+    }
+  }
   if (ext_probes) {
     pl.ext_probes = ext_probes;
     if (host_io) {

@@ -288,6 +288,8 @@ struct SearchPlan {
   bool arm_in_front = false;
   unsigned long long arm_ticks = 0;
   uint32_t arm_reset = 0;
+  // a single host query handed to the latency front in its kernel arguments (no staging copy): the HOST pointer
+  const float* host_q = nullptr;
 };
 // the latency front (k_coarse_lat + k_select_plan) applies to this pass: a handful of queries on the production scan
 bool lat_front_applies(const mi355_index* ix, uint32_t nq, const SearchPlan& pl);

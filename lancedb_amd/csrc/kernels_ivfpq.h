@@ -504,8 +504,15 @@ static __global__ __launch_bounds__(64) void k_coarse_split(const float* __restr
 // (register arrays of this kernel are clang ext-vectors, not HIP's cl_f32x4 struct: an array of 12+ cl_f32x4 stays in SCRATCH —
 //  hipcc then waits for every global load on its own to store it there: 24 serial HBM round trips, 16 of the kernel's 27 us)
 typedef __attribute__((ext_vector_type(4))) float cl_f32x4;
+// A single host query travels in the kernel's ARGUMENT block (3.5 KB of the 4 KB HIP allows): the runtime copies the
+// arguments into the kernarg segment at launch anyway, so the query needs no staging copy, no copy kernel (4 us) and no
+// launch boundary of its own; the workgroups read it with ordinary loads from the kernarg segment.
+#define CL_ARG_FLOATS 896u
+struct CoarseLatQuery {
+  float v[CL_ARG_FLOATS];
+};
 template <int LPC, int PF>
-static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restrict__ q, uint32_t nq, uint32_t dim,
+static __global__ __launch_bounds__(64) void k_coarse_lat(CoarseLatQuery qarg, uint32_t q_in_arg, const float* __restrict__ q, uint32_t nq, uint32_t dim,
                                                           const float* __restrict__ cen, uint32_t nlist,
                                                           float* __restrict__ qp, float* __restrict__ qq_out,
                                                           float* __restrict__ out /*[nq, nlist] raw dot chains*/,
@@ -523,8 +530,13 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(const float* __restric
 #ifdef MI355_DEV_FRONT  // dev: block 0's stage times -> DevCtl::dev[0..3] (query to LDS / row loads + staging / chains / store)
   const unsigned long long cf_t0 = wall_clock64();
 #endif
-  for (uint32_t j = 0; j < nq; ++j)
-    for (uint32_t d4 = lane; d4 < np; d4 += 64) *(cl_f32x4*)(sq + (size_t)j * dimq + 4u * d4) = *(const cl_f32x4*)(q + (size_t)j * dim + 4u * d4);
+  if (q_in_arg) {  // (nq == 1, dim <= CL_ARG_FLOATS)
+    const cl_f32x4* qa = (const cl_f32x4*)qarg.v;
+    for (uint32_t d4 = lane; d4 < np; d4 += 64) *(cl_f32x4*)(sq + 4u * d4) = qa[d4];
+  } else {
+    for (uint32_t j = 0; j < nq; ++j)
+      for (uint32_t d4 = lane; d4 < np; d4 += 64) *(cl_f32x4*)(sq + (size_t)j * dimq + 4u * d4) = *(const cl_f32x4*)(q + (size_t)j * dim + 4u * d4);
+  }
   __syncthreads();
   // one query lane's |v|^2 chain over an LDS row: eight 16-B reads ahead of 32 fmas
   auto chain_sq = [&](const cl_f32x4* v) -> float {

@@ -61,7 +61,6 @@ extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) try {
   // queries re-searched over maximum_nprobes partitions were counted on the device
   out->n_queries += h_ctl.short_queries;
   out->partitions_probed += (uint64_t)h_ctl.short_queries * ix->second_np;
-  out->work_items += h_ctl.lat_items;  // (work items the sparse planner cut by rows are counted where they are made)
   out->struct_size = sizeof(mi355_stats);
   return MI355_OK;
 } MI355_ABI_GUARD("mi355_last_stats")
@@ -192,7 +191,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   slice = (slice + 15u) & ~15u;
   // the production scan slices by tile positions instead (SkewArgs::n_slices): only when the batch cannot
   // give every CU a work item, and never below ~2 k rows per slice (each slice rebuilds the distance table)
-  uint32_t sk_slices = 1, sk_target = 0;
+  uint32_t sk_slices = 1;
   if (skew) {
     const uint64_t pairs = (uint64_t)nq * nprobe;
     // (round 4: up to 3 work items per CU.  A batch of 8 queries is 512 whole-partition items on 256 CUs: its scan took
@@ -200,17 +199,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     //  distance table, so batches that already give a CU 3 items keep whole partitions.)
     if (pairs && pairs < 3ull * ix->n_cus)
       sk_slices = (uint32_t)std::min<uint64_t>(dev_knob("MI355_LAT_SLICES_MAX", 8), (3ull * ix->n_cus + pairs - 1) / pairs);
-    // A handful of queries (the sparse planner): pairs are cut BY ROWS — about `sk_target` work items of about equal
-    // length (one per CU for a single query: a work item's fixed costs, its distance table first, are paid once per CU
-    // and no CU waits for the longest partition's slice); sk_slices is then the most slices one pair can get.
-    if (pairs && pairs <= PLAN_SPARSE_MAX_PAIRS && pairs < 3ull * ix->n_cus && dev_knob("MI355_LAT_BY_ROWS", 0) && dev_knob("MI355_PLAN_SPARSE", 1)) {
-      const uint32_t per_cu = dev_knob("MI355_LAT_ITEMS_PER_CU", 0);
-      sk_target = per_cu ? per_cu * ix->n_cus : pairs <= ix->n_cus / 2 ? ix->n_cus : pairs <= ix->n_cus ? 2 * ix->n_cus : 3 * ix->n_cus;
-      sk_slices = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, (7ull * sk_target / 2 + pairs - 1) / pairs));
-    }
     sk_slices = std::max(1u, std::min(sk_slices, ix->max_len / 2048u));
     if (pl.kk > 256u) sk_slices = 1;  // (multi-pass selection re-scans per pass: keep whole partitions)
-    if (sk_slices <= 1u) sk_target = 0;
   }
   const uint32_t n_slices = skew ? sk_slices : std::max(1u, (ix->max_len + slice - 1) / slice);
 
@@ -307,8 +297,6 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       // sharded coarse merge, otherwise rank 0 is just the caller's first probe
       pa.best_first = (pl.kk >= dev_knob("MI355_BEST_FIRST_MIN_KK", 1) && nprobe > 1u) ? 1u : 0u;
       pa.n_slices = n_slices;
-      pa.target_items = (pa.n_pairs <= PLAN_SPARSE_MAX_PAIRS) ? sk_target : 0u;
-      pa.items_made = pa.target_items ? &d_ctl->lat_items : (uint32_t*)nullptr;
       pa.act = act;
     }
     if (lat_front) {
@@ -564,8 +552,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ix->ev_pending.push_back(es);
     }
   }
-  if (!(skew && sk_target && (uint64_t)std::min(chunk, nq) * nprobe <= PLAN_SPARSE_MAX_PAIRS))  // (cut by rows: counted on the device, DevCtl::lat_items)
-    ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
+  ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
   return MI355_OK;
 }
 

@@ -28,7 +28,7 @@ struct DevCtl {
   // per-call counters, zeroed together (DEVCTL_COUNTER_BYTES) unless the profile mode is cumulative
   unsigned long long rows_scanned;  // stats: vectors scanned (sum over (query, partition) pairs)
   uint32_t short_queries;           // queries re-searched over maximum_nprobes partitions (decided on the device)
-  uint32_t lat_items;               // work items made by the sparse planner when it cuts pairs by rows (PlanArgs::target_items)
+  uint32_t pad0;
   unsigned long long deadline;      // wall_clock64() value after which kernels stop; 0 = none
   uint32_t timed_out;
   uint32_t bad_probes;              // probe ids outside 0..nlist-1 (mi355_search_probes)
@@ -55,7 +55,6 @@ static __global__ void k_arm_deadline(DevCtl* ctl, unsigned long long ticks, uin
   if (reset_counters) {
     ctl->rows_scanned = 0ull;
     ctl->short_queries = 0u;
-    ctl->lat_items = 0u;
   }
 }
 

@@ -579,7 +579,6 @@ static __global__ __launch_bounds__(64) void k_coarse_lat(CoarseLatQuery qarg, u
       if (arm_reset) {
         ctl->rows_scanned = 0ull;
         ctl->short_queries = 0u;
-        ctl->lat_items = 0u;
       }
     }
     for (uint32_t j = 0; j < nq; ++j)

@@ -78,8 +78,8 @@ struct __attribute__((aligned(32))) SkewItem {
 __host__ __device__ __forceinline__ uint32_t sk_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // SkewItem::pair of a SLICED batch (SkewArgs::n_slices > 1): [31:26] slices of this pair - 1, [25:20] this item's
-// slice, [19:0] the pair.  The pairs of one batch may be cut into different numbers of slices (the sparse planner cuts
-// by rows, so that a single query's ~n_cus work items are about equally long).
+// slice, [19:0] the pair.  (The slice count travels with the item: a planner may cut pairs unevenly — round 5 measured
+// cutting by rows, no gain, NOTES 10.3 — without touching the kernel.)
 #define SK_MAX_SLICES 64u
 __host__ __device__ __forceinline__ uint32_t sk_pack_pair(uint32_t pair, uint32_t slice, uint32_t n_sl) {
   return pair | (slice << 20) | ((n_sl - 1u) << 26);
@@ -316,11 +316,7 @@ struct PlanArgs {
   // candidate lists cost is selection, and selection work follows the rows admitted.  The price is one
   // extra, un-shared read of ~one partition per query (+13 % L2 fills at C3, HBM is 15 % busy).
   uint32_t best_first;
-  uint32_t n_slices;        // work items per pair (SkewArgs::n_slices); the sparse planner: at most this many
-  // Sparse planner only, n_slices > 1: cut every pair into round(len / target) slices, target = probed rows of the batch /
-  // target_items — about target_items work items of about equal length (0 = n_slices slices for every pair).
-  uint32_t target_items;
-  uint32_t* items_made;     // device counter of the work items the sparse planner made (DevCtl::lat_items), or nullptr
+  uint32_t n_slices;        // work items per pair (SkewArgs::n_slices)
   ActiveMask act;           // device-side batch size: pairs of inactive queries make no item, no slot writes
 };
 
@@ -447,7 +443,7 @@ static __global__ __launch_bounds__(1024) void k_plan_fused(PlanArgs a) {
 //  k_select_plan.  FRESH: the probe lists were written by OTHER workgroups of the same launch — read them at L2.)
 template <bool FRESH>
 __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_key /*[PLAN_SPARSE_MAX_PAIRS]*/, uint32_t* s_xf /*[9]*/,
-                                                 uint32_t* s_q /*[10]*/, uint32_t* s_nsl /*[PLAN_SPARSE_MAX_PAIRS]*/,
+                                                 uint32_t* s_q /*[10]*/,
                                                  const uint32_t* lds_probes = nullptr /*[n_pairs] in LDS: skip the global read*/,
                                                  unsigned long long* stat_rows = nullptr /*+= probed rows of the batch*/) {
   const uint32_t i = threadIdx.x, lane = i & 63u;
@@ -478,44 +474,28 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
     }
   }
   if (i < PLAN_SPARSE_MAX_PAIRS) s_key[i] = key;
-  // slices of this pair: by rows when the batch asks for it (a single query's partitions differ 3 x in length: cut
-  // evenly, the longest slice decided the kernel's time; cut by rows, ~target_items items of about equal length)
-  const bool by_rows = a.target_items && a.n_slices > 1u;
-  if (by_rows || stat_rows) {  // probed rows of the batch: wave sums, one LDS atomic per wave
+  if (stat_rows) {  // probed rows of the batch: wave sums, one LDS atomic per wave
     uint32_t v = key != 0xFFFFFFFFu ? len : 0u;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += (uint32_t)__shfl_xor((int)v, off);
     if (lane == 0 && v) atomicAdd(&s_q[9], v);
     __syncthreads();
-    if (i == 0 && stat_rows && s_q[9]) atomicAdd(stat_rows, (unsigned long long)s_q[9]);
+    if (i == 0 && s_q[9]) atomicAdd(stat_rows, (unsigned long long)s_q[9]);
   }
-  uint32_t n_sl = key != 0xFFFFFFFFu ? a.n_slices : 0u;
-  if (by_rows && key != 0xFFFFFFFFu) {
-    const uint32_t target = max(1u, (s_q[9] + a.target_items - 1u) / a.target_items);
-    const uint32_t unit_tiles = max(1u, ((len + SK_TILE - 1u) / SK_TILE) / SK_STREAMS);  // tile positions of a stream: a slice needs one
-    n_sl = min(min(max(1u, (len + target / 2u) / target), a.n_slices), unit_tiles);
-  }
-  if (i < PLAN_SPARSE_MAX_PAIRS) s_nsl[i] = n_sl;
   // queue x starts behind the items whose place is below its first virtual index
 #pragma unroll
   for (uint32_t x = 0; x < 9; ++x) {
-    const bool below = key != 0xFFFFFFFFu && key < ncls * s_xf[x];
-    if (by_rows) {
-      if (below) atomicAdd(&s_q[x], n_sl);
-    } else {  // the same number of slices for every pair: count lanes
-      const uint64_t m = __ballot(below);
-      if (lane == 0 && m) atomicAdd(&s_q[x], (uint32_t)__popcll((unsigned long long)m) * a.n_slices);
-    }
+    const uint64_t m = __ballot(key != 0xFFFFFFFFu && key < ncls * s_xf[x]);
+    if (lane == 0 && m) atomicAdd(&s_q[x], (uint32_t)__popcll((unsigned long long)m));
   }
   __syncthreads();
   if (key != 0xFFFFFFFFu) {
-    uint32_t start = 0;  // items of the pairs placed before this one
+    uint32_t rank = 0;  // pairs placed before this one
     for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {  // (s_key beyond n_pairs holds 0xFFFFFFFF: never below a real key)
       const uint4 kj = *(const uint4*)&s_key[j0];
-      const uint4 nj = *(const uint4*)&s_nsl[j0];
-      const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w}, nv[4] = {nj.x, nj.y, nj.z, nj.w};
+      const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) start += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? nv[e] : 0u;
+      for (int e = 0; e < 4; ++e) rank += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? 1u : 0u;
     }
     SkewItem it;
     it.part = p;
@@ -523,19 +503,18 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
     it.lrow0 = it_lrow0;
     it.grow0 = it_grow0;
     it.code_off = it_code_off;
-    for (uint32_t sl = 0; sl < n_sl; ++sl) {
-      it.pair = a.n_slices > 1u ? sk_pack_pair(i, sl, n_sl) : i;
-      a.items[(size_t)start + sl] = it;
+    for (uint32_t sl = 0; sl < a.n_slices; ++sl) {
+      it.pair = a.n_slices > 1u ? sk_pack_pair(i, sl, a.n_slices) : i;
+      a.items[(size_t)rank * a.n_slices + sl] = it;
     }
   }
-  if (i < 9) a.q_start[i] = s_q[i];
-  if (i == 8 && a.items_made) atomicAdd(a.items_made, s_q[8]);
+  if (i < 9) a.q_start[i] = s_q[i] * a.n_slices;
   if (i < 8) a.heads[i * SK_HEAD_STRIDE] = 0;
 }
 static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(PlanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
   __shared__ uint32_t s_xf[9], s_q[10];
-  plan_sparse_body<false>(a, s_key, s_xf, s_q, s_nsl);
+  plan_sparse_body<false>(a, s_key, s_xf, s_q);
 }
 
 // ---- latency front, second half: probe selection of every query + the work list, ONE launch ----------------------
@@ -568,7 +547,7 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_and, s_or, s_prefix, s_need, s_less, s_wave_cnt[SELPLAN_NT / 64], s_running, s_best_at, s_eq_all, s_last;
   __shared__ unsigned long long s_best;
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
   __shared__ uint32_t s_xf[9], s_q[10];
   constexpr int NT = SELPLAN_NT, NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -748,11 +727,11 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   const unsigned long long sp_t3 = wall_clock64();
 #endif
   if (!alone && !s_last) return;
-  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q, s_nsl, alone ? s_out : (const uint32_t*)nullptr, a.stat_rows);
+  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q, alone ? s_out : (const uint32_t*)nullptr, a.stat_rows);
 #ifdef MI355_DEV_FRONT
   __syncthreads();
   if (tid == 0 && a.stat_rows) {  // (stat_rows = &DevCtl::rows_scanned, the first member: the counters follow it)
-    uint32_t* dev = (uint32_t*)a.stat_rows + 8;  // rows_scanned(2), short_queries, lat_items, deadline(2), timed_out, bad_probes, dev[0]
+    uint32_t* dev = (uint32_t*)a.stat_rows + 8;  // rows_scanned(2), short_queries, pad, deadline(2), timed_out, bad_probes, dev[0]
     atomicAdd(dev + 4, (uint32_t)(sp_t1 - sp_t0));
     atomicAdd(dev + 5, (uint32_t)(sp_t2 - sp_t1));
     atomicAdd(dev + 6, (uint32_t)(sp_t3 - sp_t2));

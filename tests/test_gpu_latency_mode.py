@@ -38,17 +38,15 @@ def test_sliced_work_items_return_the_unsliced_result(oracle, m, dim):
             _same(ix.search(q, **kw), o.search(q, **kw))
         st = ix.stats()
         pairs = nq * nprobe
-        # a handful of queries: the planner cuts the pairs BY ROWS into about one work item per CU (256; two / three per CU
-        # from 128 / 256 pairs on), at least one per non-empty probed partition and at most 16 per pair
-        assert pairs - 2 * nq <= st["work_items"] <= 16 * pairs, (st["work_items"], pairs)
-        assert st["work_items"] >= min(200, pairs), (st["work_items"], pairs)
+        slices = min(8, -(-768 // pairs)) if pairs < 768 else 1  # up to 3 work items per CU (256 CUs), at most 8 slices per pair
+        assert st["work_items"] == pairs * slices, (st["work_items"], pairs, slices)
     # a batch that fills the chip keeps whole partitions
     q = rng.normal(size=(128, dim)).astype(np.float32)
     _same(ix.search(q, k=10, nprobe_min=8, nprobe_max=8), o.search(q, k=10, nprobe_min=8, nprobe_max=8))
     assert ix.stats()["work_items"] == 128 * 8
-    # in between (512 pairs on 256 CUs): cut by rows into about three work items per CU, so that the longest partition does not decide alone
+    # in between (512 pairs on 256 CUs): two slices per pair, so that the longest partition does not decide alone
     _same(ix.search(q[:64], k=10, nprobe_min=8, nprobe_max=8), o.search(q[:64], k=10, nprobe_min=8, nprobe_max=8))
-    assert 512 - 128 <= ix.stats()["work_items"] <= 512 + 3 * 256
+    assert ix.stats()["work_items"] == 64 * 8 * 2
 
 
 @pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])

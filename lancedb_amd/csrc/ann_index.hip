@@ -525,7 +525,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       if (prof) HIP_TRY(hipEventRecord(es.ev[4], rs));
       // (deferred: MI355_REFINE_SIDE_CUS workgroups in all — the CUs the scans of this handle leave free meanwhile)
       ST_TRY(launch_refine(ix, view, q, n, ann, d_cnt_ann + q0, nullptr, 0, pl.kk, pl.range, exact, rs, act,
-                           defer ? std::max(1u, MI355_REFINE_SIDE_CUS / ((pl.kk + 255u) / 256u)) : 0u));
+                           defer ? std::max(1u, MI355_REFINE_SIDE_CUS * MI355_REFINE_SIDE_WGS_PER_CU / ((pl.kk + 255u) / 256u)) : 0u));
       MergeArgs mr = merge_args_dense(exact, 1, pl.kk, n, pl.k);
       mr.ctl = d_ctl;
       mr.act = act;

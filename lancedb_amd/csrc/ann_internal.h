@@ -126,7 +126,13 @@ static inline uint32_t dev_knob(const char*, uint32_t dflt) { return dflt; }
 #endif
 
 // CUs the scans of a handle leave free while its deferred re-rank (a PCIe gather) runs beside them
+#ifndef MI355_REFINE_SIDE_CUS
 #define MI355_REFINE_SIDE_CUS 16u
+#endif
+// ... and the four-wave workgroups of that re-rank per reserved CU (no LDS, ~80 VGPRs: up to six fit)
+#ifndef MI355_REFINE_SIDE_WGS_PER_CU
+#define MI355_REFINE_SIDE_WGS_PER_CU 1u
+#endif
 
 // top-k selection width: slots per lane of the in-register selector (64 lanes each);
 // k > 256 runs the same selector in several passes (device_common.h, WaveTopK floor)

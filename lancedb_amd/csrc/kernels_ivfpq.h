@@ -1686,7 +1686,10 @@ __device__ __forceinline__ float dist_finish(const DistAcc& a, uint32_t metric, 
   return 1.0f - ieee_divf(a.qv, ieee_sqrtf(qq) * ieee_sqrtf(a.vv));
 }
 
-template <int PIECES = 4>  // 16-B pieces of the row in flight per lane (8 for rows that arrive over PCIe)
+#ifndef MI355_REFINE_SIDE_PIECES
+#define MI355_REFINE_SIDE_PIECES 8  // 16-B pieces in flight per lane of the re-rank that runs beside a scan (rows arrive over PCIe)
+#endif
+template <int PIECES = 4>  // 16-B pieces of the row in flight per lane
 __device__ __forceinline__ float exact_distance(const float* __restrict__ q, const void* raw,
                                                 uint32_t dtype, uint64_t row, uint32_t dim,
                                                 uint32_t metric, float qq) {
@@ -1697,16 +1700,18 @@ __device__ __forceinline__ float exact_distance(const float* __restrict__ q, con
   const unsigned char* p = (const unsigned char*)raw + base * esz;
   if ((dim % per) == 0 && (((size_t)p) & 15u) == 0) {
     const uint32_t n_pieces = dim / per;
-    const uint4* pv = (const uint4*)p;
+    // (ext-vector registers, unconditional loads at a clamped piece: an array of more than eight HIP uint4 structs lives in
+    //  scratch and every load into it is waited for on its own — scripts/check_scratch.py)
+    typedef __attribute__((ext_vector_type(4))) uint32_t ed_u32x4;
+    const ed_u32x4* pv = (const ed_u32x4*)p;
     uint32_t d = 0;
     for (uint32_t i0 = 0; i0 < n_pieces; i0 += PIECES) {
-      uint4 buf[PIECES];
+      ed_u32x4 buf[PIECES];
 #pragma unroll
-      for (int u = 0; u < PIECES; ++u)
-        if (i0 + u < n_pieces) buf[u] = pv[i0 + u];
+      for (int u = 0; u < PIECES; ++u) buf[u] = pv[min(i0 + (uint32_t)u, n_pieces - 1u)];
 #pragma unroll
       for (int u = 0; u < PIECES; ++u) {
-        if (i0 + u >= n_pieces) break;
+        if (i0 + u >= n_pieces) continue;  // (not `break`: an early exit keeps the loop rolled and buf[] in scratch)
         const uint32_t w[4] = {buf[u].x, buf[u].y, buf[u].z, buf[u].w};
         if (dtype == MI355_DTYPE_F32) {
 #pragma unroll
@@ -1808,7 +1813,7 @@ static __global__ __launch_bounds__(256) void k_refine_dist(RefineArgs a) {
         const Cand in = a.in[(size_t)b * a.kk + c];
         if (in.pos != CAND_EMPTY_POS && in.pos < a.n_rows) {
           const uint64_t rrow = a.ix.raw_by_global ? global_pos_of(a.ix, in.pos) : (uint64_t)in.pos;
-          const float d = exact_distance<SIDE ? 8 : 4>(sq, a.ix.raw, a.ix.raw_dtype, rrow, a.ix.dim, a.ix.metric, qq);
+          const float d = exact_distance<SIDE ? MI355_REFINE_SIDE_PIECES : 4>(sq, a.ix.raw, a.ix.raw_dtype, rrow, a.ix.dim, a.ix.metric, qq);
           if (in_range(d, a.range)) {
             o.d = d;
             o.pos = in.pos;

@@ -1042,7 +1042,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         };
         // (measured and not kept, round 5: a two-set software pipeline of these rounds — 27.7 -> 46.5 ms per C3 launch, the
         //  second register set spills under the 128-VGPR cap; 12 / 16 / 24 pieces in flight per thread instead of 8:
-        //  -0.7 / -3.5 / -9 % QPS.  The build streams 786 KB of codebook per table from L2; profiles/r05_lut_build_ab.txt)
+        //  -0.7 / -3.5 / -9 % QPS; entry indices carried incrementally ((code, column) += (NT / M, NT % M), scalar base +
+        //  32-bit offsets) instead of e / M, e % M and 64-bit address adds: -1.3 %.  The build streams 786 KB of codebook
+        //  per table from L2 and is not bound by its instruction count; profiles/r05_lut_build_ab.txt)
         for (uint32_t e0 = tid; e0 < TOTAL; e0 += EPR * NT) {
           sk_f32x4 cv4[EPR][V];
           bool ok[EPR];

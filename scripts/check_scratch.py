@@ -15,8 +15,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# kernels known to keep a little scratch for reasons other than staged loads (checked by hand, not on a hot path)
-ALLOW = ()
+# kernels known to keep a little scratch for reasons other than staged loads (checked by hand in the disassembly):
+#   k_scan_skew   register spills at the 128-VGPR cap of a 16-wave workgroup; stores in the item prologue, reloads in the
+#                 table build and the merge, none in the scan loop (NOTES.md 10.3)
+#   k_flat_gemm<  12 bytes in the two-barrier kernel's prologue
+ALLOW = ("k_scan_skew", "11k_flat_gemmILi")
 
 
 def unit_report(src):

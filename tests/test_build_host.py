@@ -229,3 +229,18 @@ def test_coalescing_queue_under_thread_sanitizer(tmp_path):
     r = subprocess.run([exe, "48", "300"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout + r.stderr)[-3000:]
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_latency_path_kernels_use_no_scratch():
+    """Round 5: register arrays of HIP `float4` / `uint4` structs (a dozen elements or more), and arrays indexed in a loop with an
+    early exit, are placed in SCRATCH by hipcc and every global load that fills them is then waited for on its own — the
+    latency path's coarse kernel spent 16 of its 27 us in 24 serial HBM round trips that way.  scripts/check_scratch.py
+    compiles a translation unit's device code and lists the kernels with a private segment; the search pipeline's unit
+    (coarse, select, plan, merge, refine kernels) must have none."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_scratch.py"),
+                        os.path.join(root, "lancedb_amd", "csrc", "ann_index.hip")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert "outside the allow-list: 0" in r.stdout

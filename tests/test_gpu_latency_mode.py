@@ -146,3 +146,35 @@ def test_latency_front_serves_concurrent_shapes_back_to_back(oracle):
         q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.5, size=(nq, dim))).astype(np.float32)
         kw = dict(k=10, nprobe_min=32, nprobe_max=32)
         _same(ix.search(q, **kw), o.search(q, **kw))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_latency_front_random_shapes_against_the_oracle(oracle, seed):
+    """Seeded random shapes across the latency front's branches: 4 / 8 / 16 lanes per centroid (nlist 8192 / ~4096 / small), centroid
+    counts that do not fill the last workgroup, one to eight queries (the single host query rides in the kernel's argument block when
+    dim <= 896, otherwise through the staging copy), nprobe from 1 to nlist (more than 512 pairs falls back to the general planner),
+    all three metrics, refine and ranges — every result is the oracle's, bit for bit."""
+    rng = np.random.default_rng(7000 + seed)
+    nlist = int(rng.choice([2, 3, 17, 64, 100, 511, 1024, 2049, 4096, 8192]))
+    dsub = int(rng.choice([1, 2, 4, 8, 16]))
+    m = int(rng.choice([4, 8, 12, 24, 32, 48, 96]))
+    dim = m * dsub
+    if dim % 4:
+        dim, dsub = m * 4, 4
+    if dim > 1536:
+        m, dim = 96, 96 * dsub
+    metric = ["l2", "cosine", "dot"][seed % 3]
+    n = int(max(3000, min(60_000, nlist * int(rng.integers(2, 12)))))
+    s = train.synthetic_index(n, dim, nlist, m, seed=seed, skew=0.7, empty_parts=min(2, nlist // 4))
+    raw = rng.normal(size=(n, dim)).astype(np.float32)
+    g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw, metric=metric)
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw, metric=metric)
+    g.configure(graph=False, coalesce=False)
+    for nq in (1, int(rng.integers(2, 9)), 8):
+        q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.4, size=(nq, dim))).astype(np.float32)
+        for nprobe in sorted({1, min(nlist, int(rng.integers(1, 80))), min(nlist, 64), nlist if nlist <= 128 else 100}):
+            k = int(rng.choice([1, 10, 33]))
+            kw = dict(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
+            _same(g.search(q, **kw), o.search(q, **kw))
+        kw = dict(k=10, nprobe_min=min(nlist, 8), nprobe_max=min(nlist, 8), refine_factor=5)
+        _same(g.search(q, **kw), o.search(q, **kw))

@@ -121,6 +121,8 @@ def main_flat(a):
 
 def main():
     a = parse()
+    import bench_legs
+    bench_legs.claim_stdout()  # stdout carries the ONE JSON line; everything else this process prints goes to stderr
     if a.workload == "flat":
         return main_flat(a)
     import numpy as np

@@ -639,6 +639,18 @@ def summary_of(result):
 
 
 LINE_LIMIT = 4096  # the driver's parser lost round 4's 29.7 KB line (BENCH_r04.parsed = null): the final line stays under this
+_REAL_STDOUT = None  # claim_stdout(): the process's original stdout, kept for the ONE JSON line
+
+
+def claim_stdout():
+    """Keep the real stdout for the final line only: file descriptor 1 is pointed at stderr for the rest of the run, so that
+    nothing else — RCCL's version banner (C stdio: buffered when stdout is a pipe and flushed at EXIT, i.e. after the JSON
+    line), torch or ROCm notices — can land on the stream the driver parses."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
 
 
 def _short(x, n):
@@ -712,4 +724,4 @@ def emit(result, root=None):
             print(f"bench: could not write {path}: {e}", file=sys.stderr)
     s = json.dumps(compact_line(result))
     assert len(s) < LINE_LIMIT, len(s)
-    print(s, flush=True)
+    print(s, file=_REAL_STDOUT or sys.stdout, flush=True)

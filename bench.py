@@ -101,6 +101,8 @@ def parse():
                          "gather of nprobe (partition, distance) pairs per query per rank) — the C4 mode")
     ap.add_argument("--batch-per-gpu", type=int, default=0,
                     help="N > 1: queries per step = this x N (the batch grows with the ranks) instead of --batch")
+    ap.add_argument("--default-shape-rows", type=int, default=100_000_000,
+                    help="rows of the leg at the reference's DEFAULT index shape (rows / 8192 partitions, m = dim / 16, nprobes 20 and 64); 0 = skip")
     ap.add_argument("--widths", type=int, default=1, help="secondary lines at the reference's default PQ widths m = dim / 16 (384-d, 3072-d); 0 = skip")
     ap.add_argument("--gist-rows", type=int, default=1_000_000, help="rows of the GIST1M-shaped recall@1 / latency line; 0 = skip")
     ap.add_argument("--c5-hugepages", type=int, default=0, help="back the C5 host column with MADV_HUGEPAGE memory (A/B of the PCIe gather)")
@@ -383,6 +385,8 @@ def main():
         torch.cuda.empty_cache()
         if a.c4_rows > 0:
             result["secondary"]["c4"] = legs.c4_leg(a, torch, np, dev, n_rows=a.c4_rows, world=a.loopback_world)
+        if a.default_shape_rows > 0:
+            result["secondary"]["default_shape"] = legs.default_shape_leg(a, torch, np, dev, n_rows=a.default_shape_rows)
         if a.widths:
             result["secondary"].update(legs.width_lines(a, torch, np, dev, n_rows=a.n_rows))
         if a.gist_rows > 0:

@@ -346,6 +346,94 @@ def c4_leg(a, torch, np, dev, n_rows=1_000_000_000, world=8, parity_queries=64):
     return res
 
 
+# ------------------------------------------------------------------ the reference's DEFAULT index shape ----
+def default_shape_leg(a, torch, np, dev, n_rows=100_000_000, dim=768, parity_queries=64):
+    """The index a LanceDB user gets without setting anything: num_partitions = rows / 8192 (rust/lancedb/src/table/create_index.rs:
+    741-794: 12 207 for 100 M rows), num_sub_vectors = dim / 16 (index/vector.rs:306-319: 48 for 768-d), and a query with the default
+    nprobes = 20 (query.rs:1097-1114); the same index at nprobes = 64 beside it.  Partitions of ~8 k rows x 48 code bytes make a work
+    item of 393 KB: the PQ distance table of the item, not its code stream, used to decide (in-item build: 786 KB of codebook per
+    table) — round 6 builds the tables of a batch with one batch-level kernel that keeps the codebook in registers
+    (csrc/kernels_lut.h); `in_item_tables` is the same run with that switched off (MI355_CFG_LUT_INLINE), ids and distances equal.
+    Section-8d bytes = 48 per scanned row; roofline fractions for the scan kernel alone and for tables + scan."""
+    import lancedb_amd
+    from lancedb_amd import _abi
+    nlist, m, k, B = max(1, n_rows // 8192), dim // 16, a.k, a.batch
+    free, _ = torch.cuda.mem_get_info(dev)
+    n = n_rows
+    while n * (m + 8) * 2.2 + (12 << 30) > free and n > 10_000_000:
+        n //= 2
+    nlist = max(1, n // 8192)
+    s = synth_ivfpq(torch, np, dev, n, dim, nlist, m, a.skew, seed=SEED + 6)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric="l2",
+                                codes_layout=_abi.CODES_PART_TRANSPOSED)
+    qpool = query_pool(torch, s, nlist, dim, B, 3)
+    outb = out_buffers(torch, dev, B, k)
+    ix.set_stream(torch.cuda.current_stream().cuda_stream)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    steps = max(4, a.steps // 2)
+    res = {"config": {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "batch_queries": B, "k": k, "partition_rows_median": int(np.median(s["lens"])),
+                      "partition_rows_max": int(s["lens"].max()), "table_image_bytes_per_pair": 256 * m * 4,
+                      "codebook_bytes_per_in_item_build": 256 * dim * 4}}
+    for nprobe in (20, 64):
+        params = _abi.make_params(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
+        legs = {}
+        for name, inline in (("table_images", False), ("in_item_tables", True)):
+            ix.configure(profile=0, lut_inline=inline)
+            dt, st, last = timed_steps(torch, ix, qpool, params, outb, steps)
+            line = scan_line(st, steps, B, dt, n_cus)
+            us_plan = st["us_plan"] / steps
+            by = st["code_bytes_scanned"] / steps
+            line["stage_us_per_step"]["plan_and_tables"] = us_plan
+            line["lut_images"] = st["lut_images"]
+            line["roofline"]["frac_tables_plus_scan"] = by / max(line["roofline"]["us_per_launch"] + us_plan, 1e-9) / 1e3 / HBM_PEAK_GBS
+            line["tables_share_of_tables_plus_scan"] = us_plan / max(us_plan + line["roofline"]["us_per_launch"], 1e-9)
+            line["rowid_checksum"] = int(torch.as_tensor(last.rowids).to(torch.int64).sum().item())
+            line["distance_checksum"] = float(torch.as_tensor(last.distances).double().sum().item())
+            legs[name] = line
+        ix.configure(profile=0, lut_inline=False)
+        ti, ii = legs["table_images"], legs["in_item_tables"]
+        ent = {**ti, "workload": f"ivfpq_{n}x{dim}_nlist{nlist}_m{m}x8_nprobe{nprobe}_k{k}_l2",
+               "in_item_tables": {"value": ii["value"], "stage_us_per_step": ii["stage_us_per_step"], "roofline_frac": ii["roofline"]["frac"]},
+               "speedup_over_in_item_tables": ti["value"] / ii["value"],
+               "both_paths_return_the_same_bits": ti["rowid_checksum"] == ii["rowid_checksum"] and ti["distance_checksum"] == ii["distance_checksum"],
+               "roofline_qps_at_8tbs": HBM_PEAK_GBS * 1e9 / (ti["roofline"]["algorithmic_bytes_per_launch"] / B)}
+        res[f"nprobe{nprobe}"] = ent
+    # ---- CPU-oracle parity sample (nprobes 20) on a host copy of the partitions the sample probes
+    if a.cpu_seconds > 0 and parity_queries:
+        from oracle import oracle as orc
+        orc.build()
+        nq = min(parity_queries, B)
+        nprobe = 20
+        params = _abi.make_params(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
+        q_dev = qpool[0][:nq].contiguous()
+        pr, _, _ = ix.coarse_topn(q_dev, nprobe)
+        ix.sync()
+        parts = np.unique(pr.cpu().numpy().astype(np.int64).reshape(-1))
+        parts = parts[(parts >= 0) & (parts < nlist)]
+        red_po, h_codes, h_ids = _reduced_host_index(torch, np, s, parts, m)
+        ox = orc.OracleIndex(s["centroids"].cpu().numpy(), s["codebook"].cpu().numpy(), red_po, h_codes, h_ids, metric="l2",
+                             codes_layout=1, borrow=True)
+        t1 = time.perf_counter()
+        o_ids, o_dist, o_cnt, _ = ox.search(q_dev.cpu().numpy(), params)
+        t_cpu = time.perf_counter() - t1
+        got = ix.search(q_dev, params)
+        torch.cuda.synchronize()
+        eng_rows = ix.stats()["vectors_scanned"]
+        res["cpu_baseline"] = {
+            "value": nq / t_cpu, "unit": "queries/s", "cores": host_cores()["usable"], "kind": "port",
+            "sample": f"{nq} queries at nprobes 20, one per thread, {t_cpu:.1f} s, on a host copy of the {len(parts)} partitions they probe",
+            "parity": {"queries": nq, "rowids_bit_exact": bool((got.rowids.cpu().numpy().astype(np.uint64) == o_ids).all()),
+                       "distances_equal": bool((got.distances.cpu().numpy() == o_dist).all()),
+                       "counts_equal": bool((got.counts.cpu().numpy().astype(np.uint32) == o_cnt).all()),
+                       "oracle_probed_only_copied_partitions": bool(int(eng_rows) == int(ox.last_vectors_scanned))}}
+        ox.close()
+        del h_codes, h_ids
+    ix.close()
+    del ix, s
+    torch.cuda.empty_cache()
+    return res
+
+
 # -------------------------------------------------------------------- the reference's default PQ widths ----
 def width_lines(a, torch, np, dev, shapes=((384, 24, 8), (3072, 192, 8), (768, 96, 4)), n_rows=100_000_000):
     """`suggested_num_sub_vectors` (rust/lancedb/src/index/vector.rs:306-319) gives m = dim / 16: 24 for 384-d, 192 for
@@ -624,6 +712,15 @@ def summary_of(result):
          "trained_index_rows": v(result, "recall_at_10", "n_rows"),
          "trained_qps_rf0": v(result, "recall_at_10", "nprobe64_queries_per_s"), "trained_qps_rf10": v(result, "recall_at_10", "nprobe64_refine10_queries_per_s"),
          "trained_qps_rf25": v(result, "recall_at_10", "nprobe64_refine25_queries_per_s"), "recall10_rf10": v(result, "recall_at_10", "nprobe64_refine10")}
+    # the reference's DEFAULT index shape (rows / 8192 partitions, m = dim / 16) at its default nprobes 20, and at 64
+    for np_ in (20, 64):
+        d = sec.get("default_shape", {}).get(f"nprobe{np_}")
+        if d:
+            s[f"dflt_np{np_}"] = {"qps": round(d["value"]), "frac": v(d, "roofline", "frac"), "frac_tables_scan": v(d, "roofline", "frac_tables_plus_scan"),
+                                  "lds_gather": v(d, "roofline", "lds_gather_frac"), "tables_share": v(d, "tables_share_of_tables_plus_scan"),
+                                  "x_in_item": v(d, "speedup_over_in_item_tables"), "same_bits": v(d, "both_paths_return_the_same_bits")}
+    if "default_shape" in sec:
+        s["dflt_parity_ids"] = v(sec, "default_shape", "cpu_baseline", "parity", "rowids_bit_exact")
     cc = sec.get("concurrent_callers_c3", {})
     s["callers_qps"] = {k2.replace("_threads", ""): round(v2["queries_per_s"]) for k2, v2 in cc.items()}
     for key, line in sec.items():

@@ -224,7 +224,7 @@ typedef struct mi355_stats {
   uint64_t work_items;         /* scan work items launched */
   float us_coarse;             /* per-stage device time; 0 unless profiling on */
   float us_select;
-  float us_plan;
+  float us_plan;               /* between probe selection and the scan kernel: work list + table images */
   float us_scan;
   float us_merge;
   float us_refine;
@@ -236,7 +236,8 @@ typedef struct mi355_stats {
                                   index (they are skipped; host-I/O calls also fail with InvalidInput) */
   uint32_t coalesced_calls;    /* concurrent host-I/O mi355_search calls served by the last device batch */
   uint32_t graph_replays;      /* searches of this handle served by a cached hipGraph so far */
-  uint32_t reserved;
+  uint32_t lut_images;         /* 1 = the distance tables of the last search came from the batch-level table
+                                  kernel (us_plan holds its time), 0 = every work item built its own */
 } mi355_stats;
 
 enum {
@@ -268,7 +269,13 @@ enum {
      handle, which all join the pending re-rank first); the caller keeps the query and output buffers
      untouched until then.  Off after open: without it every device-I/O result is ordered on the
      handle's stream. */
-  MI355_CFG_DEFER_REFINE = 0x400u
+  MI355_CFG_DEFER_REFINE = 0x400u,
+  /* opt-out: build every PQ distance table inside its scan work item.  By default an index whose sub-vectors are 16
+     floats long (num_sub_vectors = dim / 16, the reference's default: rust/lancedb/src/index/vector.rs:306-319) gets the
+     tables of a whole batch from one batch-level kernel that keeps the codebook in registers (k * refine_factor <= 128;
+     up to 8 GiB of table images in HBM per batch chunk, falling back to in-item builds when HBM is full).  Results are
+     bit-identical either way (same operations in the same order); the bit is for A/B measurements and tests. */
+  MI355_CFG_LUT_INLINE = 0x800u
 };
 
 /* ---- library ------------------------------------------------------------ */

@@ -6,7 +6,7 @@
 #![allow(non_camel_case_types, non_upper_case_globals, dead_code)]
 use core::ffi::{c_char, c_void};
 
-// ---- constants (47)
+// ---- constants (48)
 pub const MI355_ANN_ABI_VERSION: u32 = 5;
 pub const MI355_COMM_ID_BYTES: usize = 128;
 pub const MI355_MAX_RANKS: usize = 64;
@@ -43,6 +43,7 @@ pub const MI355_PROFILE_MASK: u32 = 255;
 pub const MI355_CFG_GRAPH: u32 = 256;
 pub const MI355_CFG_COALESCE: u32 = 512;
 pub const MI355_CFG_DEFER_REFINE: u32 = 1024;
+pub const MI355_CFG_LUT_INLINE: u32 = 2048;
 pub const MI355_FLAT_GEMM_AUTO: u32 = 0;
 pub const MI355_FLAT_GEMM_128: u32 = 1;
 pub const MI355_FLAT_GEMM_256: u32 = 2;
@@ -151,7 +152,7 @@ pub struct mi355_stats {
     pub bad_probes: u32,
     pub coalesced_calls: u32,
     pub graph_replays: u32,
-    pub reserved: u32,
+    pub lut_images: u32,
 }
 #[repr(C)]
 #[derive(Clone, Copy)]

@@ -51,6 +51,7 @@ PROFILE_MASK = 0xFF
 CFG_GRAPH = 0x100
 CFG_COALESCE = 0x200
 CFG_DEFER_REFINE = 0x400
+CFG_LUT_INLINE = 0x800
 
 FLAT_GEMM_AUTO = 0
 FLAT_GEMM_128 = 1
@@ -195,7 +196,7 @@ class Stats(C.Structure):
         ("bad_probes", C.c_uint32),
         ("coalesced_calls", C.c_uint32),
         ("graph_replays", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("lut_images", C.c_uint32),
     ]
 
 

@@ -23,9 +23,15 @@ int32_t drain_events(mi355_index* ix, bool discard) {
         HIP_TRY(hipEventElapsedTime(&ms, es.ev[i], es.ev[i + 1]));
         us[i] = ms * 1000.f;
       }
+      // ev[6] sits between the planner (+ the batch's distance-table images) and the scan kernel: us_scan is the scan
+      // kernel's own time, us_plan what ran between the probe selection and it
+      float ms_plan = 0;
+      HIP_TRY(hipEventElapsedTime(&ms_plan, es.ev[2], es.ev[6]));
+      const float us_plan = std::min(ms_plan * 1000.f, us[2]);
       ix->stats.us_coarse += us[0];
       ix->stats.us_select += us[1];
-      ix->stats.us_scan += us[2];
+      ix->stats.us_plan += us_plan;
+      ix->stats.us_scan += us[2] - us_plan;
       ix->stats.us_merge += us[3];
       ix->stats.us_refine += us[4];
       ix->stats.us_total += us[0] + us[1] + us[2] + us[3] + us[4];
@@ -201,6 +207,10 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       sk_slices = (uint32_t)std::min<uint64_t>(dev_knob("MI355_LAT_SLICES_MAX", 8), (3ull * ix->n_cus + pairs - 1) / pairs);
     sk_slices = std::max(1u, std::min(sk_slices, ix->max_len / 2048u));
     if (pl.kk > 256u) sk_slices = 1;  // (multi-pass selection re-scans per pass: keep whole partitions)
+    // a sliced item's `pair` word is [6 bits slices - 1][6 bits slice][20 bits pair] (sk_pack_pair): whatever the knobs and
+    // the CU count say, never more slices or pairs than the fields hold
+    sk_slices = std::min(sk_slices, SK_MAX_SLICES);
+    if (sk_slices > 1 && pairs >= (1ull << 20)) sk_slices = 1;
   }
   const uint32_t n_slices = skew ? sk_slices : std::max(1u, (ix->max_len + slice - 1) / slice);
 
@@ -210,6 +220,25 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   const size_t budget = (size_t)(pl.ws_mb ? pl.ws_mb : dev_knob("MI355_WORKSPACE_MB", 2048)) << 20;
   uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / std::max<size_t>(per_q, 1)));
   chunk = std::min(chunk, 65535u);  // grid.z limit
+  // Distance tables of the whole chunk by the batch-level kernels (kernels_lut.h) instead of one build per work item: where
+  // the shape qualifies (dsub 16: the reference's m = dim / 16), for candidate lists the image kernels are instantiated
+  // for, and not for a maximum_nprobes second pass (device-side batch size: its slots are mostly inactive).  The images
+  // get their own budget (4 * M bytes per code row and pair: 48 KiB at m = 48); if they cannot be allocated the work
+  // items build their tables as before.
+  bool lut_img = skew && ix->lut_img_ok && !ix->lut_inline_cfg && pl.kk <= 128u && !pl.act.n && dev_knob("MI355_LUT_IMAGES", 1);
+  if (lut_img) {
+    const size_t per_q_img = (size_t)nprobe * (lut_image_bytes_per_pair(ix) + lut_residual_bytes_per_pair(ix));
+    const size_t img_budget = (size_t)dev_knob("MI355_LUT_IMAGES_MB", 8192) << 20;
+    const uint32_t chunk_img = (uint32_t)std::max<size_t>(1, img_budget / std::max<size_t>(per_q_img, 1));
+    const uint32_t c2 = std::min(chunk, chunk_img);
+    if (ix->w_lutimg.ensure((size_t)c2 * nprobe * lut_image_bytes_per_pair(ix)) != MI355_OK ||
+        ix->w_lutres.ensure((size_t)c2 * nprobe * lut_residual_bytes_per_pair(ix)) != MI355_OK) {
+      (void)hipGetLastError();
+      lut_img = false;  // (HBM is full: no images; the failed buffer is empty again)
+    } else {
+      chunk = c2;
+    }
+  }
   if (skew) {
     ST_TRY(ix->items.ensure(sizeof(SkewItem) * (size_t)chunk * nprobe * n_slices));
     ST_TRY(ix->qthr.ensure(sizeof(uint32_t) * chunk));
@@ -409,6 +438,10 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
         hipLaunchKernelGGL(k_plan_fill, dim3(pb), dim3(256), 0, st, pa);
       }
       HIP_TRY(hipGetLastError());
+      if (lut_img)
+        ST_TRY(launch_lut_images(ix, ix->w_qp.as<float>(), ix->items.as<SkewItem>(), ix->q_start.as<uint32_t>(), pa.n_pairs, n_slices, nprobe,
+                                 ix->w_lutres.as<float>(), ix->w_lutimg.as<float>(), st));
+      if (prof) HIP_TRY(hipEventRecord(es.ev[6], st));
       SkewArgs ka;
       ka.ix = view;
       ka.cbT = ix->cbT.as<float>();
@@ -432,7 +465,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       const uint32_t scan_cus = (pl.defer_refine && ix->n_cus > 4 * MI355_REFINE_SIDE_CUS) ? ix->n_cus - MI355_REFINE_SIDE_CUS : ix->n_cus;
       uint32_t n_blocks = std::max(1u, (uint32_t)std::min<uint64_t>(scan_cus, (uint64_t)n * nprobe * n_slices));
       ka.n_slabs = ix->sk_slabs;
-      ka.res_floats = ix->sk_res_floats;
+      ka.res_floats = lut_img ? 0u : ix->sk_res_floats;  // (image kernels keep no residual in LDS)
+      ka.lut_img = lut_img ? ix->w_lutimg.as<float>() : nullptr;
       ka.partial = nullptr;
       ka.partial_stride = 0;
       if (ix->sk_slabs > 1) {
@@ -446,8 +480,12 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
         ka.partial = ix->w_partial.as<float2>();
         ka.partial_stride = (uint32_t)stride;
       }
-      ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
+      if (lut_img)
+        ST_TRY(launch_scan_skew_img(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
+      else
+        ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
     } else {
+      if (prof) HIP_TRY(hipEventRecord(es.ev[6], st));
       ScanArgs sa;
       sa.ix = view;
       sa.qp = ix->w_qp.as<float>();
@@ -553,6 +591,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     }
   }
   ix->stats.work_items += (uint64_t)nq * nprobe * n_slices;
+  ix->stats.lut_images = lut_img ? 1u : 0u;
   return MI355_OK;
 }
 

@@ -154,7 +154,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
                     &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt,
-                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b};
+                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b,    &ix->w_lutres, &ix->w_lutimg};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)
@@ -193,7 +193,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
   const uint32_t nlist = d->nlist, m = d->m, mb = ix->mb, cb_entries = 1u << d->nbits;
   for (DevBuf* b : {&ix->w_q, &ix->w_qp, &ix->w_qq, &ix->w_coarse, &ix->w_probes, &ix->w_cand, &ix->w_ids, &ix->w_dist,
                     &ix->w_pos, &ix->w_cnt, &ix->w_ids2, &ix->w_dist2, &ix->w_cnt2, &ix->w_cand2, &ix->items, &ix->qthr, &ix->w_ccnt,
-                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial, &ix->w_cand2b, &ix->w_cnt2b})
+                    &ix->w_filter, &ix->w_probes64, &ix->w_spill, &ix->w_partial, &ix->w_cand2b, &ix->w_cnt2b, &ix->w_lutres, &ix->w_lutimg})
     b->gen = &ix->ws_gen;  // a re-allocation of any of these invalidates the cached hipGraphs
 
   // -- ownership + local layout
@@ -230,6 +230,7 @@ static int32_t index_open_impl(const mi355_index_desc* d, mi355_index* ix) {
     }
   }
   const bool skew = ix->layout == MI355_SCAN_SKEW;
+  ix->lut_img_ok = lut_images_shape_ok(ix);  // batch-level distance tables (kernels_lut.h) for this shape
   const bool local_arrays = (d->flags & MI355_INDEX_LOCAL_ARRAYS) != 0;
   for (uint32_t p = 0; p < nlist; ++p) {
     uint64_t len = d->part_offsets[p + 1] - d->part_offsets[p];
@@ -530,7 +531,7 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   if (!ix) return fail(MI355_ERR_INVALID_INPUT, "index is NULL");
   if (scan_variant > MI355_SCAN_SKEW) return fail(MI355_ERR_INVALID_INPUT, "unknown scan variant");
   if ((profile & MI355_PROFILE_MASK) > 2 ||
-      (profile & ~(uint32_t)(MI355_PROFILE_MASK | MI355_CFG_GRAPH | MI355_CFG_COALESCE | MI355_CFG_DEFER_REFINE)))
+      (profile & ~(uint32_t)(MI355_PROFILE_MASK | MI355_CFG_GRAPH | MI355_CFG_COALESCE | MI355_CFG_DEFER_REFINE | MI355_CFG_LUT_INLINE)))
     return fail(MI355_ERR_INVALID_INPUT, "unknown profile / mode bits 0x%x", profile);
   if (scan_variant != MI355_SCAN_AUTO && scan_variant != ix->layout)
     return fail(MI355_ERR_INVALID_INPUT,
@@ -543,6 +544,9 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ST_TRY(drain_events(ix, true));
   HIP_TRY(hipMemset(ix->w_ctl.p, 0, sizeof(DevCtl)));
+  // the ticket word of k_select_plan resets itself in the launch's last workgroup; a launch that never got there (aborted)
+  // must not leave later calls reading a stale work list: every configure() starts from zero
+  if (ix->heads.p) HIP_TRY(hipMemset(ix->heads.as<uint32_t>() + 8 * SK_HEAD_STRIDE, 0, sizeof(uint32_t)));
   reset_stats(ix);
   ix->scan_variant = scan_variant;
   ix->slice_rows = (slice_rows + 15u) & ~15u;
@@ -550,6 +554,7 @@ extern "C" int32_t mi355_index_configure(mi355_index* ix, uint32_t scan_variant,
   ix->use_graph = (profile & MI355_CFG_GRAPH) != 0;
   ix->coalesce.store((profile & MI355_CFG_COALESCE) != 0, std::memory_order_relaxed);
   ix->defer_cfg = (profile & MI355_CFG_DEFER_REFINE) != 0;
+  ix->lut_inline_cfg = (profile & MI355_CFG_LUT_INLINE) != 0;
   ++ix->ws_gen;  // captured graphs bake in the slicing
   return MI355_OK;
 } MI355_ABI_GUARD("mi355_index_configure")

@@ -11,13 +11,16 @@
 
 // ---- one call's launch sequence: control word, deadline, pipeline -------------------------------
 // (everything here is stream work with stable arguments, so it can be captured in a hipGraph)
+// `arm` = false: the control word was armed by the caller (graph replays arm it eagerly: the budget left differs from call to
+// call — it shrinks by the time spent in the queue — and must not be baked into a captured graph)
 static int32_t launch_sequence(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPlan& pl, uint64_t* d_ids,
-                               float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann, uint32_t timeout_ms) {
+                               float* d_dist, uint32_t* d_cnt, uint32_t* d_cnt_ann, uint32_t timeout_ms, bool arm = true) {
   hipStream_t st = ix->stream;
   DevCtl* ctl = ix->w_ctl.as<DevCtl>();
   // (profile 2 = cumulative: the row counter runs until the next configure())
   const unsigned long long ticks = (unsigned long long)timeout_ms * ix->wall_khz;
   const uint32_t reset = (ix->profile & MI355_PROFILE_MASK) != 2 ? 1u : 0u;
+  if (!arm) return run_ivfpq(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann);
   if (lat_front_applies(ix, nq, pl)) {  // a handful of queries: the pipeline's first kernel arms the word (one launch less)
     SearchPlan pl2 = pl;
     pl2.arm_in_front = true;
@@ -46,9 +49,16 @@ static int32_t run_graphed(mi355_index* ix, const float* d_q, uint32_t nq, const
   GraphKey key{nq, pl.k, pl.kk, pl.nprobe,
                (pl.refine ? 1u : 0u) | (pl.range.has_lower ? 2u : 0u) | (pl.range.has_upper ? 4u : 0u)};
   GraphEntry& e = ix->graphs[key];
-  const bool same = e.lower == pl.range.lower && e.upper == pl.range.upper && e.timeout_ms == timeout_ms &&
-                    e.d_q == d_q && e.d_ids == d_ids;
+  const bool same = e.lower == pl.range.lower && e.upper == pl.range.upper && e.d_q == d_q && e.d_ids == d_ids;
+  // the deadline is armed eagerly, in front of the replayed (or captured) sequence
+  auto arm_now = [&]() -> int32_t {
+    hipLaunchKernelGGL(k_arm_deadline, dim3(1), dim3(1), 0, ix->stream, ix->w_ctl.as<DevCtl>(),
+                       (unsigned long long)timeout_ms * ix->wall_khz, (ix->profile & MI355_PROFILE_MASK) != 2 ? 1u : 0u);
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+  };
   if (e.exec && e.gen == ix->ws_gen && same) {
+    ST_TRY(arm_now());
     HIP_TRY(hipGraphLaunch(e.exec, ix->stream));
     ix->stats.work_items += e.work_items;
     ix->stats.graph_replays += 1;
@@ -64,13 +74,14 @@ static int32_t run_graphed(mi355_index* ix, const float* d_q, uint32_t nq, const
     return launch_sequence(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann, timeout_ms);
   }
   hipGraph_t graph = nullptr;
+  ST_TRY(arm_now());
   if (hipStreamBeginCapture(ix->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
     e.failed = true;
     return launch_sequence(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann, timeout_ms);
   }
   const uint64_t wi0 = ix->stats.work_items;
-  const int32_t s = launch_sequence(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann, timeout_ms);
+  const int32_t s = launch_sequence(ix, d_q, nq, pl, d_ids, d_dist, d_cnt, d_cnt_ann, timeout_ms, /*arm=*/false);
   e.work_items = ix->stats.work_items - wi0;
   const hipError_t ce = hipStreamEndCapture(ix->stream, &graph);
   if (s != MI355_OK || ce != hipSuccess || !graph ||
@@ -86,7 +97,6 @@ static int32_t run_graphed(mi355_index* ix, const float* d_q, uint32_t nq, const
   e.gen = ix->ws_gen;
   e.lower = pl.range.lower;
   e.upper = pl.range.upper;
-  e.timeout_ms = timeout_ms;
   e.d_q = d_q;
   e.d_ids = d_ids;
   HIP_TRY(hipGraphLaunch(e.exec, ix->stream));
@@ -215,8 +225,12 @@ int32_t join_exchange(mi355_index* ix) {
 
 // The device work of one submission (ix->mu held): `calls` share `p`; host-I/O callers are packed
 // into one device batch (the coalescing queue hands over several), device I/O is exactly one call.
-static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& calls, const mi355_search_params* p,
-                             const SearchShape& sh, const uint64_t* ext_probes, uint32_t ext_nprobe) {
+// `per_call` (coalesced batches): the outcome of every call of `all_calls` — MI355_OK, or MI355_ERR_TIMEOUT for a call whose
+// OWN budget (QueryExecutionOptions.timeout is per query, rust/lancedb/src/query.rs:641) was spent before the device was reached
+// or had passed when the batch completed; the return value is calls[0]'s, or a failure of the whole batch.
+static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& all_calls, const mi355_search_params* p,
+                             const SearchShape& sh, const uint64_t* ext_probes, uint32_t ext_nprobe,
+                             std::vector<int32_t>* per_call = nullptr) {
   HIP_TRY(hipSetDevice(ix->device));
   (void)hipGetLastError();  // the launch checks below must report THIS call's errors, not what another HIP user of the thread left
   const bool host_io = p->io_mem == MI355_MEM_HOST;
@@ -225,19 +239,38 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
   // untouched until then, as for any device-I/O call): the NEXT call's scan starts at once.  With a host-mapped raw
   // column (C5) the re-rank is a PCIe gather, the scan an LDS / VALU loop: the two overlap almost entirely.
   const bool defer = !host_io && p->refine_factor != 0 && p->timeout_ms == 0 && sh.np_max == sh.np_min && !ext_probes &&
-                     (ix->profile & MI355_PROFILE_MASK) != 1 && calls.size() == 1 && ix->raw_is_host && ix->defer_cfg;
+                     (ix->profile & MI355_PROFILE_MASK) != 1 && all_calls.size() == 1 && ix->raw_is_host && ix->defer_cfg;
   if (!defer) ST_TRY(join_exchange(ix));
   hipStream_t st = ix->stream;
-  // the deadline of a coalesced batch is its OLDEST call's: the device is armed with what is left of that budget
-  auto t_start = calls[0].t0;
-  for (const SearchCall& c : calls) t_start = std::min(t_start, c.t0);
+  // Every call has its own deadline, counted from when IT entered the library (one expired call at the front of
+  // the queue used to fail the whole batch, newcomers included — and the batch after it, and so on).  Calls whose budget is
+  // already spent are failed here, one by one, and take no part in the batch; the device is armed with the smallest budget left
+  // among the others.
+  std::vector<SearchCall> live_calls;
+  std::vector<size_t> live_at;  // index of each live call in all_calls
   uint32_t timeout_left = p->timeout_ms;
+  if (per_call) per_call->assign(all_calls.size(), MI355_OK);
   if (p->timeout_ms) {
-    const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
-    if (waited >= (long long)p->timeout_ms)
-      return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms (before the device was reached)", waited, p->timeout_ms);
-    timeout_left = p->timeout_ms - (uint32_t)waited;
+    const auto now = std::chrono::steady_clock::now();
+    long long worst = 0;
+    for (size_t i = 0; i < all_calls.size(); ++i) {
+      const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(now - all_calls[i].t0).count();
+      if (waited >= (long long)p->timeout_ms) {
+        worst = std::max(worst, waited);
+        if (per_call) (*per_call)[i] = MI355_ERR_TIMEOUT;
+      } else {
+        timeout_left = std::min(timeout_left, p->timeout_ms - (uint32_t)waited);
+        live_at.push_back(i);
+      }
+    }
+    if (live_at.empty() || (!per_call && live_at.size() != all_calls.size()))
+      return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms (before the device was reached)", worst, p->timeout_ms);
+    if (live_at.size() != all_calls.size())
+      for (size_t i : live_at) live_calls.push_back(all_calls[i]);
   }
+  const std::vector<SearchCall>& calls = live_calls.empty() ? all_calls : live_calls;
+  if (live_at.empty())
+    for (size_t i = 0; i < all_calls.size(); ++i) live_at.push_back(i);
   const uint32_t k = sh.k;
   uint32_t n_queries = 0;
   for (const SearchCall& c : calls) n_queries += c.nq;
@@ -392,12 +425,24 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& cal
     if (ext_probes && h_ctl.bad_probes)
       return fail(MI355_ERR_INVALID_INPUT, "%u probe ids are not partitions of this index", h_ctl.bad_probes);
     if (p->timeout_ms) {
-      auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
-      if (h_ctl.timed_out || ms > (long long)p->timeout_ms)
-        return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms%s", (long long)ms, p->timeout_ms,
+      const auto now = std::chrono::steady_clock::now();
+      long long first_late = -1;
+      for (size_t j = 0; j < calls.size(); ++j) {  // every call against its own clock
+        const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(now - calls[j].t0).count();
+        if (h_ctl.timed_out || ms > (long long)p->timeout_ms) {
+          if (per_call) (*per_call)[live_at[j]] = MI355_ERR_TIMEOUT;
+          if (first_late < 0 && (live_at[j] == 0 || !per_call)) first_late = ms;
+        }
+      }
+      if (h_ctl.timed_out && per_call)  // (the batch is incomplete: nobody's results are)
+        return fail(MI355_ERR_TIMEOUT, "Query timeout: the batch was stopped on the device after %u ms", timeout_left);
+      if (first_late >= 0)
+        return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms%s", first_late, p->timeout_ms,
                     h_ctl.timed_out ? " (stopped on the device)" : "");
     }
   }
+  if (per_call && (*per_call)[0] == MI355_ERR_TIMEOUT)  // (calls[0] — the caller that runs the batch — was itself too late for it)
+    return fail(MI355_ERR_TIMEOUT, "Query timeout: more than %u ms before the device was reached", p->timeout_ms);
   return MI355_OK;
 }
 
@@ -459,9 +504,23 @@ static int32_t search_impl(mi355_index* ix, const float* queries, uint32_t n_que
   } guard{ix, served};
   for (PendingSearch* o : served) calls.push_back({o->queries, o->nq, o->out_rowids, o->out_dist, o->out_counts, o->t0});
   int32_t status;
+  std::vector<int32_t> per_call;
   {
     std::lock_guard<std::mutex> lk(ix->mu);
-    status = search_locked(ix, calls, p, sh, nullptr, 0);
+    status = search_locked(ix, calls, p, sh, nullptr, 0, &per_call);
+  }
+  // A timeout is a call's own: a parked call whose outcome differs from this caller's gets it written here (the queue
+  // delivers it instead of the batch's status).  Any other failure is the whole batch's.
+  const bool batch_failed = status != MI355_OK && status != MI355_ERR_TIMEOUT;
+  if (!batch_failed && per_call.size() == calls.size()) {
+    const bool stopped = status == MI355_ERR_TIMEOUT && per_call[0] == MI355_OK;  // (the device stopped the batch: everybody timed out)
+    for (size_t j = 0; j < served.size() && !stopped; ++j) {
+      PendingSearch* o = served[j];
+      o->status = per_call[j + 1];
+      o->error[0] = 0;
+      if (o->status == MI355_ERR_TIMEOUT) snprintf(o->error, sizeof o->error, "Query timeout: more than %u ms", p->timeout_ms);
+      o->decided = true;
+    }
   }
   guard.status = status;
   guard.err[0] = 0;

@@ -153,7 +153,7 @@ static inline void launch_by_kpl(int kpl, KernFn k1, KernFn k2, KernFn k4, dim3 
 // Per-launch-sequence timestamps, recorded on the search stream without any
 // host synchronisation; elapsed times are read back in mi355_last_stats.
 struct EventSet {
-  hipEvent_t ev[6];
+  hipEvent_t ev[7];  // [6]: between the planner (+ the batch's distance-table images) and the scan kernel
 };
 
 
@@ -169,8 +169,7 @@ struct GraphEntry {
   bool failed = false;  // capture / instantiate did not work for this shape: eager from now on
   uint32_t gen = 0;     // workspace generation the graph was captured against
   // what is baked into the captured kernels (a replay needs them to be identical)
-  float lower = 0.f, upper = 0.f;
-  uint32_t timeout_ms = 0;
+  float lower = 0.f, upper = 0.f;  // (the deadline is NOT baked in: replays arm the control word eagerly)
   const void* d_q = nullptr;
   const void* d_ids = nullptr;
   uint64_t work_items = 0;
@@ -215,6 +214,11 @@ struct mi355_index {
   // SkewShape of the packed codes (MI355_SCAN_SKEW): columns per slab, slabs per row, generalised kernel or not
   uint32_t sk_M = 0, sk_slabs = 1, sk_slabbed = 0, sk_res_floats = 0;
   DevBuf w_partial;  // per-workgroup partial row sums between the slabs of a work item (sk_slabs > 1)
+  // batch-level distance tables (kernels_lut.h): the shape qualifies (8-bit codes, sub-vectors of 16 floats: the
+  // reference's m = dim / 16), the per-pair residual rows and the table images of a chunk of the batch
+  bool lut_img_ok = false;
+  bool lut_inline_cfg = false;  // MI355_CFG_LUT_INLINE: build the tables inside the scan work items anyway
+  DevBuf w_lutres, w_lutimg;
   DevBuf w_cand2b, w_cnt2b;  // the second buffer set of the deferred refine (each set has its own allocations)
   bool defer_cfg = false;    // MI355_CFG_DEFER_REFINE
   // workspace
@@ -312,6 +316,15 @@ int32_t launch_scan_pair(const ScanArgs& sa, dim3 grid, hipStream_t st, uint32_t
 size_t scan_pair_lds(uint32_t m, uint32_t nbits, uint32_t dim, uint32_t lr, uint32_t nt);
 uint32_t scan_pair_m_lds(uint32_t m, uint32_t nbits, uint32_t dim);
 int32_t launch_scan_skew(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st);
+// ... the kernels that copy a table image (SkewArgs::lut_img) instead of building the table (ann_scan_skew_img.hip), and the
+// batch-level table kernels themselves (ann_lut.hip)
+int32_t launch_scan_skew_img(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st);
+struct SkewItem;
+bool lut_images_shape_ok(const mi355_index* ix);
+size_t lut_image_bytes_per_pair(const mi355_index* ix);
+size_t lut_residual_bytes_per_pair(const mi355_index* ix);
+int32_t launch_lut_images(mi355_index* ix, const float* qp, const SkewItem* items, const uint32_t* q_start, uint32_t n_pairs,
+                          uint32_t n_slices, uint32_t nprobe, float* res, float* img, hipStream_t st);
 
 struct IndexView;
 int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, uint32_t nq, const Cand* in,

@@ -6,12 +6,14 @@
 #include "kernels_ivfpq.h"
 #include "kernels_skew.h"
 
-template <int M, bool SLABBED>
+// IMG: the kernels that copy a pre-built table image (SkewArgs::lut_img, kernels_lut.h) instead of building the table; the
+// driver only asks for them with kk <= 128 (ann_index.hip), so only those selections are instantiated.
+template <int M, bool SLABBED, bool IMG = false>
 static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st) {
   auto lds_of = [&](int nw, int lr) { return sk_scan_lds(M, sa.res_floats, nw, lr); };
 #define LAUNCH_SK_(LR, NT, MULTI, OPT, TWO, GRID)                                               \
   {                                                                                             \
-    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT, SLABBED, TWO>;                               \
+    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT, SLABBED, TWO, IMG>;                               \
     const size_t lds = lds_of(NT / 64, LR);                                                     \
     if (lds > 160u * 1024)                                                                      \
       return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
@@ -51,12 +53,18 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_
   // lists and optimistic passes of SCAN_PASS_ROWS rows (k_scan_skew OPT) when that fits the LDS,
   // else eight waves with 320-row lists
   const bool opt_fits = lds_of(16, 3) <= 160u * 1024;
+  if constexpr (IMG) {  // (no residual in LDS: the 16-wave lists always fit)
+    if (kk <= 64) LAUNCH_SK(2, 1024, false, false)
+    else if (kk <= 128) LAUNCH_SK(3, 1024, false, false)
+    else return fail(MI355_ERR_NOT_SUPPORTED, "table images are scanned with k * refine_factor <= 128");
+  } else {
   if (kk <= 64) LAUNCH_SK(2, 1024, false, false)
   else if (kk <= 128 && opt_fits) LAUNCH_SK(3, 1024, false, false)
   else if (kk <= 128) LAUNCH_SK(3, 512, false, false)  // a long residual: the lists of 16 waves do not fit
   else if (opt_fits) LAUNCH_SK(3, 1024, true, true)
   else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
   else LAUNCH_SK(5, 512, true, false)
+  }
 #undef LAUNCH_SK
 #undef LAUNCH_SK_
   HIP_TRY(hipGetLastError());

@@ -30,6 +30,9 @@ struct QueueWaiter {
   uint32_t nq = 0;      // queries it carries (a batch is capped)
   int32_t status = 0;   // QS_SERVED: the status / message of the batch that carried it
   char error[256] = {0};  // fixed: delivering a failure must not allocate (it may be "out of host memory")
+  // the owner of the batch already wrote THIS request's own outcome into status / error (its own deadline passed while
+  // the others' did not): leave() delivers it instead of the batch's.  Only the owner writes it, before leave().
+  bool decided = false;
   // QS_PARKED, QS_SERVED = another caller's batch carried it (status / error are final), QS_LEAD = handed the device:
   // this caller runs the next batch.  Written last by the thread that decides, read without the queue lock by the owner.
   std::atomic<uint32_t> state{QS_PARKED};
@@ -138,8 +141,10 @@ struct CallQueue {
         busy = false;
       }
       for (W* f : served) {
-        f->status = status;
-        snprintf(f->error, sizeof f->error, "%s", err ? err : "");
+        if (!f->decided) {
+          f->status = status;
+          snprintf(f->error, sizeof f->error, "%s", err ? err : "");
+        }
         wake_mask |= 1u << f->cohort;
         f->state.store(QS_SERVED, std::memory_order_release);
       }

@@ -357,8 +357,17 @@ __device__ __forceinline__ void plan_scan_block(const PlanArgs& a, uint32_t* s_p
   };
   const uint32_t per = (nv + 1023u) / 1024u;
   const uint32_t i0 = tid * per, i1 = sk_min_u32(nv, i0 + per);
+  // (eight counts in flight per thread, loaded unconditionally at clamped indices: one dependent L2 round trip per count —
+  //  24 per thread and pass at the reference's default 12 207 partitions — made this single workgroup a 97 us kernel)
+  constexpr uint32_t PFN = 8;
   uint32_t sum = 0;
-  for (uint32_t i = i0; i < i1; ++i) sum += a.cnt[key_of(i)];
+  for (uint32_t i = i0; i < i1; i += PFN) {
+    uint32_t c[PFN];
+#pragma unroll
+    for (uint32_t u = 0; u < PFN; ++u) c[u] = a.cnt[key_of(sk_min_u32(i + u, i1 - 1u))];
+#pragma unroll
+    for (uint32_t u = 0; u < PFN; ++u) sum += (i + u < i1) ? c[u] : 0u;
+  }
   s_part[tid] = sum;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -368,16 +377,25 @@ __device__ __forceinline__ void plan_scan_block(const PlanArgs& a, uint32_t* s_p
     __syncthreads();
   }
   uint32_t run = s_part[tid] - sum;
-  for (uint32_t i = i0; i < i1; ++i) {
-    const uint32_t k = key_of(i);
-    const uint32_t c = a.cnt[k];
-    a.off[k] = run;
-    a.fill[k] = 0;
-    a.cnt[k] = 0;
-    // queue boundaries: the first virtual index of each queue records its offset
-    for (uint32_t x = 0; x < 8; ++x)
-      if (ncls * s_xf[x] == i) a.q_start[x] = run;
-    run += c;
+  for (uint32_t i = i0; i < i1; i += PFN) {
+    uint32_t kk[PFN], c[PFN];
+#pragma unroll
+    for (uint32_t u = 0; u < PFN; ++u) {
+      kk[u] = key_of(sk_min_u32(i + u, i1 - 1u));
+      c[u] = a.cnt[kk[u]];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < PFN; ++u) {
+      if (i + u < i1) {
+        a.off[kk[u]] = run;
+        a.fill[kk[u]] = 0;
+        a.cnt[kk[u]] = 0;
+        // queue boundaries: the first virtual index of each queue records its offset
+        for (uint32_t x = 0; x < 8; ++x)
+          if (ncls * s_xf[x] == i + u) a.q_start[x] = run;
+        run += c[u];
+      }
+    }
   }
   if (tid == 1023) {
     const uint32_t total = s_part[1023];
@@ -781,6 +799,9 @@ struct SkewArgs {
   uint32_t res_floats;      // LDS floats of the residual: dim, or one slab's M * dsub (SLABBED)
   float2* partial;          // [grid][partial_stride]: per-workgroup partial row sums between slabs (n_slabs > 1)
   uint32_t partial_stride;  // float2 elements per workgroup: (tile positions of the longest unit) * 16 units * 64 lanes
+  // IMG kernels: the distance tables of the batch, built by k_lut_images (kernels_lut.h) before this launch —
+  // [pair][slab][column block][code][16] f32; a work item copies its image into the LDS table instead of building it
+  const float* lut_img;
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -833,8 +854,12 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
 // dev builds (-DMI355_DEV_COUNTERS): thread 0 adds the item's phase times (wall_clock64 ticks) and the
 // selection's counters to DevCtl.dev[]: 0 LUT build, 1 scan, 2 merge (ticks), 3 items, 4 rows in the lists
 // at the merge, 5 optimistic passes redone, 6 ticks wave 0 waited for the slowest wave, 7 rows admitted
+// (the counters are summed per workgroup in registers and flushed ONCE when the workgroup has run out of work: one atomic per
+//  phase and item on a single cache line serialises 256 CUs — 250 k atomics per launch at the reference's default shape, where
+//  items last 15 us, turned a 2.5 ms scan into 6.4 ms and the phase split into fiction)
 #ifdef MI355_DEV_COUNTERS
 #define SK_DEV(...) __VA_ARGS__
+__device__ __forceinline__ void sk_dev_add(uint32_t& acc, uint32_t v) { acc += v; }
 #else
 #define SK_DEV(...)
 #endif
@@ -845,8 +870,11 @@ __device__ __forceinline__ uint32_t sk_pop_sync(const SkewArgs& a, const uint32_
 // last slab.  Every row sum is still LUT[0] + LUT[1] + ... in j order followed by exact `+ 0.0f` terms.
 // TWO: an eight-wave workgroup that shares its CU with a second one (a 32-column table is 64 KiB): one builds its table or
 // merges while the other scans.  The second launch-bound figure is waves per SIMD: 4 keeps both at <= 128 VGPRs.
-template <int M, int LR, int NT, bool MULTI, bool OPT = false, bool SLABBED = false, bool TWO = false>
+// IMG: the table is not built here — k_lut_images (kernels_lut.h) built every pair's table of the batch with the codebook in
+// registers, and the item copies its image (4 * M bytes per code row) into LDS: no residual, no codebook stream.
+template <int M, int LR, int NT, bool MULTI, bool OPT = false, bool SLABBED = false, bool TWO = false, bool IMG = false>
 __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a) {
+  static_assert(!IMG || !MULTI, "table images are scanned in one selection pass");
   static_assert(!TWO || (NT == 512 && M <= 32), "two workgroups per CU: eight waves and a one-slab table each");
   static_assert(!OPT || (MULTI && LR * 64 >= (int)SK_SAFE_PASS), "OPT rides on the pass machinery");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -863,7 +891,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   float* lut = (float*)smem;                                  // [256][P] (dual: two slabs)
   constexpr uint32_t TABLE_BYTES = sk_table_bytes(M);
   float* res = (float*)(smem + TABLE_BYTES);                  // [dim] (SLABBED: [M * dsub], the current slab's)
-  const uint32_t res_n = SLABBED ? a.res_floats : ix.dim;     // residual elements of the first (only) slab
+  const uint32_t res_n = IMG ? 0u : SLABBED ? a.res_floats : ix.dim;  // residual elements of the first (only) slab
   ListEnt* lists = (ListEnt*)(smem + TABLE_BYTES + (((size_t)res_n * 4 + 15) & ~(size_t)15));
   uint32_t* s_cnt = (uint32_t*)(lists + (size_t)NW * LR * MI355_WAVE);  // [NW]
   uint32_t* s_part = s_cnt + NW;                              // [NW] every wave's q-th best (sort key), QSHARE
@@ -904,7 +932,32 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   __syncthreads();
   // every thread's share of the first residual
   float pre_q[4], pre_c[4];  // up to 4 elements per thread (dim <= 4 * NT, checked at open)
+  // IMG: the item's table image instead — quads of four columns, thread e reads quad e, e + NT, ... (coalesced 16-B loads,
+  // all of a thread's loads in flight at once); requested where the residual operands are: for the first item before the
+  // loop, for every later one while the previous item's lists are merged (SK_IMG_PREFETCH=0: at the item's own start)
+#ifndef SK_IMG_PREFETCH
+#define SK_IMG_PREFETCH 1
+#endif
+#ifndef SK_IMG_NT_LOAD
+#define SK_IMG_NT_LOAD 1  // (the image is read once: it should not push the partition codes other queries reuse out of L2; scan -1.5 %)
+#endif
+  constexpr uint32_t IMG_QPR = (uint32_t)M / 4u, IMG_NQ = 256u * IMG_QPR;  // quads per code row / per table
+  constexpr int IMG_PER = IMG ? (int)((IMG_NQ + NT - 1) / NT) : 1;
+  sk_f32x4 img_pf[IMG_PER];
+  auto fetch_image = [&](uint32_t pair_, uint32_t slab_, sk_f32x4 (&v)[IMG_PER]) {
+    const uint32_t n_sl_img = SLABBED ? a.n_slabs : 1u;
+    const sk_f32x4* src = (const sk_f32x4*)(a.lut_img + ((size_t)pair_ * n_sl_img + slab_) * (256u * (uint32_t)M));
+#pragma unroll
+    for (int u = 0; u < IMG_PER; ++u) {
+      const sk_f32x4* p = src + sk_min_u32((uint32_t)tid + (uint32_t)u * NT, IMG_NQ - 1u);
+      v[u] = SK_IMG_NT_LOAD ? __builtin_nontemporal_load(p) : *p;
+    }
+  };
   auto prefetch_res = [&](const SkewItem& it) {
+    if constexpr (IMG) {
+      if (SK_IMG_PREFETCH) fetch_image(a.n_slices > 1u ? (it.pair & 0xFFFFFu) : it.pair, 0u, img_pf);
+      return;
+    }
     const uint32_t pr = a.n_slices > 1u ? (it.pair & 0xFFFFFu) : it.pair;  // (sliced pairs carry the slice on top: sk_pack_pair)
     const float* q = a.qp + (size_t)(pr / a.nprobe) * ix.dim;
     const float* c = ix.centroids + (size_t)it.part * ix.dim;
@@ -920,7 +973,22 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     }
   };
   if (s_rec[0].pair != SK_NONE) prefetch_res(s_rec[0]);
+  // IMG kernels pop TWO items ahead.  The pop is an atomic on a queue head every CU hammers, and the record load depends on
+  // it: ~2-3 us of round trips that the 12 us in-item table build used to cover.  With the table phase down to an image copy
+  // they would sit on the item's critical path (the workgroup waits for thread 0 at the barrier in front of the scan), so:
+  // at the start of item i thread 0 loads the record of item i + 1 from the index it popped at the start of item i - 1 —
+  // long since arrived — and pops the index of item i + 2.  (pa, pa_q0, pa_n, pa_q): the older pop, its queue's bounds
+  // and id when it was issued.
+  constexpr bool POP2 = IMG;
+  uint32_t pa = SK_NONE, pa_q0 = 0, pa_n = 0, pa_q = 0;
+  if (POP2 && tid == 0 && s_rec[0].pair != SK_NONE && q_tried < 8) {
+    pa_q = q_cur;
+    pa_q0 = s_q[q_cur];
+    pa_n = s_q[q_cur + 1] - pa_q0;
+    pa = atomicAdd(a.heads + q_cur * SK_HEAD_STRIDE, 1u);
+  }
 
+  SK_DEV(uint32_t dv_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
   for (uint32_t slot = 0;; slot ^= 1u) {
     // the record is wave-uniform: keep it in SGPRs
     const SkewItem* rec = s_rec + slot;
@@ -943,12 +1011,21 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
            const unsigned long long dv_c0 = clock64();)  // shader-clock ticks of the item -> dev[5] (with dev[0..2]: the clock the chip holds)
 
     // ---- pop the NEXT item now; its index arrives behind the LUT phase's loads
-    uint32_t pf = SK_NONE, pf_q0 = 0, pf_n = 0;
+    uint32_t pf = SK_NONE, pf_q0 = 0, pf_n = 0, pf_q = 0;
     if (tid == 0 && q_tried < 8 && ctl_expired(a.ctl)) q_tried = 8;
     if (tid == 0 && q_tried < 8) {
+      pf_q = q_cur;
       pf_q0 = s_q[q_cur];
       pf_n = s_q[q_cur + 1] - pf_q0;
       pf = atomicAdd(a.heads + q_cur * SK_HEAD_STRIDE, 1u);
+    }
+    // POP2: `pf` is the index of the item after the next one; the next item's is the older pop
+    const uint32_t nx = POP2 ? pa : pf, nx_q0 = POP2 ? pa_q0 : pf_q0, nx_n = POP2 ? pa_n : pf_n, nx_q = POP2 ? pa_q : pf_q;
+    if (POP2) {
+      pa = pf;
+      pa_q0 = pf_q0;
+      pa_n = pf_n;
+      pa_q = pf_q;
     }
 
     // ---- K2: residual (prefetched) + distance table ---------------------------
@@ -1089,19 +1166,53 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         }
       }
     };
-    if (!(a.dbg & 1u)) build_lut(0);
+    // IMG: the table of (pair, slab) arrives as an image; a quad is stored where sk_lut_slots puts its first entry; the
+    // columns stored twice (j >= M - 31) are whole quads because 16 | M - 32 (the quad of j = M - 32 also lands on the
+    // unused column u = 0).  The 64 lanes of a store hit 4 of the 8 bank quads (16 codes x the 4 quads of a column block,
+    // code rows are 256 B apart): half the LDS store rate, ~0.2 us per table — the price of images that the table kernel
+    // writes as contiguous 16 KiB runs.
+    auto store_image = [&](const sk_f32x4 (&v)[IMG_PER]) {
+#ifdef SK_DUAL
+#pragma unroll
+      for (int u = 0; u < IMG_PER; ++u) {
+        const uint32_t e = (uint32_t)tid + (uint32_t)u * NT;
+        if (IMG_NQ % NT == 0 || e < IMG_NQ) {
+          // image layout [column block of 16][code][4 quads] (kernels_lut.h): quad e -> (block e / 1024, code, quad e % 4)
+          const uint32_t c = (e >> 2) & 255u, j = (e >> 10) * 16u + (e & 3u) * 4u;
+          uint32_t at, dup;
+          sk_lut_slots(c, j + 3u, (uint32_t)M, at, dup);  // (the quad's LAST column decides whether the quad is stored twice)
+          *(sk_f32x4*)(lut + at - 3u) = v[u];
+          if (dup != SK_NONE) *(sk_f32x4*)(lut + dup - 3u) = v[u];
+        }
+      }
+#endif
+    };
+    auto load_lut_image = [&](uint32_t slab) {
+      if (SK_IMG_PREFETCH && slab == 0u) {  // (requested before the loop / during the previous item's merge; IMG kernels are single-pass)
+        store_image(img_pf);
+      } else {
+        sk_f32x4 v[IMG_PER];
+        fetch_image(pair, slab, v);
+        store_image(v);
+      }
+    };
+    auto make_lut = [&](uint32_t slab) {
+      if constexpr (IMG) load_lut_image(slab);
+      else build_lut(slab);
+    };
+    if (!(a.dbg & 1u)) make_lut(0);
     // the next item's record: one dependent load, lands during the scan
     SkewItem nxt;
     nxt.pair = SK_NONE;
     bool nxt_valid = false;
-    if (tid == 0 && pf != SK_NONE && pf < pf_n) {
-      nxt = a.items[pf_q0 + pf];
+    if (tid == 0 && nx != SK_NONE && nx < nx_n) {
+      nxt = a.items[nx_q0 + nx];
       nxt_valid = true;
     }
     __syncthreads();
 
     SK_DEV(const unsigned long long dv_t1 = wall_clock64();
-           if (tid == 0) { atomicAdd(&a.ctl->dev[0], (uint32_t)(dv_t1 - dv_t0)); atomicAdd(&a.ctl->dev[3], 1u);
+           if (tid == 0) { sk_dev_add(dv_acc[0], (uint32_t)(dv_t1 - dv_t0)); sk_dev_add(dv_acc[3], 1u);
                          })
     // ---- K3 + K4: skewed ADC scan, one stream per wave ----------------------
     auto idof = [&](uint32_t pos) -> uint64_t { return rid ? rid[pos] : grow0 + (pos - lrow0); };
@@ -1232,7 +1343,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     if constexpr (SLABBED) {
       if (cur_slab != slab) {  // (workgroup-uniform) the table of another slab: also a later pass coming back to slab 0
         __syncthreads();       // every wave is done with the old table and residual
-        for (uint32_t dl = tid; dl < a.res_floats; dl += NT) {
+        for (uint32_t dl = tid; !IMG && dl < a.res_floats; dl += NT) {
           const uint32_t dg = slab * a.res_floats + dl;  // res_floats = M * dsub whenever there are several slabs
           float v = 0.f;
           if (dg < ix.dim) {
@@ -1242,7 +1353,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
           res[dl] = v;
         }
         __syncthreads();
-        if (!(a.dbg & 1u)) build_lut(slab);
+        if (!(a.dbg & 1u)) make_lut(slab);
         __syncthreads();
         cur_slab = slab;
       }
@@ -1359,9 +1470,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
 #ifdef MI355_DEV_SCANSPLIT
       if (tid == 0) {
         const unsigned long long ss_t3 = wall_clock64();
-        atomicAdd(&a.ctl->dev[4], (uint32_t)(ss_t1 - ss_t0));
-        atomicAdd(&a.ctl->dev[6], (uint32_t)(ss_t2 - ss_t1));
-        atomicAdd(&a.ctl->dev[7], (uint32_t)(ss_t3 - ss_t2));
+        sk_dev_add(dv_acc[4], (uint32_t)(ss_t1 - ss_t0));
+        sk_dev_add(dv_acc[6], (uint32_t)(ss_t2 - ss_t1));
+        sk_dev_add(dv_acc[7], (uint32_t)(ss_t3 - ss_t2));
       }
 #endif
     }
@@ -1430,13 +1541,22 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     if (lane == 0) s_cnt[wid] = wl.cnt;
     auto next_item_fallback = [&]() {  // thread 0: the prefetch ran off the end of its queue (rare, synchronous)
       if (!nxt_valid) {
-        if (q_tried < 8) {
-          q_cur = (q_cur + 1) & 7u;
-          ++q_tried;
+        if (POP2 && pa != SK_NONE && pa < pa_n) {
+          // the YOUNGER pop holds a work item (it was taken from the queue the cursor moved on to, after the older one had run
+          // off the previous queue): it is the next item — nothing popped is ever dropped
+          nxt = a.items[pa_q0 + pa];
+          pa = SK_NONE;
+        } else {
+          // (a pop that ran off its queue's end leaves that queue — unless the workgroup already left it: the two-deep pop's
+          //  second index of a dry queue arrives after the first one moved the cursor on)
+          if (q_tried < 8 && nx_q == q_cur && nx != SK_NONE) {
+            q_cur = (q_cur + 1) & 7u;
+            ++q_tried;
+          }
+          const uint32_t gi = sk_pop_sync(a, s_q, q_cur, q_tried);
+          nxt.pair = SK_NONE;
+          if (gi != SK_NONE) nxt = a.items[gi];
         }
-        const uint32_t gi = sk_pop_sync(a, s_q, q_cur, q_tried);
-        nxt.pair = SK_NONE;
-        if (gi != SK_NONE) nxt = a.items[gi];
       }
       s_rec[slot ^ 1u] = nxt;
     };
@@ -1455,7 +1575,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         // it started from is untouched (s_floor is only written by a pass's merge)
         optimistic = false;
         tail_popped = tail_popped || last_known;
-        SK_DEV(if (tid == 0) atomicAdd(&a.ctl->dev[5], 1u);)
+        SK_DEV(if (tid == 0) sk_dev_add(dv_acc[5], 1u);)
         __syncthreads();  // every thread has read the flag
         if (tid == 0) {
           *s_ovf = 0u;
@@ -1534,7 +1654,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     const uint32_t total = pre[NW];
     const uint32_t n_out = min(total, kk_pass);
 #ifndef MI355_DEV_SCANSPLIT
-    SK_DEV(if (tid == 0) atomicAdd(&a.ctl->dev[4], total);)
+    SK_DEV(if (tid == 0) sk_dev_add(dv_acc[4], total);)
 #endif
     auto locate = [&](uint32_t c, uint32_t& w2, uint32_t& j2) {  // flat position -> (list, entry)
       w2 = 0;
@@ -1606,7 +1726,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     SK_DEV(const unsigned long long dv_m1 = wall_clock64();)
     if (parked) flush();
 #ifndef MI355_DEV_SCANSPLIT
-    SK_DEV(if (tid == 0) { atomicAdd(&a.ctl->dev[6], (uint32_t)(dv_m0 - dv_p1)); atomicAdd(&a.ctl->dev[7], (uint32_t)(dv_m1 - dv_m0)); })
+    SK_DEV(if (tid == 0) { sk_dev_add(dv_acc[6], (uint32_t)(dv_m0 - dv_p1)); sk_dev_add(dv_acc[7], (uint32_t)(dv_m1 - dv_m0)); })
 #endif
     const bool more = MULTI && total >= kk_pass && pass_base + kk_pass < a.kk;
     SK_DEV(__syncthreads(); dv_merge += wall_clock64() - dv_p1;)
@@ -1623,7 +1743,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     if (MULTI && !tail_done) {  // the tail work of an item whose last pass was not known in advance
       if (tid == 0 && (!nxt_valid || !rec_stored)) {
         if (!nxt_valid) {
-          if (q_tried < 8) {
+          if (q_tried < 8 && nx_q == q_cur && nx != SK_NONE) {
             q_cur = (q_cur + 1) & 7u;
             ++q_tried;
           }
@@ -1636,9 +1756,10 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       __syncthreads();
       if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     }
-    SK_DEV(if (tid == 0 && !OPT) { atomicAdd(&a.ctl->dev[5], (uint32_t)(clock64() - dv_c0)); }
-           if (tid == 0) { atomicAdd(&a.ctl->dev[1], (uint32_t)dv_scan); atomicAdd(&a.ctl->dev[2], (uint32_t)dv_merge); }
+    SK_DEV(if (tid == 0 && !OPT) { sk_dev_add(dv_acc[5], (uint32_t)(clock64() - dv_c0)); }
+           if (tid == 0) { sk_dev_add(dv_acc[1], (uint32_t)dv_scan); sk_dev_add(dv_acc[2], (uint32_t)dv_merge); }
            (void)dv_adm;)
     __syncthreads();  // LDS is rebuilt by the next item
   }
+  SK_DEV(if (tid == 0) { for (int x = 0; x < 8; ++x) if (dv_acc[x]) atomicAdd(&a.ctl->dev[x], dv_acc[x]); })
 }

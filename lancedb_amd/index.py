@@ -161,13 +161,15 @@ class IvfPqIndex(_Handle):
         check(lib().mi355_index_open(C.byref(d), C.byref(self._h)))
         self._keep = [raw] if raw_host_mapped else []  # the library copied everything else it needs
 
-    def configure(self, scan_variant=None, slice_rows=None, profile=0, graph=None, coalesce=None, defer_refine=None):
+    def configure(self, scan_variant=None, slice_rows=None, profile=0, graph=None, coalesce=None, defer_refine=None, lut_inline=None):
         """profile: 0 counters only, 1 per-stage times of the last search,
         2 accumulate over searches until the next configure().  graph / coalesce: the
         hipGraph-replay and coalescing-queue modes of host-I/O searches; None keeps the current
         setting (after open: coalescing on, graph replay off — measured slower than eager launches
         on the driver's box, profiles/r02 latency leg).  defer_refine (opt-in, MI355_CFG_DEFER_REFINE): device-I/O refine
-        calls over a host-resident raw column leave their re-rank on a private stream — results complete at sync()."""
+        calls over a host-resident raw column leave their re-rank on a private stream — results complete at sync().
+        lut_inline (opt-out, MI355_CFG_LUT_INLINE): build every PQ distance table inside its scan work item even where the
+        batch-level table kernel applies (dim / m = 16); results are bit-identical either way."""
         # None keeps the handle's current value (a profile-only call such as analyze_plan() must not reset the tuning)
         if scan_variant is not None:
             self._scan_variant = int(scan_variant)
@@ -177,12 +179,15 @@ class IvfPqIndex(_Handle):
         slice_rows = getattr(self, "_slice_rows", 0)
         if defer_refine is not None:
             self._defer = bool(defer_refine)
+        if lut_inline is not None:
+            self._lut_inline = bool(lut_inline)
         if graph is not None:
             self._graph = bool(graph)
         if coalesce is not None:
             self._coalesce = bool(coalesce)
         mode = int(profile) | (_abi.CFG_GRAPH if getattr(self, "_graph", False) else 0) | \
-            (_abi.CFG_COALESCE if getattr(self, "_coalesce", True) else 0) | (_abi.CFG_DEFER_REFINE if getattr(self, "_defer", False) else 0)
+            (_abi.CFG_COALESCE if getattr(self, "_coalesce", True) else 0) | (_abi.CFG_DEFER_REFINE if getattr(self, "_defer", False) else 0) | \
+            (_abi.CFG_LUT_INLINE if getattr(self, "_lut_inline", False) else 0)
         check(lib().mi355_index_configure(self._h, C.c_uint32(scan_variant), C.c_uint32(slice_rows), C.c_uint32(mode)))
 
     def set_stream(self, hip_stream):

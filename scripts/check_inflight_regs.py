@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the SLABBED k_scan_skew instantiations (csrc/kernels_skew.h): the partial-sum register px is loaded
+"""Static check of the SLABBED k_scan_skew instantiations (csrc/kernels_skew.h; table-building and table-image kernels): the partial-sum register px is loaded
 by inline asm (global_load_dwordx2) and consumed a tile later behind a counted s_waitcnt.  hipcc does not know the
 register is in flight; if its register allocator ever copies px (v_mov) between the load and the wait, the copy reads
 stale data.  This script compiles the translation unit to assembly and fails if any such copy exists.
@@ -18,15 +18,21 @@ sys.path.insert(0, ROOT)
 
 def main():
     from lancedb_amd import _lib
-    src = os.path.join(ROOT, "lancedb_amd", "csrc", "ann_scan_skew_slab.hip")
+    # both families of SLABBED kernels: the ones that build their distance tables and the ones that copy table images
+    s = ""
+    procs = []
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "slab.s")
-        cmd = [_lib._hipcc()] + _lib.HIPCC_FLAGS + ["-S", "--cuda-device-only", "-o", out, src]
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            print(r.stdout[-3000:])
-            return 2
-        s = open(out).read()
+        for unit in ("ann_scan_skew_slab.hip", "ann_scan_skew_slab_img.hip"):
+            src = os.path.join(ROOT, "lancedb_amd", "csrc", unit)
+            out = os.path.join(td, unit + ".s")
+            cmd = [_lib._hipcc()] + _lib.HIPCC_FLAGS + ["-S", "--cuda-device-only", "-o", out, src]
+            procs.append((out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for out, pr in procs:
+            log, _ = pr.communicate()
+            if pr.returncode != 0:
+                print(log[-3000:])
+                return 2
+            s += open(out).read()
     bad, n_kernels, n_loads = [], 0, 0
     for name in re.findall(r"\n(_Z11k_scan_skew\w+):", s):
         i = s.index("\n" + name + ":")

@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   const unsigned n_threads = argc > 1 ? (unsigned)atoi(argv[1]) : 48, per = argc > 2 ? (unsigned)atoi(argv[2]) : 400;
   CallQueue<Req> q;
   std::atomic<int> in_device{0};
-  std::atomic<uint64_t> batches{0}, carried{0}, failed_calls{0}, errors{0}, biggest{0};
+  std::atomic<uint64_t> batches{0}, carried{0}, failed_calls{0}, errors{0}, biggest{0}, own_outcomes{0}, own_seen{0};
   std::vector<std::thread> th;
   for (unsigned t = 0; t < n_threads; ++t)
     th.emplace_back([&, t] {
@@ -48,7 +48,18 @@ int main(int argc, char** argv) {
           status = (b % 97 == 96) ? 7 : 0;  // every 97th batch "fails": its callers must all see the error
           if (status == 0) {
             me.result = me.payload * 3 + 1;
-            for (Req* o : served) o->result = o->payload * 3 + 1;
+            for (Req* o : served) {
+              // a call's deadline is its own: every 5th carried request "timed out before the device was reached" — the
+              // owner writes that request's own outcome, and leave() must deliver it instead of the batch's status
+              if (o->payload % 5 == 4) {
+                o->status = 3;
+                snprintf(o->error, sizeof o->error, "late");
+                o->decided = true;
+                own_outcomes.fetch_add(1);
+              } else {
+                o->result = o->payload * 3 + 1;
+              }
+            }
           }
           carried.fetch_add(served.size() + 1);
           uint64_t big = biggest.load();
@@ -59,7 +70,10 @@ int main(int argc, char** argv) {
           q.leave(served, status, status ? "boom" : "");
         } else {
           status = me.status;
-          if (status != 0 && strcmp(me.error, "boom") != 0) errors.fetch_add(1);
+          if (status == 7 && strcmp(me.error, "boom") != 0) errors.fetch_add(1);
+          if (status == 3 && (strcmp(me.error, "late") != 0 || me.payload % 5 != 4)) errors.fetch_add(1);
+          if (status != 0 && status != 3 && status != 7) errors.fetch_add(1);
+          if (status == 3) own_seen.fetch_add(1);
         }
         if (status == 0) {
           if (me.result != me.payload * 3 + 1) errors.fetch_add(1);
@@ -72,6 +86,7 @@ int main(int argc, char** argv) {
   const uint64_t calls = (uint64_t)n_threads * per;
   if (carried.load() != calls) errors.fetch_add(1);  // every call ran in exactly one batch
   if (q.busy || !q.queue.empty()) errors.fetch_add(1);
+  if (own_outcomes.load() != own_seen.load()) errors.fetch_add(1);  // every per-request outcome reached its caller
   std::printf("%s: %llu calls in %llu batches (largest %llu), %llu calls saw their batch fail, %llu errors\n",
               errors.load() ? "FAILED" : "ok", (unsigned long long)calls, (unsigned long long)batches.load(),
               (unsigned long long)biggest.load(), (unsigned long long)failed_calls.load(), (unsigned long long)errors.load());

@@ -688,8 +688,10 @@ def summary_of(result):
             if not isinstance(d, dict) or p not in d:
                 return None
             d = d[p]
-        return round(d, 4) if isinstance(d, float) else d
-    s = {"c3_qps": v(result, "value"), "c3_scan_frac": v(result, "roofline", "frac"), "c3_lds_gather_frac": v(result, "roofline", "lds_gather", "frac"),
+        if isinstance(d, float):  # (rates as integers, fractions / times to 4 significant digits: the line has 4 KB)
+            return int(round(d)) if abs(d) >= 1000 else float(f"{d:.4g}")
+        return d
+    s = {"c3_qps": v(result, "value"), "c3_qps_device_io": v(result, "device_io", "value"), "c3_scan_frac": v(result, "roofline", "frac"), "c3_lds_gather_frac": v(result, "roofline", "lds_gather", "frac"),
          "c3_parity_ids": v(result, "cpu_baseline", "parity", "rowids_bit_exact"),
          "cpu_qps": v(result, "cpu_baseline", "value"), "cpu_cores": v(result, "cpu_baseline", "cores"),
          "c4_qps": v(sec, "c4", "value"), "c4_scan_frac": v(sec, "c4", "roofline", "frac"), "c4_rows": v(sec, "c4", "config", "n_rows"),
@@ -764,7 +766,6 @@ def compact_line(result):
         if isinstance(line.get(k), float):
             line[k] = round(line[k], 4)
     cfg = dict(result.get("config", {}))
-    cfg.pop("timed_region", None)
     line["config"] = {k: _short(v, 96) for k, v in cfg.items()}
     rf = result.get("roofline")
     if rf:
@@ -819,6 +820,21 @@ def emit(result, root=None):
                 f.write(doc)
         except OSError as e:  # a read-only checkout must not cost the bench line
             print(f"bench: could not write {path}: {e}", file=sys.stderr)
-    s = json.dumps(compact_line(result))
-    assert len(s) < LINE_LIMIT, len(s)
+    line = compact_line(result)
+    s = json.dumps(line)
+    # the line must come out whatever happens (an assert here lost the ONE line the driver parses after the
+    # whole benchmark had run): drop the optional parts, least important first, until it fits
+    for drop in (("summary",), ("multi_gpu",), ("cpu_baseline", "sample"), ("cpu_baseline", "parity_caveat"), ("roofline", "frac_definition"),
+                 ("roofline", "traffic_source"), ("roofline", "stage_us_per_step"), ("roofline", "lds_gather"), ("detail",), ("config",)):
+        if len(s) < LINE_LIMIT:
+            break
+        if drop == ("summary",):
+            summ = line.get("summary") or {}
+            while summ and len(json.dumps(line)) >= LINE_LIMIT:
+                summ.popitem()
+        elif len(drop) == 1:
+            line.pop(drop[0], None)
+        elif isinstance(line.get(drop[0]), dict):
+            line[drop[0]].pop(drop[1], None)
+        s = json.dumps(line)
     print(s, file=_REAL_STDOUT or sys.stdout, flush=True)

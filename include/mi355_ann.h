@@ -126,7 +126,12 @@ typedef struct mi355_index_desc {
   uint32_t dim;         /* vector dimension */
   uint32_t nlist;       /* IVF partitions (num_partitions) */
   uint32_t m;           /* PQ sub-vectors (num_sub_vectors); dim % m == 0 */
-  uint32_t nbits;       /* PQ bits: 8, or 4 with even m (table/create_index.rs:96-101) */
+  uint32_t nbits;       /* PQ bits: 8, or 4 with even m (table/create_index.rs:96-101).
+                           4-BIT PARITY AGAINST lance-index IS UNKNOWN: the engine sums f32 table entries per row like the
+                           8-bit path (and matches this repository's CPU restatement bit for bit); lance-index's 4-bit scan
+                           is, to our knowledge, a SIMD-shuffle scan over a table QUANTISED to u8 [EXT], whose distances
+                           and tie-breaks differ materially.  No "bit-exact" statement of this library covers 4-bit
+                           indexes against the reference; expect recall-level agreement, not id-level. */
   uint32_t metric;      /* MI355_METRIC_* the index was trained with */
   uint64_t n_rows;      /* rows covered by the index */
   uint32_t mem;         /* MI355_MEM_*: where the pointers below live */

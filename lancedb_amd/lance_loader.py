@@ -107,3 +107,63 @@ def open_ivf_pq(centroids, codebook, pq_codes, row_ids, offsets, lengths, metric
     codes = a["codes"] if transposed else a["codes"].reshape(-1, a["m"] * nbits // 8)
     return IvfPqIndex(a["centroids"], a["codebook"], a["part_offsets"], codes, a["row_ids"], raw_vectors=raw_vectors,
                       metric=metric, codes_layout=a["codes_layout"], raw_dtype=raw_dtype, device=device, nbits=nbits, **open_kw)
+
+
+def verify_against_raw(arrays, raw_rows, raw_row_ids, metric="l2", encode=None, min_partition_match=0.98, min_byte_match=0.95,
+                       strict=True):
+    """Self-check of the [EXT] guesses above, for the shim to call once per opened index (a wrong
+    guess about the codebook layout, the transposed storage or the nibble order returns garbage SILENTLY).
+
+    `arrays` = engine_arrays(...); `raw_rows` [s, dim] f32 are the raw vectors of s sampled rows and `raw_row_ids` [s] their
+    `_rowid` values (the shim takes them from the table it indexes: `take` of a few thousand rows).  The sample is re-encoded
+    with the index's OWN centroids and codebook — `mi355_ivfpq_encode` by default, or any callable with
+    `lancedb_amd.ivfpq_encode`'s signature and return value — and compared with what the index stores: the partition every
+    row sits in, and its code bytes.  lance's trainer / encoder differ from the engine's in rounding and tie-breaks [EXT],
+    so a few rows may land in a neighbouring partition or pick another codeword: the thresholds are fractions, not
+    equality.  A wrong layout guess leaves ~1 / 2^nbits of the bytes matching.
+
+    -> dict(rows, found, partition_match, byte_match, code_match, ok); raises InvalidInput when `strict` and not ok."""
+    cen, cb, po, codes, rid = (arrays[k] for k in ("centroids", "codebook", "part_offsets", "codes", "row_ids"))
+    nbits, m = int(arrays["nbits"]), int(arrays["m"])
+    mb = m * nbits // 8
+    raw = np.ascontiguousarray(raw_rows, dtype=np.float32)
+    ids = np.ascontiguousarray(raw_row_ids, dtype=np.uint64)
+    if raw.ndim != 2 or raw.shape[1] != cen.shape[1] or ids.shape != (raw.shape[0],):
+        raise InvalidInput(1, "raw_rows must be [s, dim] and raw_row_ids [s]")
+    if encode is None:
+        from .index import ivfpq_encode as encode
+    _, enc_codes, enc_order, enc_assign = encode(raw, cen, cb, metric=metric, nbits=nbits, return_assign=True)
+    enc_codes = np.asarray(enc_codes).reshape(-1, mb)
+    enc_order = np.asarray(enc_order).astype(np.int64)
+    by_row = np.empty_like(enc_codes)
+    by_row[enc_order] = enc_codes            # codes of input row i (the encoder returns them in index order)
+    assign = np.asarray(enc_assign).astype(np.int64)
+    # where the index stores each sampled row
+    sorter = np.argsort(rid, kind="stable")
+    at = np.searchsorted(rid, ids, sorter=sorter)
+    at = np.minimum(at, len(rid) - 1) if len(rid) else at
+    pos = sorter[at] if len(rid) else at
+    found = (rid[pos] == ids) if len(rid) else np.zeros(len(ids), bool)
+    po_i = po.astype(np.int64)
+    part = np.searchsorted(po_i, pos, side="right") - 1
+    ln = po_i[part + 1] - po_i[part]
+    local = pos - po_i[part]
+    j = np.arange(mb, dtype=np.int64)[None, :]
+    if arrays["codes_layout"] == _abi.CODES_PART_TRANSPOSED:
+        idx = po_i[part][:, None] * mb + j * ln[:, None] + local[:, None]
+    else:
+        idx = pos[:, None] * mb + j
+    stored = np.asarray(codes).reshape(-1)[np.where(found[:, None], idx, 0)]
+    n_found = int(found.sum())
+    same_part = found & (part == assign)
+    byte_eq = (stored == by_row) & same_part[:, None]
+    denom = max(int(same_part.sum()), 1)
+    out = {"rows": int(len(ids)), "found": n_found,
+           "partition_match": float(same_part.sum()) / max(n_found, 1),
+           "byte_match": float(byte_eq.sum()) / (denom * mb),
+           "code_match": float(byte_eq.all(axis=1).sum()) / denom}
+    out["ok"] = bool(n_found == len(ids) and out["partition_match"] >= min_partition_match and out["byte_match"] >= min_byte_match)
+    if strict and not out["ok"]:
+        raise InvalidInput(1, "the index does not decode to its own raw rows under the assumed lance layout "
+                              f"([EXT-2/3/4], lance_loader.py): {out}")
+    return out

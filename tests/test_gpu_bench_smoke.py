@@ -56,3 +56,25 @@ def test_default_bench_line_at_toy_sizes():
     rec = d["recall_at_10"]
     assert all(v for k2, v in rec.items() if k2.endswith("_rowids_bit_exact"))
     assert d["summary"]["c4_parity_ids"] is True and d["summary"]["c3_parity_ids"] is True
+
+
+def test_sharded_bench_path_in_a_world_of_one():
+    """Preflight of the driver's N > 1 run on the one GPU a test box has: `bench.py --gpus 1 --force-sharded-path`
+    under torch.distributed.run goes through everything an N-rank run goes through — process group, RCCL communicator behind the
+    C ABI, mi355_search_sharded with its packed all-gather and k-way merge, teardown — and must print ONE JSON line whose
+    sharded result equals the plain search.  The first 8-GPU run cannot then fail on plumbing."""
+    pytest.importorskip("torch")
+    for extra in ([], ["--shard-coarse", "--batch-per-gpu", "128"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded-path", "--n-rows", "3000000",
+               "--nlist", "512", "--batch", "256", "--steps", "3", "--warmup", "1"] + extra
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]  # (RCCL's banner goes to stderr: stdout carries the one line)
+        d = json.loads(lines[0])
+        assert len(lines[0]) < 4096 and d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+        mg = d["multi_gpu"]
+        assert mg["rccl_ranks"] == 1 and mg["sharded_equals_unsharded"] is True and mg["all_ranks_returned_the_same_results"] is True
+        assert mg["coarse"].startswith("sharded" if extra else "replicated")

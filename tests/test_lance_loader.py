@@ -78,3 +78,43 @@ def test_open_ivf_pq_on_the_device(oracle):
     ids, dist, cnt, _ = ref.search(q, k=10, nprobe_min=8, nprobe_max=8)
     assert (got.rowids == ids).all() and (got.distances == dist).all() and (got.counts == cnt).all()
     assert ix.stats()["scan_variant"] == _abi.SCAN_SKEW
+
+
+@pytest.mark.parametrize("nbits", [8, 4])
+def test_self_check_catches_a_wrong_layout_guess(oracle, nbits):
+    """verify_against_raw re-encodes sampled raw rows with the index's own centroids and codebook and compares partitions and code
+    bytes with what the index stores (here with the ORACLE's encoder: the check itself needs no GPU).  A trained index passes; each
+    wrong [EXT] guess — row-major storage read as transposed, a codebook read in the other layout, swapped nibbles — fails."""
+    rng = np.random.default_rng(4)
+    n, dim, nlist, m = 3000, 32, 8, 8
+    x = rng.normal(size=(n, dim)).astype(np.float32)
+    cen = x[rng.choice(n, nlist, replace=False)].copy()
+    cb = (rng.normal(size=(m, 1 << nbits, dim // m)) * 0.7).astype(np.float32)
+    po, codes, order, _ = oracle.ivfpq_encode(x, cen, cb, nbits=nbits)
+    s = {"centroids": cen, "codebook": cb, "part_offsets": po, "codes": codes, "row_ids": order.astype(np.uint64)}
+    pieces = _arrow_index(s, nbits)
+    enc = lambda v, c, b, metric="l2", nbits=8, return_assign=True: oracle.ivfpq_encode(v, c, b, metric=metric, nbits=nbits)  # noqa: E731
+    pick = rng.choice(n, 500, replace=False)
+    good = lance_loader.engine_arrays(*pieces, nbits=nbits)
+    rep = lance_loader.verify_against_raw(good, x[pick], pick.astype(np.uint64), encode=enc)
+    assert rep["ok"] and rep["found"] == 500 and rep["partition_match"] == 1.0 and rep["code_match"] == 1.0
+    # [EXT-3] wrong: the storage is transposed per partition, read as row-major
+    bad = lance_loader.engine_arrays(*pieces, nbits=nbits, transposed=False)
+    rep = lance_loader.verify_against_raw(bad, x[pick], pick.astype(np.uint64), encode=enc, strict=False)
+    assert not rep["ok"] and rep["byte_match"] < 0.5
+    with pytest.raises(Exception, match="does not decode to its own raw rows"):
+        lance_loader.verify_against_raw(bad, x[pick], pick.astype(np.uint64), encode=enc)
+    # [EXT-2] wrong: a sub-vector-major codebook handed over as code-major
+    cen_a, cb_a, codes_a, rid_a, off, ln = pieces
+    cb_sv = pa.FixedSizeListArray.from_arrays(pa.array(np.ascontiguousarray(cb).reshape(-1)), dim)  # [m * ks * dsub] cut into rows of dim
+    bad = lance_loader.engine_arrays(cen_a, cb_sv, codes_a, rid_a, off, ln, nbits=nbits)
+    rep = lance_loader.verify_against_raw(bad, x[pick], pick.astype(np.uint64), encode=enc, strict=False)
+    assert not rep["ok"]
+    if nbits == 4:  # [EXT-4] wrong: sub-quantiser 2t in the HIGH nibble
+        sw = dict(good)
+        sw["codes"] = ((good["codes"] >> 4) | (good["codes"] << 4)).astype(np.uint8)
+        rep = lance_loader.verify_against_raw(sw, x[pick], pick.astype(np.uint64), encode=enc, strict=False)
+        assert not rep["ok"] and rep["byte_match"] < 0.5
+    # rows the index does not hold
+    rep = lance_loader.verify_against_raw(good, x[pick[:10]], (pick[:10] + 10 ** 9).astype(np.uint64), encode=enc, strict=False)
+    assert not rep["ok"] and rep["found"] == 0

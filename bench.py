@@ -900,24 +900,52 @@ def recall_nlist(a):
     return 4096 if a.recall_rows >= 8_000_000 else 1024
 
 
-def recall_index(a, dim, m):
-    """The trained index of the recall leg (also used by tests/tools/parity_exposure.py): a Gaussian-mixture column,
-    IVF + residual PQ trained and the rows encoded by the engine's build entry points; everything stays on the device."""
+def recall_column(a, dim, data):
+    """The raw column and held-out queries of the recall legs, on the device.
+      "embedding": unit vectors of intrinsic dimension 48 with a power-law spectrum, x = normalise(z W + 2 % noise), z from a
+                   2000-cluster mixture — the shape of text-embedding columns; neighbours are separated by more than the PQ
+                   error, so nprobes AND refine_factor move recall (round 6: the one-index leg uses this set);
+      "mixture":   the isotropic 4096-component Gaussian mixture of rounds 1-5 (true top-10 within the PQ error of each other:
+                   recall without refine is PQ-limited, 0.21 at any nprobes) — kept for tests/tools/parity_exposure*.py."""
     import torch
-    import lancedb_amd
-    n, nlist, nq, dsub = a.recall_rows, recall_nlist(a), a.recall_queries, dim // m
+    n, nq = a.recall_rows, a.recall_queries
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
-    g.manual_seed(SEED)
-    n_comp = 4096
-    comps = torch.randn((n_comp, dim), generator=g, device=dev) * 1.5
+    if data == "mixture":
+        g.manual_seed(SEED)
+        n_comp = 4096
+        comps = torch.randn((n_comp, dim), generator=g, device=dev) * 1.5
+        x = torch.empty((n, dim), device=dev)
+        for r0 in range(0, n, 500_000):
+            c = min(500_000, n - r0)
+            x[r0:r0 + c] = comps[torch.randint(0, n_comp, (c,), generator=g, device=dev)] + torch.randn((c, dim), generator=g, device=dev)
+        q = comps[torch.randint(0, n_comp, (nq,), generator=g, device=dev)] + torch.randn((nq, dim), generator=g, device=dev)
+        return x, q, g, f"{n_comp}-component isotropic Gaussian mixture"
+    import numpy as np
+    g.manual_seed(SEED + 21)
+    idim, n_cl = 48, 2000
+    spec = 1.0 / torch.sqrt(1.0 + torch.arange(idim, device=dev, dtype=torch.float32))
+    W = torch.linalg.qr(torch.randn((dim, idim), generator=g, device=dev))[0].T.contiguous()  # [idim, dim], orthonormal rows
+    centers = torch.randn((n_cl, idim), generator=g, device=dev)
+
+    def draw(cnt):
+        z = (centers[torch.randint(0, n_cl, (cnt,), generator=g, device=dev)] + 0.35 * torch.randn((cnt, idim), generator=g, device=dev)) * spec
+        v = z @ W + 0.02 * torch.randn((cnt, dim), generator=g, device=dev) * float(spec.norm()) / np.sqrt(dim)
+        return v / v.norm(dim=1, keepdim=True)
     x = torch.empty((n, dim), device=dev)
     for r0 in range(0, n, 500_000):
-        c = min(500_000, n - r0)
-        x[r0:r0 + c] = comps[torch.randint(0, n_comp, (c,), generator=g, device=dev)] + torch.randn((c, dim), generator=g, device=dev)
-    q = comps[torch.randint(0, n_comp, (nq,), generator=g, device=dev)] + torch.randn((nq, dim), generator=g, device=dev)
-    iters = a.recall_iters
-    torch.cuda.synchronize()
+        x[r0:r0 + 500_000] = draw(min(500_000, n - r0))
+    return x, draw(nq), g, f"embedding-like: unit vectors of intrinsic dimension {idim} (power-law spectrum) from a {n_cl}-cluster mixture + 2 % isotropic noise"
+
+
+def train_and_encode(a, x, g, nlist, m):
+    """IVF centroids (sample_rate 256 rows per partition) and residual PQ codebooks (256 x 256 rows) trained for `--recall-iters`
+    Lloyd iterations, all rows encoded — by the engine's own build entry points (mi355_kmeans_train / mi355_ivf_residuals /
+    mi355_pq_train / mi355_ivfpq_encode; parameters as the reference's builder, rust/lancedb/src/index/vector.rs:61-119, :266-319)."""
+    import torch
+    import lancedb_amd
+    n, dim = x.shape
+    dsub, iters, dev = dim // m, a.recall_iters, x.device
     pick = torch.randperm(n, generator=g, device=dev)
     ivf_rows = x[pick[:min(n, 256 * nlist)].sort().values].contiguous()
     init = ivf_rows[torch.randperm(ivf_rows.shape[0], generator=g, device=dev)[:nlist].sort().values].contiguous()
@@ -943,90 +971,140 @@ def recall_index(a, dim, m):
     for r0 in range(0, n, 1_000_000):
         xs[r0:r0 + 1_000_000] = x[order[r0:r0 + 1_000_000].to(torch.int64)].to(torch.bfloat16)
     torch.cuda.synchronize()
-    return {"x": x, "q": q, "cen": cen, "codebook": codebook, "part_offsets": part_offsets, "codes": codes, "order": order,
-            "xs": xs, "n_comp": n_comp, "t_train": t_train, "t_enc": t_enc}
+    return {"cen": cen, "codebook": codebook, "part_offsets": part_offsets, "codes": codes, "order": order, "xs": xs,
+            "t_train": t_train, "t_enc": t_enc, "nlist": nlist, "m": m}
+
+
+def recall_index(a, dim, m, data="mixture"):
+    """One trained index over a recall column (tests/tools/parity_exposure*.py, trained_dev_counters.py); everything stays on the device."""
+    x, q, g, desc = recall_column(a, dim, data)
+    R = train_and_encode(a, x, g, recall_nlist(a), m)
+    R.update({"x": x, "q": q, "n_comp": 4096, "data": desc})
+    return R
+
+
+def host_truth_top10(np, x, hq, chunk=1_000_000):
+    """Exact top-10 (L2) of the host queries `hq` over the device column `x`, computed ON THE HOST with numpy's sgemm, chunk by
+    chunk — a truth that shares no code with the engine (the recall "truth" was the engine's own flat path)."""
+    nq = hq.shape[0]
+    best_d = np.full((nq, 10), np.inf, np.float32)
+    best_i = np.zeros((nq, 10), np.int64)
+    qq = (hq.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    for r0 in range(0, x.shape[0], chunk):
+        xc = x[r0:r0 + chunk].cpu().numpy()
+        d = (xc * xc).sum(1)[None, :] - 2.0 * (hq @ xc.T) + qq[:, None]
+        k = min(10, d.shape[1])
+        part = np.argpartition(d, k - 1, axis=1)[:, :k]
+        pd = np.take_along_axis(d, part, axis=1)
+        cat_d = np.concatenate([best_d, pd], axis=1)
+        cat_i = np.concatenate([best_i, part + r0], axis=1)
+        sel = np.argsort(cat_d, axis=1, kind="stable")[:, :10]
+        best_d, best_i = np.take_along_axis(cat_d, sel, axis=1), np.take_along_axis(cat_i, sel, axis=1)
+    return best_i
 
 
 def recall_at_10(a, np, dim, m):
-    """recall@10 of IVF-PQ search against exact flat search on a REAL index:
-    `--recall-rows` Gaussian-mixture vectors; IVF centroids (sample_rate 256 rows per partition) and
-    residual PQ codebooks (256 x 256 rows) trained for `--recall-iters` Lloyd iterations and all rows
-    encoded by the engine's own build entry points (mi355_kmeans_train / mi355_ivf_residuals /
-    mi355_pq_train / mi355_ivfpq_encode; parameters as the reference's builder,
-    rust/lancedb/src/index/vector.rs:61-119, :266-319); `--recall-queries` held-out queries.
-    Reported for the ENGINE and for the CPU ORACLE (same index, same queries): with bit-exact row ids
-    the two must be equal.  The 100 M throughput index has random codes, so recall is only
-    meaningful here; `nprobe64_refine10` is the operating point of `secondary.c3_refine10`."""
+    """queries/sec AND recall@10 on trained indexes over ONE embedding-like column (BASELINE.json's metric is
+    "queries/sec @ recall@10"): `--recall-rows` x `dim` rows, two indexes —
+      A: nlist 4096, m = 96 (C3's shape);  B: nlist = rows / 8192, m = dim / 16 (what the reference builds by default,
+         table/create_index.rs:741-794, index/vector.rs:306-319) —
+    each swept over nprobes x refine_factor with the bf16 raw column in HBM; every point carries its QPS (device-resident batches)
+    and its recall@10 against (i) the engine's exact flat search, all queries, and (ii) an independent host truth (numpy sgemm)
+    on the first 512; the CPU oracle answers 512 queries of three points per index row for row (ids must be ==).
+    `qps_at_recall`: the fastest point of each index reaching recall 0.95 / 0.99."""
     import torch
     import lancedb_amd
     from lancedb_amd import _abi
     t0 = time.perf_counter()
-    n, nlist, nq = a.recall_rows, recall_nlist(a), a.recall_queries
-    R = recall_index(a, dim, m)
-    x, q, cen, codebook, part_offsets, codes, order, xs = (R[k2] for k2 in ("x", "q", "cen", "codebook", "part_offsets", "codes", "order", "xs"))
-    iters, n_comp, t_train, t_enc = a.recall_iters, R["n_comp"], R["t_train"], R["t_enc"]
+    n, nq = a.recall_rows, a.recall_queries
+    x, q, g, desc = recall_column(a, dim, "embedding")
     dev = x.device
-    ix = lancedb_amd.IvfPqIndex(cen.contiguous(), codebook.contiguous(), part_offsets, codes, order,
-                                raw_vectors=xs.view(torch.int16), raw_dtype=_abi.DTYPE_BF16)
+    hq = q.cpu().numpy()
     fl = lancedb_amd.FlatIndex(x.contiguous())
     torch.cuda.synchronize()
-    hq = q.cpu().numpy()
     truth = fl.search(hq, k=10).rowids
     del fl
     torch.cuda.empty_cache()
-    out = {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "queries": nq, "truth": "exact flat search over the f32 column (engine flat path)",
-           "raw_column": "bf16, index order, in HBM (the refine points re-rank on it)",
-           "data": f"{n_comp}-component Gaussian mixture; IVF (sample_rate 256) + residual PQ trained by {iters} Lloyd "
-                   "iterations on the GPU (mi355_kmeans_train / mi355_pq_train), rows encoded by mi355_ivfpq_encode",
-           "train_seconds": round(t_train, 2), "encode_rows_per_s": round(n / t_enc)}
+    n_host = min(nq, 512)
+    t1 = time.perf_counter()
+    truth_host = host_truth_top10(np, x, hq[:n_host]) if a.cpu_seconds > 0 else None
+    out = {"n_rows": n, "dim": dim, "queries": nq, "data": desc,
+           "truth": "exact flat search over the f32 column (engine flat path), all queries; and numpy sgemm on the host for the first "
+                    f"{n_host} (independent of the engine)",
+           "raw_column": "bf16, index order, in HBM (the refine points re-rank on it)"}
+    if truth_host is not None:
+        agree = float(np.mean([len(set(truth[i].tolist()) & set(truth_host[i].tolist())) / 10.0 for i in range(n_host)]))
+        out["engine_flat_truth_vs_host_truth_overlap"] = round(agree, 5)
+        out["host_truth_seconds"] = round(time.perf_counter() - t1, 1)
 
-    def rec(ids, upto):
-        return round(float(np.mean([len(set(truth[i].tolist()) & set(ids[i].tolist())) / 10.0 for i in range(upto)])), 4)
-
-    ox = None
-    if a.cpu_seconds > 0:
-        from oracle import oracle as orc
-        orc.build()
-        ox = orc.OracleIndex(cen.cpu().numpy(), codebook.cpu().numpy(), part_offsets, codes.cpu().numpy(),
-                             order.cpu().numpy().astype(np.uint64), raw_vectors=xs.view(torch.int16).cpu().numpy().view(np.uint16),
-                             raw_dtype=_abi.DTYPE_BF16)
-    # the oracle answers the first `n_or` queries of every operating point (row for row against the engine; its recall is
-    # over those queries) — all 10 k on the host were 110 s of a 190 s bench run
-    n_or = min(nq, 2048)
-    out["cpu_oracle_queries"] = n_or
-    # QPS of every operating point ON THIS INDEX: device-resident batches of the held-out queries, results in HBM
+    def rec(ids, tr, upto):
+        return round(float(np.mean([len(set(tr[i].tolist()) & set(ids[i].tolist())) / 10.0 for i in range(upto)])), 4)
     B = min(a.batch, nq)
     qb = [q[i:i + B].contiguous() for i in range(0, nq - B + 1, B)][:4]
     dout = (torch.empty((B, 10), dtype=torch.int64, device=dev), torch.empty((B, 10), dtype=torch.float32, device=dev),
             torch.empty((B,), dtype=torch.int32, device=dev))
-    ix.set_stream(torch.cuda.current_stream().cuda_stream)
-    points = []
-    for nprobe, rf in ((64, 0), (64, 10), (64, 25), (64, 50), (16, 0)):
-        key = f"nprobe{nprobe}" + (f"_refine{rf}" if rf else "")
-        got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf).rowids
-        out[key] = rec(got, nq)
-        params = _abi.make_params(k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
-        for i in range(2):
-            ix.search(qb[i % len(qb)], params, out=dout)
-        torch.cuda.synchronize()
-        steps = max(4, a.steps // 2)
-        t1 = time.perf_counter()
-        for i in range(steps):
-            ix.search(qb[i % len(qb)], params, out=dout)
-        torch.cuda.synchronize()
-        qps = B * steps / (time.perf_counter() - t1)
-        out[key + "_queries_per_s"] = round(qps, 1)
-        pt = {"index": f"trained {n}x{dim} nlist{nlist} m{m} (this leg)", "nprobe": nprobe, "refine_factor": rf, "batch_queries": B,
-              "queries_per_s": round(qps, 1), "recall_at_10": out[key]}
+    small = n < 2_000_000  # (toy runs)
+    # (on this column a query's neighbours sit in a handful of partitions: recall saturates at a few probes, and the 48-byte codes
+    #  of index B need a deeper re-rank than A's 96-byte codes to reach the same recall)
+    shapes = (("A", recall_nlist(a), m, (1, 4, 16, 64), (0, 5, 10)), ("B", max(8, n // 8192), dim // 16, (1, 5, 20), (0, 5, 10, 20)))
+    points, n_or = [], min(nq, 512)
+    for name, nlist, m_i, nprobes, rfs in shapes:
+        nprobes = tuple(p_ for p_ in nprobes if p_ <= nlist)
+        # the oracle answers three points per index: the widest probe list without and with refine, a narrower one with refine
+        oracle_pts = ((nprobes[-1], 0), (nprobes[-1], 10), (nprobes[max(0, len(nprobes) - 2)], 5))
+        R = train_and_encode(a, x, g, nlist, m_i)
+        ix = lancedb_amd.IvfPqIndex(R["cen"].contiguous(), R["codebook"].contiguous(), R["part_offsets"], R["codes"], R["order"],
+                                    raw_vectors=R["xs"].view(torch.int16), raw_dtype=_abi.DTYPE_BF16)
+        ix.set_stream(torch.cuda.current_stream().cuda_stream)
+        lens = np.diff(np.asarray(R["part_offsets"]).astype(np.int64))
+        meta = {"nlist": nlist, "m": m_i, "train_seconds": round(R["t_train"], 2), "encode_rows_per_s": round(n / R["t_enc"]),
+                "partition_rows_median": int(np.median(lens)), "partition_rows_max": int(lens.max())}
+        ox = None
+        if a.cpu_seconds > 0:
+            from oracle import oracle as orc
+            orc.build()
+            ox = orc.OracleIndex(R["cen"].cpu().numpy(), R["codebook"].cpu().numpy(), R["part_offsets"], R["codes"].cpu().numpy(),
+                                 R["order"].cpu().numpy().astype(np.uint64), raw_vectors=R["xs"].view(torch.int16).cpu().numpy().view(np.uint16),
+                                 raw_dtype=_abi.DTYPE_BF16)
+        for nprobe in nprobes:
+            for rf in rfs:
+                got = ix.search(hq, k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf).rowids
+                params = _abi.make_params(k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+                for i in range(2):
+                    ix.search(qb[i % len(qb)], params, out=dout)
+                torch.cuda.synchronize()
+                steps = 3 if small else max(4, a.steps // 2)
+                t1 = time.perf_counter()
+                for i in range(steps):
+                    ix.search(qb[i % len(qb)], params, out=dout)
+                torch.cuda.synchronize()
+                qps = B * steps / (time.perf_counter() - t1)
+                pt = {"index": name, "nlist": nlist, "m": m_i, "nprobe": nprobe, "refine_factor": rf, "batch_queries": B,
+                      "queries_per_s": round(qps, 1), "recall_at_10": rec(got, truth, nq), "rows_scanned_per_query": int(ix.stats()["vectors_scanned"] // max(ix.stats()["n_queries"], 1))}
+                if truth_host is not None:
+                    pt["recall_at_10_vs_host_truth"] = rec(got, truth_host, n_host)
+                if ox is not None and (nprobe, rf) in oracle_pts:
+                    o_ids, _, _, _ = ox.search(hq[:n_or], k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
+                    pt["recall_at_10_cpu_oracle"] = rec(o_ids, truth, n_or)
+                    pt["recall_at_10_engine_same_queries"] = rec(got, truth, n_or)
+                    pt["rowids_bit_exact_vs_oracle"] = bool((o_ids == got[:n_or]).all())
+                    out[f"{name}_nprobe{nprobe}_refine{rf}_rowids_bit_exact"] = pt["rowids_bit_exact_vs_oracle"]
+                points.append(pt)
+        at = {}
+        for target in (0.95, 0.99):
+            ok = [p_ for p_ in points if p_["index"] == name and p_["recall_at_10"] >= target]
+            if ok:
+                best = max(ok, key=lambda p_: p_["queries_per_s"])
+                at[str(target)] = {k2: best[k2] for k2 in ("queries_per_s", "recall_at_10", "nprobe", "refine_factor")}
+        meta["qps_at_recall"] = at
+        out["index_" + name] = meta
         if ox is not None:
-            o_ids, _, _, _ = ox.search(hq[:n_or], k=10, nprobe_min=nprobe, nprobe_max=nprobe, refine_factor=rf)
-            out[key + "_cpu_oracle"] = rec(o_ids, n_or)
-            out[key + "_engine_same_queries"] = rec(got, n_or)
-            out[key + "_rowids_bit_exact"] = bool((o_ids == got[:n_or]).all())
-            pt.update({"recall_at_10_cpu_oracle": out[key + "_cpu_oracle"], "recall_at_10_engine_same_queries": out[key + "_engine_same_queries"],
-                       "rowids_bit_exact_vs_oracle": out[key + "_rowids_bit_exact"]})
-        points.append(pt)
+            ox.close()
+        ix.close()
+        del ix, R
+        torch.cuda.empty_cache()
     out["points"] = points
+    out["cpu_oracle_queries"] = n_or
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 

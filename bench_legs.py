@@ -710,10 +710,18 @@ def summary_of(result):
          "flat_cos_qps": v(sec, "flat_c2_cosine", "value"), "flat_cos_gemm_frac": v(sec, "flat_c2_cosine", "roofline", "frac"),
          "lat_p50_us": v(sec, "latency_c3", "single_query_us_eager", "p50"), "lat_p99_us": v(sec, "latency_c3", "single_query_us_eager", "p99"),
          "c1_engine_us": v(sec, "c1_flat", "engine_single_query_us", "p50"), "c1_cpu_us": v(sec, "c1_flat", "cpu_baseline", "us_per_query"),
-         "recall10": v(result, "recall_at_10", "nprobe64"), "recall10_rf25": v(result, "recall_at_10", "nprobe64_refine25"),
-         "trained_index_rows": v(result, "recall_at_10", "n_rows"),
-         "trained_qps_rf0": v(result, "recall_at_10", "nprobe64_queries_per_s"), "trained_qps_rf10": v(result, "recall_at_10", "nprobe64_refine10_queries_per_s"),
-         "trained_qps_rf25": v(result, "recall_at_10", "nprobe64_refine25_queries_per_s"), "recall10_rf10": v(result, "recall_at_10", "nprobe64_refine10")}
+         "trained_index_rows": v(result, "recall_at_10", "n_rows")}
+    # QPS at a recall the trained indexes deliver (one embedding-like column; A = nlist 4096 m 96, B = rows / 8192 partitions m = dim / 16):
+    # [queries/s, recall@10, nprobes, refine_factor] of the fastest point reaching the target
+    for ixn in ("A", "B"):
+        for target in ("0.95", "0.99"):
+            d = v(result, "recall_at_10", "index_" + ixn, "qps_at_recall", target)
+            if d:
+                s[f"qps_at_recall{target}_{ixn}"] = [round(d["queries_per_s"]), d["recall_at_10"], d["nprobe"], d["refine_factor"]]
+    pts = (result.get("recall_at_10") or {}).get("points") or []
+    ex = [p for p in pts if "rowids_bit_exact_vs_oracle" in p]
+    if ex:
+        s["trained_parity_ids"] = all(p["rowids_bit_exact_vs_oracle"] for p in ex)
     # the reference's DEFAULT index shape (rows / 8192 partitions, m = dim / 16) at its default nprobes 20, and at 64
     for np_ in (20, 64):
         d = sec.get("default_shape", {}).get(f"nprobe{np_}")

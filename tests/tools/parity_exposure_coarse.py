@@ -4,7 +4,8 @@ The contract (oracle/ann_oracle.c, every kernel) scores a centroid with the expa
 dot products d-ascending fmaf chains — the form that is a GEMM.  lance's partition finder most likely computes l2(q, c)
 directly, with SIMD lane accumulators ([EXT], lance-linalg is not in the container).  The two forms round differently, so the
 nprobes-th and (nprobes + 1)-th nearest partitions can swap: a different partition is scanned, and the top-10 MAY change.
-On the trained index of the bench's recall leg (10 M x 768 Gaussian mixture, nlist 4096, m 96) this tool measures, at
+On the trained index of the bench's recall leg (10 M x 768, nlist 4096, m 96; the embedding-like column or rounds 1-5's
+Gaussian mixture) this tool measures, at
 nprobes 20 and 64:
   * how many queries get a different probe SET under (a) a direct, non-fused, 16-lane-summed f32 l2 and (b) float64;
   * how many of those queries then return a different top-10 (ids), by scanning the alternative probe list with the engine
@@ -12,7 +13,7 @@ nprobes 20 and 64:
 The engine's own probe list is taken from mi355_coarse_topn and cross-checked against a numpy restatement of the contract
 on a sample.
 
-usage (GPU box): python tests/tools/parity_exposure_coarse.py [queries] [rows] > profiles/r06_parity_exposure.json"""
+usage (GPU box): python tests/tools/parity_exposure_coarse.py [queries] [rows] [embedding|mixture] > profiles/r06_parity_exposure.json"""
 import json
 import os
 import sys
@@ -26,10 +27,11 @@ import bench  # noqa: E402
 
 NQ = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 ROWS = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+DATA = sys.argv[3] if len(sys.argv) > 3 else "embedding"  # bench.recall_column: "embedding" (the bench's recall leg) | "mixture" (rounds 1-5)
 a = types.SimpleNamespace(recall_rows=ROWS, recall_queries=NQ, recall_iters=25)
 dim, m = 768, 96
 t0 = time.perf_counter()
-R = bench.recall_index(a, dim, m)
+R = bench.recall_index(a, dim, m, data=DATA)
 import torch  # noqa: E402
 import lancedb_amd  # noqa: E402
 
@@ -75,7 +77,7 @@ def probes_of(score, nprobe):
     return np.lexsort((np.arange(nlist), score))[:nprobe]
 
 
-res = {"index": f"bench.py recall index: {ROWS} x 768 Gaussian mixture, nlist {nlist}, m 96, trained + encoded by the engine",
+res = {"index": f"bench.py recall index: {ROWS} x 768, {R['data']}, nlist {nlist}, m 96, trained + encoded by the engine",
        "queries": NQ,
        "forms": {"contract": "fmaf(-2, q.c, |q|^2 + |c|^2), d-ascending fmaf chains (oracle/ann_oracle.c; every kernel)",
                  "direct_16_lanes": "sum (q - c)^2, products not fused, 16 f32 lane accumulators, tree reduction ([EXT] model of an AVX2 build)",

@@ -105,6 +105,8 @@ def parse():
                     help="rows of the leg at the reference's DEFAULT index shape (rows / 8192 partitions, m = dim / 16, nprobes 20 and 64); 0 = skip")
     ap.add_argument("--widths", type=int, default=1, help="secondary lines at the reference's default PQ widths m = dim / 16 (384-d, 3072-d); 0 = skip")
     ap.add_argument("--gist-rows", type=int, default=1_000_000, help="rows of the GIST1M-shaped recall@1 / latency line; 0 = skip")
+    ap.add_argument("--c5-column", default="register", choices=["register", "hostmalloc"],
+                    help="C5 host column: the caller's pages registered with hipHostRegister (default) or a hipHostMalloc allocation (A/B of the PCIe gather)")
     ap.add_argument("--c5-hugepages", type=int, default=0, help="back the C5 host column with MADV_HUGEPAGE memory (A/B of the PCIe gather)")
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--slice-rows", type=int, default=0)
@@ -703,7 +705,12 @@ def c5_refine10(a, torch, np, dev):
     # depend on the values); host: filled by 64 threads from one random block
     t_raw = time.perf_counter()
     if host_mapped:
-        raw = host_column(np, n, dim, a.c5_hugepages)
+        col_alloc = None
+        if getattr(a, "c5_column", "register") == "hostmalloc":  # dev A/B: pages allocated AND mapped by the HIP runtime
+            col_alloc = lancedb_amd.HostAllocArray((n, dim), np.uint16)
+            raw = col_alloc.host
+        else:
+            raw = host_column(np, n, dim, a.c5_hugepages)
         flat = raw.reshape(-1)
         blk = np.random.default_rng(SEED + 6).integers(0, 0x4000, size=1 << 27, dtype=np.uint16)  # 256 MB
 
@@ -717,7 +724,7 @@ def c5_refine10(a, torch, np, dev):
         [t.join() for t in th]
         t_fill = time.perf_counter() - t_raw
         t_raw = time.perf_counter()
-        col = lancedb_amd.HostMappedArray(raw)
+        col = col_alloc if col_alloc is not None else lancedb_amd.HostMappedArray(raw)
         t_map = time.perf_counter() - t_raw
     else:
         col = torch.empty((n, dim), dtype=torch.int16, device=dev)
@@ -770,7 +777,8 @@ def c5_refine10(a, torch, np, dev):
                    "raw_vectors": "host memory, page-locked + mapped, gathered over PCIe" if host_mapped else "HBM (host RAM too small)",
                    "host_mem_usable_gb": round(avail / 1e9), "build_s": round(t_build, 1), "raw_fill_s": round(t_fill, 1),
                    "raw_page_lock_s": round(t_map, 2)},
-        "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge", "refine")},
+        "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "plan", "scan", "merge", "refine")},
+        "lut_images": st["lut_images"],
         "refine_gather": {"algorithmic_bytes_per_step": refine_bytes, "gb_per_s": refine_bytes / max(st["us_refine"] / steps, 1e-9) / 1e3,
                           "peak": "PCIe Gen5 x16 ≈ 64 GB/s per direction" if host_mapped else "HBM 8 TB/s",
                           "rows_per_step": B * k * rf, "row_bytes": row_bytes},

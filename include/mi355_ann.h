@@ -278,7 +278,7 @@ enum {
   /* opt-out: build every PQ distance table inside its scan work item.  By default an index whose sub-vectors are 16
      floats long (num_sub_vectors = dim / 16, the reference's default: rust/lancedb/src/index/vector.rs:306-319) gets the
      tables of a whole batch from one batch-level kernel that keeps the codebook in registers (k * refine_factor <= 128;
-     up to 8 GiB of table images in HBM per batch chunk, falling back to in-item builds when HBM is full).  Results are
+     up to 16 GiB of table images in HBM per batch chunk, falling back to in-item builds when HBM is full).  Results are
      bit-identical either way (same operations in the same order); the bit is for A/B measurements and tests. */
   MI355_CFG_LUT_INLINE = 0x800u
 };

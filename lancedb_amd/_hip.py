@@ -147,3 +147,43 @@ class HostMappedArray:
 
 def synchronize():
     _check(runtime().hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+
+class HostAllocArray:
+    """A LIBRARY-allocated page-locked host array (hipHostMalloc, mapped, coherent): the other way a raw column can live in
+    host memory — `HostMappedArray` registers pages the caller already owns (hipHostRegister).  Used by the C5 A/B of the
+    PCIe gather (tests/tools/c5_gather_ab.py --c5-column hostmalloc): same rows, same kernel, the only difference is who
+    allocated (and how the driver mapped) the pages.  `host` is a numpy view of the memory."""
+    is_cuda = True
+
+    def __init__(self, shape, dtype, device=0, flags=0):
+        self.shape = tuple(int(x) for x in shape)
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        rt = runtime()
+        rt.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        rt.hipHostFree.argtypes = [C.c_void_p]
+        rt.hipHostGetDevicePointer.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint]
+        _check(rt.hipSetDevice(C.c_int(device)), "hipSetDevice")
+        self._hp = C.c_void_p()
+        _check(rt.hipHostMalloc(C.byref(self._hp), C.c_size_t(max(self.nbytes, 16)), C.c_uint(flags)), f"hipHostMalloc({self.nbytes} B)")
+        self._dp = C.c_void_p()
+        _check(rt.hipHostGetDevicePointer(C.byref(self._dp), self._hp, C.c_uint(0)), "hipHostGetDevicePointer")
+        buf = (C.c_char * max(self.nbytes, 16)).from_address(self._hp.value)
+        self.host = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape, dtype=np.int64))).reshape(self.shape)
+
+    def data_ptr(self):
+        return self._dp.value or 0
+
+    def close(self):
+        if getattr(self, "_hp", None):
+            self.host = None
+            runtime().hipHostFree(self._hp)
+            self._hp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -223,12 +223,14 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   // Distance tables of the whole chunk by the batch-level kernels (kernels_lut.h) instead of one build per work item: where
   // the shape qualifies (dsub 16: the reference's m = dim / 16), for candidate lists the image kernels are instantiated
   // for, and not for a maximum_nprobes second pass (device-side batch size: its slots are mostly inactive).  The images
-  // get their own budget (4 * M bytes per code row and pair: 48 KiB at m = 48); if they cannot be allocated the work
+  // get their own budget (4 * M bytes per code row and pair: 48 KiB at m = 48, 16 GiB in all); if they cannot be allocated the work
   // items build their tables as before.
   bool lut_img = skew && ix->lut_img_ok && !ix->lut_inline_cfg && pl.kk <= 128u && !pl.act.n && dev_knob("MI355_LUT_IMAGES", 1);
   if (lut_img) {
     const size_t per_q_img = (size_t)nprobe * (lut_image_bytes_per_pair(ix) + lut_residual_bytes_per_pair(ix));
-    const size_t img_budget = (size_t)dev_knob("MI355_LUT_IMAGES_MB", 8192) << 20;
+    // (16 GiB: a C5 batch — 2048 queries x 64 probes x 96 KiB — must stay ONE chunk, or its deferred re-rank falls back to
+    //  the serial path: a batch cut in two by an 8 GiB budget ran 35.5 ms per step where the overlapped one takes 24)
+    const size_t img_budget = (size_t)dev_knob("MI355_LUT_IMAGES_MB", 16384) << 20;
     const uint32_t chunk_img = (uint32_t)std::max<size_t>(1, img_budget / std::max<size_t>(per_q_img, 1));
     const uint32_t c2 = std::min(chunk, chunk_img);
     if (ix->w_lutimg.ensure((size_t)c2 * nprobe * lut_image_bytes_per_pair(ix)) != MI355_OK ||

@@ -17,4 +17,5 @@ a.cpu_seconds = 0
 torch.cuda.set_device(0)
 r = bench.c5_refine10(a, torch, np, torch.device("cuda", 0))
 print(json.dumps({"qps": r.get("value"), "stage_us": r.get("stage_us_per_step"), "gather": r.get("refine_gather"),
-                  "rows": r.get("config", {}).get("n_rows"), "hugepages": a.c5_hugepages}))
+                  "rows": r.get("config", {}).get("n_rows"), "hugepages": a.c5_hugepages, "column": a.c5_column,
+                  "page_lock_s": r.get("config", {}).get("raw_page_lock_s"), "fill_s": r.get("config", {}).get("raw_fill_s")}))

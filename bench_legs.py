@@ -131,12 +131,17 @@ def timed_steps(torch, ix, qpool, params, out, steps, warmup=2, searcher=None):
 
 def scan_line(st, steps, B, dt, n_cus=256):
     """The section-8d numbers of a run: algorithmic code bytes (m bytes per scanned row) over the scan kernel's own time."""
-    us = st["us_scan"] / max(steps, 1)
+    # (round 6: us_scan is the scan kernel alone; the planner and — for dim / m = 16 shapes — the batch-level distance tables are
+    #  us_plan.  The section-8d fraction of a line counts BOTH: a table kernel is part of what a scanned byte costs.)
+    us_scan_only = st["us_scan"] / max(steps, 1)
+    us = (st["us_scan"] + st.get("us_plan", 0.0)) / max(steps, 1)
     by = st["code_bytes_scanned"] / max(steps, 1)
     gbs = by / max(us, 1e-9) / 1e3
     return {"value": B / dt, "unit": "queries/s", "ms_per_step": dt * 1e3, "steps": steps,
-            "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "scan", "merge")},
+            "stage_us_per_step": {s2: st["us_" + s2] / steps for s2 in ("coarse", "select", "plan", "scan", "merge") if "us_" + s2 in st},
+            "lut_images": st.get("lut_images", 0),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "frac_scan_kernel_alone": by / max(us_scan_only, 1e-9) / 1e3 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": by, "us_per_launch": us,
                          "lds_gather_frac": by / max(us * 1e-6, 1e-12) / (n_cus * 32 * 2.4e9),
                          "frac_definition": "no-reuse algorithmic code bytes / scan-kernel time / 8 TB/s (SURVEY.md section 8d)"},
@@ -382,11 +387,10 @@ def default_shape_leg(a, torch, np, dev, n_rows=100_000_000, dim=768, parity_que
             dt, st, last = timed_steps(torch, ix, qpool, params, outb, steps)
             line = scan_line(st, steps, B, dt, n_cus)
             us_plan = st["us_plan"] / steps
-            by = st["code_bytes_scanned"] / steps
             line["stage_us_per_step"]["plan_and_tables"] = us_plan
-            line["lut_images"] = st["lut_images"]
-            line["roofline"]["frac_tables_plus_scan"] = by / max(line["roofline"]["us_per_launch"] + us_plan, 1e-9) / 1e3 / HBM_PEAK_GBS
-            line["tables_share_of_tables_plus_scan"] = us_plan / max(us_plan + line["roofline"]["us_per_launch"], 1e-9)
+            line["roofline"]["frac_tables_plus_scan"] = line["roofline"]["frac"]
+            line["roofline"]["frac"] = line["roofline"]["frac_scan_kernel_alone"]  # (this leg quotes the scan kernel and the sum side by side)
+            line["tables_share_of_tables_plus_scan"] = us_plan / max(line["roofline"]["us_per_launch"], 1e-9)
             line["rowid_checksum"] = int(torch.as_tensor(last.rowids).to(torch.int64).sum().item())
             line["distance_checksum"] = float(torch.as_tensor(last.distances).double().sum().item())
             legs[name] = line
@@ -421,7 +425,7 @@ def default_shape_leg(a, torch, np, dev, n_rows=100_000_000, dim=768, parity_que
         eng_rows = ix.stats()["vectors_scanned"]
         res["cpu_baseline"] = {
             "value": nq / t_cpu, "unit": "queries/s", "cores": host_cores()["usable"], "kind": "port",
-            "sample": f"{nq} queries at nprobes 20, one per thread, {t_cpu:.1f} s, on a host copy of the {len(parts)} partitions they probe",
+            "sample": f"{nq} queries at nprobes 20, one per thread, {t_cpu * 1e3:.0f} ms, on a host copy of the {len(parts)} partitions they probe",
             "parity": {"queries": nq, "rowids_bit_exact": bool((got.rowids.cpu().numpy().astype(np.uint64) == o_ids).all()),
                        "distances_equal": bool((got.distances.cpu().numpy() == o_dist).all()),
                        "counts_equal": bool((got.counts.cpu().numpy().astype(np.uint32) == o_cnt).all()),
@@ -774,14 +778,16 @@ def compact_line(result):
         if isinstance(line.get(k), float):
             line[k] = round(line[k], 4)
     cfg = dict(result.get("config", {}))
+    for k in ("index_open_s", "partitions_on_rank0", "rows_on_rank0", "partition_skew_sigma", "scan_variant"):  # (in bench_detail.json)
+        cfg.pop(k, None)
     line["config"] = {k: _short(v, 96) for k, v in cfg.items()}
     rf = result.get("roofline")
     if rf:
         r = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "hbm_measured_frac",
                                 "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "us_per_launch", "launches") if k in rf}
         r = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
-        r["frac_definition"] = _short(rf.get("frac_definition"), 120)
-        r["traffic_source"] = _short(rf.get("traffic_source"), 100)
+        r["frac_definition"] = _short(rf.get("frac_definition"), 90)
+        r["traffic_source"] = _short(rf.get("traffic_source"), 60)
         if isinstance(rf.get("lds_gather"), dict):
             r["lds_gather"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rf["lds_gather"].items() if k in ("achieved", "peak", "unit", "frac")}
         if "stage_us_per_step" in rf:
@@ -792,21 +798,21 @@ def compact_line(result):
         c = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
         if isinstance(c.get("value"), float):
             c["value"] = round(c["value"], 4)
-        c["sample"] = _short(cb.get("sample"), 200)
+        c["sample"] = _short(cb.get("sample"), 130)
         c["parity"] = cb.get("parity")
-        c["parity_caveat"] = ("bit-exact vs the repo's CPU restatement (oracle/ann_oracle.c), not the lance-index binary; expected top-10 id "
-                              "mismatch under another f32 summation order ~0.05 % (profiles/r03_l_parity_exposure.json)")
+        c["parity_caveat"] = ("bit-exact vs the repo's CPU restatement (oracle/ann_oracle.c), NOT the lance-index binary; another f32 "
+                              "summation order changes a top-10 id for ~0.05 % of queries (profiles/r03_l_*, r06_parity_exposure.json)")
         line["cpu_baseline"] = c
     mg = result.get("multi_gpu")
     if mg:
         line["multi_gpu"] = {k: mg[k] for k in ("rccl_ranks", "gathers_per_step", "bytes_gathered_per_step", "load_imbalance_max_over_mean",
                                                 "exchange_overlapped_with_next_scan", "coarse", "batch_queries",
                                                 "all_ranks_returned_the_same_results", "sharded_equals_unsharded") if k in mg}
-    line["detail"] = "bench_detail.json (the full document: every secondary leg, recall tables, per-rank stage times)"
+    line["detail"] = "bench_detail.json = the full document"
     summ = dict(result.get("summary") or {})
     line["summary"] = summ  # LAST key
     # the summary's nested tables go first if the line is still too long
-    soft = LINE_LIMIT - 512  # margin for longer numbers / workload names than the ones this was sized on
+    soft = LINE_LIMIT - 200  # margin for longer numbers / workload names than the ones this was sized on
     for drop in ("gist_like", "qps_vs_batch", "callers_qps"):
         if len(json.dumps(line)) < soft:
             break

@@ -9,7 +9,8 @@
 
 // 8-bit codes on the production scan with sub-vectors of 16 floats (the kernels are instantiated for that length)
 bool lut_images_shape_ok(const mi355_index* ix) {
-  return ix->layout == MI355_SCAN_SKEW && ix->nbits == 8 && ix->dsub == 16 && ix->m * ix->dsub == ix->dim;
+  const bool ds_ok = ix->dsub == 16 || (ix->dsub == 8 && dev_knob("MI355_LUT_IMAGES_DS8", 0));  // (dsub 8: dev A/B, see NOTES 11.8)
+  return ix->layout == MI355_SCAN_SKEW && ix->nbits == 8 && ds_ok && ix->m * ix->dsub == ix->dim;
 }
 size_t lut_image_bytes_per_pair(const mi355_index* ix) { return (size_t)ix->sk_slabs * 256u * ix->sk_M * sizeof(float); }
 size_t lut_residual_bytes_per_pair(const mi355_index* ix) { return (size_t)lut_res_stride(ix->m, ix->dsub) * sizeof(float); }
@@ -28,12 +29,16 @@ int32_t launch_lut_images(mi355_index* ix, const float* qp, const SkewItem* item
   const dim3 grid(lanes, col_blocks, halves);
   const uint32_t warm = dev_knob("MI355_LUT_WARM_AHEAD", 8);  // (pairs ahead of the L2 warm-up, 0 = off)
   const uint32_t dbg = dev_knob("MI355_LUT_DBG", 0) << 1;      // (dev: 1 = no image stores, 2 = all stores over one image)
-  if (ix->metric == MI355_METRIC_DOT)
-    hipLaunchKernelGGL((k_lut_images<16, true>), grid, dim3(LUT_NT), 0, st, res, ix->codebook.as<float>(), q_start, n_slices, ix->m, ix->sk_M,
-                       ix->sk_slabs, warm, dbg, img);
-  else
-    hipLaunchKernelGGL((k_lut_images<16, false>), grid, dim3(LUT_NT), 0, st, res, ix->codebook.as<float>(), q_start, n_slices, ix->m, ix->sk_M,
-                       ix->sk_slabs, warm, dbg, img);
+#define LAUNCH_LUT(DS, DOT)                                                                                                            \
+  hipLaunchKernelGGL((k_lut_images<DS, DOT>), grid, dim3(LUT_NT), 0, st, res, ix->codebook.as<float>(), q_start, n_slices, ix->m, ix->sk_M, \
+                     ix->sk_slabs, warm, dbg, img)
+  const bool dot = ix->metric == MI355_METRIC_DOT;
+  if (ix->dsub == 16) {
+    if (dot) LAUNCH_LUT(16, true); else LAUNCH_LUT(16, false);
+  } else {
+    if (dot) LAUNCH_LUT(8, true); else LAUNCH_LUT(8, false);
+  }
+#undef LAUNCH_LUT
   HIP_TRY(hipGetLastError());
   return MI355_OK;
 }

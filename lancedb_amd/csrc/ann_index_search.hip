@@ -251,20 +251,17 @@ static int32_t search_locked(mi355_index* ix, const std::vector<SearchCall>& all
   uint32_t timeout_left = p->timeout_ms;
   if (per_call) per_call->assign(all_calls.size(), MI355_OK);
   if (p->timeout_ms) {
-    const auto now = std::chrono::steady_clock::now();
-    long long worst = 0;
-    for (size_t i = 0; i < all_calls.size(); ++i) {
-      const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(now - all_calls[i].t0).count();
-      if (waited >= (long long)p->timeout_ms) {
-        worst = std::max(worst, waited);
-        if (per_call) (*per_call)[i] = MI355_ERR_TIMEOUT;
-      } else {
-        timeout_left = std::min(timeout_left, p->timeout_ms - (uint32_t)waited);
-        live_at.push_back(i);
-      }
+    std::vector<std::chrono::steady_clock::time_point> t0s;
+    for (const SearchCall& c : all_calls) t0s.push_back(c.t0);
+    const DeadlineSplit ds = split_by_deadline(t0s, std::chrono::steady_clock::now(), p->timeout_ms);  // (call_queue.h)
+    timeout_left = ds.timeout_left;
+    live_at = ds.live;
+    if (per_call) {
+      per_call->assign(all_calls.size(), MI355_ERR_TIMEOUT);
+      for (size_t i : live_at) (*per_call)[i] = MI355_OK;
     }
     if (live_at.empty() || (!per_call && live_at.size() != all_calls.size()))
-      return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms (before the device was reached)", worst, p->timeout_ms);
+      return fail(MI355_ERR_TIMEOUT, "Query timeout: %lld ms > %u ms (before the device was reached)", ds.worst_wait_ms, p->timeout_ms);
     if (live_at.size() != all_calls.size())
       for (size_t i : live_at) live_calls.push_back(all_calls[i]);
   }

@@ -47,6 +47,34 @@ static inline void cq_futex_wake_all(std::atomic<uint32_t>* a) {
   (void)syscall(SYS_futex, (uint32_t*)a, FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0);
 }
 
+// The deadline rule of a coalesced batch (QueryExecutionOptions.timeout is per query, rust/lancedb/src/query.rs:641): every call is
+// held against ITS OWN entry time.  -> the calls that still have budget (`live`, indices into t0) and the smallest budget left
+// among them (what the device is armed with); `worst_wait_ms` = the longest wait among the expired ones (for the message).
+// Free of HIP like the queue: tests/tools/queue_stress.cpp checks it on the CPU.
+struct DeadlineSplit {
+  std::vector<size_t> live;
+  uint32_t timeout_left = 0;
+  long long worst_wait_ms = 0;
+};
+static inline DeadlineSplit split_by_deadline(const std::vector<std::chrono::steady_clock::time_point>& t0,
+                                              std::chrono::steady_clock::time_point now, uint32_t timeout_ms) {
+  DeadlineSplit d;
+  d.timeout_left = timeout_ms;
+  for (size_t i = 0; i < t0.size(); ++i) {
+    const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(now - t0[i]).count();
+    if (timeout_ms && waited >= (long long)timeout_ms) {
+      d.worst_wait_ms = waited > d.worst_wait_ms ? waited : d.worst_wait_ms;
+    } else {
+      if (timeout_ms) {
+        const uint32_t left = timeout_ms - (uint32_t)(waited > 0 ? waited : 0);
+        d.timeout_left = left < d.timeout_left ? left : d.timeout_left;
+      }
+      d.live.push_back(i);
+    }
+  }
+  return d;
+}
+
 template <class W>  // W derives from QueueWaiter
 struct CallQueue {
   std::mutex mu;

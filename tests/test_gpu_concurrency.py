@@ -294,3 +294,55 @@ def test_two_hundred_native_threads_each_get_their_own_results():
         got, qps = run(threads, per)
         assert got == one, (threads, got, one)
         print(f"{threads} native threads: {qps:.0f} QPS")
+
+
+def test_a_timeout_is_a_calls_own_in_a_coalesced_batch(oracle):
+    """QueryExecutionOptions.timeout is per query (rust/lancedb/src/query.rs:641).  Round 5 armed a coalesced batch with its OLDEST
+    call's deadline: one call that had expired while parked failed the whole batch — newcomers included — and, the queue being
+    collected front to back, every batch after it.  Now an expired call gets status 3 alone.  48 threads hammer a
+    handle with a budget a parked call sometimes misses: every call must end OK with exact results or with Timeout, and the OK
+    calls must be the bulk — with the cascade they were almost none."""
+    s = train.synthetic_index(400000, 128, 64, 32, seed=6, skew=0.5)
+    ix = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
+    rng = np.random.default_rng(2)
+    n_threads, per_thread = 48, 30
+    qs = rng.normal(size=(n_threads, 128)).astype(np.float32)
+    kw = dict(k=10, nprobe_min=64, nprobe_max=64)
+    exp = [o.search(qs[t:t + 1], **kw) for t in range(n_threads)]
+    # how long one coalesced round of everybody takes on this box: the budget is about one and a half such rounds
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ix.search(qs, **kw)
+    round_ms = (time.perf_counter() - t0) / 5 * 1e3
+    budget = max(2, int(round_ms * 1.5 + 1))
+    ok, late, errors = [0] * n_threads, [0] * n_threads, []
+    barrier = threading.Barrier(n_threads)
+
+    def worker(t):
+        try:
+            barrier.wait()
+            for i in range(per_thread):
+                try:
+                    got = ix.search(qs[t:t + 1], timeout_ms=budget, **kw)
+                except lancedb_amd.QueryTimeout:
+                    late[t] += 1
+                    continue
+                ids, dist, cnt, _ = exp[t]
+                assert (got.counts == cnt).all() and (got.rowids == ids).all() and (got.distances == dist).all()
+                ok[t] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[:3]
+    total = n_threads * per_thread
+    assert sum(ok) + sum(late) == total
+    print(f"budget {budget} ms (one round of {n_threads} callers: {round_ms:.2f} ms): {sum(ok)} ok, {sum(late)} timed out")
+    assert sum(ok) >= total // 2, (sum(ok), sum(late))
+    # and the handle is healthy afterwards
+    got = ix.search(qs[:3], **kw)
+    e = o.search(qs[:3], **kw)
+    assert (got.rowids == e[0]).all() and (got.distances == e[1]).all()

@@ -20,6 +20,27 @@ struct Req : QueueWaiter {
   uint64_t result = 0;    // "output buffer" of the caller, written by whoever runs the batch
 };
 
+// the deadline rule of a coalesced batch (call_queue.h split_by_deadline): every call against its own entry time
+static int check_deadline_rule() {
+  using clk = std::chrono::steady_clock;
+  using ms = std::chrono::milliseconds;
+  int bad = 0;
+  const clk::time_point now = clk::now();
+  // budget 50 ms: waited 70 (expired), 10 (40 left), 49 (1 left), 50 (expired: the budget is spent), 0 (50 left)
+  const std::vector<clk::time_point> t0 = {now - ms(70), now - ms(10), now - ms(49), now - ms(50), now};
+  DeadlineSplit d = split_by_deadline(t0, now, 50);
+  bad += !(d.live == std::vector<size_t>{1, 2, 4});
+  bad += !(d.timeout_left == 1u);      // the device is armed with the SMALLEST budget left among the live calls
+  bad += !(d.worst_wait_ms == 70);
+  d = split_by_deadline(t0, now, 0);   // no timeout: everybody is live, nothing to arm
+  bad += !(d.live.size() == 5 && d.timeout_left == 0u);
+  d = split_by_deadline({now - ms(5)}, now, 5);  // a single call whose budget is exactly spent
+  bad += !(d.live.empty() && d.worst_wait_ms == 5);
+  d = split_by_deadline({now + ms(3)}, now, 20);  // (a clock read before the call's own stamp: never more than the budget)
+  bad += !(d.live.size() == 1 && d.timeout_left == 20u);
+  return bad;
+}
+
 int main(int argc, char** argv) {
   const unsigned n_threads = argc > 1 ? (unsigned)atoi(argv[1]) : 48, per = argc > 2 ? (unsigned)atoi(argv[2]) : 400;
   CallQueue<Req> q;
@@ -87,6 +108,7 @@ int main(int argc, char** argv) {
   if (carried.load() != calls) errors.fetch_add(1);  // every call ran in exactly one batch
   if (q.busy || !q.queue.empty()) errors.fetch_add(1);
   if (own_outcomes.load() != own_seen.load()) errors.fetch_add(1);  // every per-request outcome reached its caller
+  errors.fetch_add((uint64_t)check_deadline_rule());
   std::printf("%s: %llu calls in %llu batches (largest %llu), %llu calls saw their batch fail, %llu errors\n",
               errors.load() ? "FAILED" : "ok", (unsigned long long)calls, (unsigned long long)batches.load(),
               (unsigned long long)biggest.load(), (unsigned long long)failed_calls.load(), (unsigned long long)errors.load());

@@ -84,6 +84,19 @@ extern "C" int32_t mi355_dev_counters(mi355_index* ix, uint32_t* out8, int32_t r
 } MI355_ABI_GUARD("mi355_dev_counters")
 #endif
 
+#ifdef MI355_DEV_TIMELINE
+// dev builds only: the per-workgroup stamps of the last scan launch (kernels_skew.h SK_TL) -> out[grid][SK_TL_WORDS]
+extern "C" int32_t mi355_dev_timeline(mi355_index* ix, unsigned long long* out, uint32_t max_words, uint32_t* grid, uint32_t* words) try {
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  *grid = ix->tl_grid;
+  *words = SK_TL_WORDS;
+  const size_t n = std::min<size_t>(max_words, (size_t)ix->tl_grid * SK_TL_WORDS);
+  if (n) HIP_TRY(hipMemcpy(out, ix->w_tl.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return MI355_OK;
+} MI355_ABI_GUARD("mi355_dev_timeline")
+#endif
+
 // ------------------------------------------------------------------ search --
 int32_t validate_params(const mi355_search_params* p) {
   if (!p) return fail(MI355_ERR_INVALID_INPUT, "params is NULL");
@@ -156,6 +169,12 @@ int32_t launch_refine(mi355_index* ix, const IndexView& view, const float* q, ui
   return MI355_OK;
 }
 
+// CUs the scan's persistent workgroups take: a handle whose re-rank runs beside its scans (deferred refine over a host column)
+// keeps a few CUs free for it — a scan workgroup takes a whole CU (128 VGPRs x 16 waves), so nothing can share one with it
+static uint32_t scan_cus_of(const mi355_index* ix, const SearchPlan& pl) {
+  return (pl.defer_refine && ix->n_cus > 4 * MI355_REFINE_SIDE_CUS) ? ix->n_cus - MI355_REFINE_SIDE_CUS : ix->n_cus;
+}
+
 bool lat_front_applies(const mi355_index* ix, uint32_t nq, const SearchPlan& pl) {
   const size_t small_lds = ((size_t)nq * (((size_t)ix->dim + 3) & ~(size_t)3) + nq) * sizeof(float);
   return ix->layout == MI355_SCAN_SKEW && !pl.ext_probes && !pl.act.n && nq >= 1 && nq <= CS_MAXQ && small_lds <= 96u * 1024 &&
@@ -198,19 +217,32 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   // the production scan slices by tile positions instead (SkewArgs::n_slices): only when the batch cannot
   // give every CU a work item, and never below ~2 k rows per slice (each slice rebuilds the distance table)
   uint32_t sk_slices = 1;
+  uint32_t sk_by_rows = 0;  // (PlanArgs::by_rows) the sparse planner cuts pairs by rows: sk_slices is then the most a pair is cut into
   if (skew) {
     const uint64_t pairs = (uint64_t)nq * nprobe;
     // (round 4: up to 3 work items per CU.  A batch of 8 queries is 512 whole-partition items on 256 CUs: its scan took
     //  370 us because the longest partition decides; cut in two it is bounded by half of it.  Every slice rebuilds the
     //  distance table, so batches that already give a CU 3 items keep whole partitions.)
-    if (pairs && pairs < 3ull * ix->n_cus)
-      sk_slices = (uint32_t)std::min<uint64_t>(dev_knob("MI355_LAT_SLICES_MAX", 8), (3ull * ix->n_cus + pairs - 1) / pairs);
+    if (pairs && pairs < 3ull * ix->n_cus) {
+      // (round 6) batches the sparse planner lays out are cut by rows, not by count: equal work items whatever the partition
+      // lengths are, one per CU for a single query; a pair's candidate slots are strided by the most slices a pair may get
+      const bool sparse = pairs <= PLAN_SPARSE_MAX_PAIRS && dev_knob("MI355_PLAN_SPARSE", 1) && dev_knob("MI355_LAT_BY_ROWS", 1) &&
+                          !(ix->lut_img_ok && !ix->lut_inline_cfg);  // (the table-image kernels walk a fixed number of items per pair)
+      if (sparse) {
+        sk_by_rows = dev_knob("MI355_LAT_IPC", 0);
+        if (!sk_by_rows) sk_by_rows = PLAN_BY_ROWS_AUTO;
+        sk_slices = std::min<uint32_t>(dev_knob("MI355_LAT_SLICES_MAX", 16), std::max(1u, MERGE_PRE_SRC / nprobe));
+      } else {
+        sk_slices = (uint32_t)std::min<uint64_t>(dev_knob("MI355_LAT_SLICES_MAX", 8), (3ull * ix->n_cus + pairs - 1) / pairs);
+      }
+    }
     sk_slices = std::max(1u, std::min(sk_slices, ix->max_len / 2048u));
     if (pl.kk > 256u) sk_slices = 1;  // (multi-pass selection re-scans per pass: keep whole partitions)
     // a sliced item's `pair` word is [6 bits slices - 1][6 bits slice][20 bits pair] (sk_pack_pair): whatever the knobs and
     // the CU count say, never more slices or pairs than the fields hold
     sk_slices = std::min(sk_slices, SK_MAX_SLICES);
     if (sk_slices > 1 && pairs >= (1ull << 20)) sk_slices = 1;
+    if (sk_slices == 1) sk_by_rows = 0;
   }
   const uint32_t n_slices = skew ? sk_slices : std::max(1u, (ix->max_len + slice - 1) / slice);
 
@@ -328,6 +360,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       // sharded coarse merge, otherwise rank 0 is just the caller's first probe
       pa.best_first = (pl.kk >= dev_knob("MI355_BEST_FIRST_MIN_KK", 1) && nprobe > 1u) ? 1u : 0u;
       pa.n_slices = n_slices;
+      pa.by_rows = lut_img ? 0u : sk_by_rows;
+      pa.n_wg = std::max(1u, scan_cus_of(ix, pl));
       pa.act = act;
     }
     if (lat_front) {
@@ -464,11 +498,18 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       ka.ctl = d_ctl;
       // a handle whose re-rank runs beside its scans (deferred refine over a host column) keeps a few CUs free for it:
       // a scan workgroup takes a whole CU (128 VGPRs x 16 waves), so nothing can share one with it
-      const uint32_t scan_cus = (pl.defer_refine && ix->n_cus > 4 * MI355_REFINE_SIDE_CUS) ? ix->n_cus - MI355_REFINE_SIDE_CUS : ix->n_cus;
+      const uint32_t scan_cus = scan_cus_of(ix, pl);
       uint32_t n_blocks = std::max(1u, (uint32_t)std::min<uint64_t>(scan_cus, (uint64_t)n * nprobe * n_slices));
       ka.n_slabs = ix->sk_slabs;
       ka.res_floats = lut_img ? 0u : ix->sk_res_floats;  // (image kernels keep no residual in LDS)
       ka.lut_img = lut_img ? ix->w_lutimg.as<float>() : nullptr;
+      ka.dev_tl = nullptr;
+#ifdef MI355_DEV_TIMELINE
+      ST_TRY(ix->w_tl.ensure(sizeof(unsigned long long) * SK_TL_WORDS * 2u * ix->n_cus));
+      HIP_TRY(hipMemsetAsync(ix->w_tl.p, 0, sizeof(unsigned long long) * SK_TL_WORDS * 2u * ix->n_cus, st));
+      ka.dev_tl = ix->w_tl.as<unsigned long long>();
+      ix->tl_grid = n_blocks;
+#endif
       ka.partial = nullptr;
       ka.partial_stride = 0;
       if (ix->sk_slabs > 1) {
@@ -484,6 +525,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       }
       if (lut_img)
         ST_TRY(launch_scan_skew_img(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
+      else if (n_slices > 1 && !ix->sk_slabbed && pl.kk <= 64u && dev_knob("MI355_LAT_KERNEL", 1))
+        ST_TRY(launch_scan_skew_lat(ka, ix->sk_M, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
       else
         ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
     } else {

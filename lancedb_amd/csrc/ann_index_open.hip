@@ -154,7 +154,7 @@ static int32_t index_free(mi355_index* ix) {
                     &ix->p_fill,    &ix->q_start, &ix->heads,   &ix->items,   &ix->qthr,
                     &ix->w_filter,  &ix->w_probes64, &ix->w_cand2, &ix->w_sq,     &ix->w_sids,
                     &ix->w_sdist,   &ix->w_scnt,     &ix->w_scnt_ann, &ix->w_spill, &ix->w_srows, &ix->w_ccnt,
-                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b,    &ix->w_lutres, &ix->w_lutimg};
+                    &ix->w_partial,  &ix->w_cand2b,   &ix->w_cnt2b,    &ix->w_lutres, &ix->w_lutimg, &ix->w_tl};
   for (DevBuf* b : bufs) b->release();
   for (auto* v : {&ix->ev_free, &ix->ev_pending})
     for (auto& es : *v)

@@ -219,6 +219,8 @@ struct mi355_index {
   bool lut_img_ok = false;
   bool lut_inline_cfg = false;  // MI355_CFG_LUT_INLINE: build the tables inside the scan work items anyway
   DevBuf w_lutres, w_lutimg;
+  DevBuf w_tl;           // (-DMI355_DEV_TIMELINE builds) the last scan launch's per-workgroup stamps
+  uint32_t tl_grid = 0;
   DevBuf w_cand2b, w_cnt2b;  // the second buffer set of the deferred refine (each set has its own allocations)
   bool defer_cfg = false;    // MI355_CFG_DEFER_REFINE
   // workspace
@@ -319,6 +321,7 @@ int32_t launch_scan_skew(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint3
 // ... the kernels that copy a table image (SkewArgs::lut_img) instead of building the table (ann_scan_skew_img.hip), and the
 // batch-level table kernels themselves (ann_lut.hip)
 int32_t launch_scan_skew_img(const SkewArgs& sa, uint32_t M, uint32_t slabbed, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st);
+int32_t launch_scan_skew_lat(const SkewArgs& sa, uint32_t M, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st);
 struct SkewItem;
 bool lut_images_shape_ok(const mi355_index* ix);
 size_t lut_image_bytes_per_pair(const mi355_index* ix);

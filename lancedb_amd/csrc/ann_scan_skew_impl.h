@@ -8,12 +8,12 @@
 
 // IMG: the kernels that copy a pre-built table image (SkewArgs::lut_img, kernels_lut.h) instead of building the table; the
 // driver only asks for them with kk <= 128 (ann_index.hip), so only those selections are instantiated.
-template <int M, bool SLABBED, bool IMG = false>
+template <int M, bool SLABBED, bool IMG = false, bool LAT = false>
 static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_t n_items, uint32_t kk, hipStream_t st) {
   auto lds_of = [&](int nw, int lr) { return sk_scan_lds(M, sa.res_floats, nw, lr); };
 #define LAUNCH_SK_(LR, NT, MULTI, OPT, TWO, GRID)                                               \
   {                                                                                             \
-    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT, SLABBED, TWO, IMG>;                               \
+    auto kern = k_scan_skew<M, LR, NT, MULTI, OPT, SLABBED, TWO, IMG, LAT>;                          \
     const size_t lds = lds_of(NT / 64, LR);                                                     \
     if (lds > 160u * 1024)                                                                      \
       return fail(MI355_ERR_NOT_SUPPORTED, "scan work item needs %zu B of LDS (> 160 KiB)", lds); \
@@ -31,6 +31,12 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_
     hipLaunchKernelGGL(kern, dim3(GRID), dim3(NT), lds, st, sa);                                \
   }
 #define LAUNCH_SK(LR, NT, MULTI, OPT) LAUNCH_SK_(LR, NT, MULTI, OPT, false, n_blocks)
+  if constexpr (LAT) {  // (the driver asks for these with k * refine_factor <= 64 only, ann_index.hip)
+    if (kk > 64) return fail(MI355_ERR_NOT_SUPPORTED, "the sliced scan kernels select k * refine_factor <= 64");
+    LAUNCH_SK(2, 1024, false, false)
+    HIP_TRY(hipGetLastError());
+    return MI355_OK;
+  }
 #ifndef SK_NO_PAIRED_WG
   // Tables of 32 columns (m <= 32: 128- to 512-d vectors at the reference's dim / 16) are 64 KiB, so TWO eight-wave
   // workgroups share a CU: a work item of so few columns spends a third of its time building its table and merging,

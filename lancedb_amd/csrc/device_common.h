@@ -445,18 +445,93 @@ struct WaveList {
   uint32_t q;     // (QTRACK) rank tracked by t_q
   float t_q;      // (QTRACK) distance of the q-th best row seen so far (+inf until q rows were compacted)
 
-  __device__ __forceinline__ void init(ListEnt* lds, uint32_t kk_, uint32_t q_ = 0) {
+  bool fast;      // compactions may leave the kk best rows UNSORTED (compact_select); callers then use filter(), not prune()
+
+  __device__ __forceinline__ void init(ListEnt* lds, uint32_t kk_, uint32_t q_ = 0, bool fast_ = false) {
     list = lds;
     cnt = 0;
     kk = kk_;
     t_run = __builtin_huge_valf();
     q = q_;
     t_q = __builtin_huge_valf();
+    fast = fast_;
   }
 
-  // keep the kk best entries, sorted by (distance, id); idof(pos) -> row id
+  // The kk best entries by a radix select over the lanes' registers: 32 rounds of ballots find the kk-th smallest distance key T,
+  // and the entries at or below it are packed to the front of the list in their old order — no LDS sweep.  (The rank-counting
+  // compaction below reads the list entry by entry, one dependent LDS broadcast per entry: ~8 us for a full list of 128 rows.
+  // A single query's work items all start without a bound, so every wave fills its list at once and compacted it twice per
+  // item: 20 of a 43 us scan phase, round 6.)  Exact unless MORE rows than needed tie with the kk-th distance — then the row ids
+  // decide and the caller falls back to the ranking form: returns false, nothing changed.  Needs cnt > kk.
+  __device__ __forceinline__ bool compact_select(int lane) {
+    __threadfence_block();
+    ListEnt mine[R];
+    uint32_t key[R];
+    bool in[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t slot = (uint32_t)(r * MI355_WAVE + lane);
+      in[r] = slot < cnt;
+      mine[r].d = 0.f;
+      mine[r].pos = CAND_EMPTY_POS;
+      if (in[r]) mine[r] = list[slot];
+      key[r] = in[r] ? f32_sort_key(mine[r].d) : 0xFFFFFFFFu;
+    }
+    // the k-th smallest key of the list (k <= cnt) and how many of the entries EQUAL to it the k smallest include
+    auto kth = [&](uint32_t k, uint32_t& need_eq) -> uint32_t {
+      bool alive[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) alive[r] = in[r];
+      uint32_t prefix = 0, need = k;
+#pragma unroll
+      for (int bit = 31; bit >= 0; --bit) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) c += (uint32_t)__popcll((unsigned long long)__ballot(alive[r] && ((key[r] >> bit) & 1u) == 0u));
+        const bool take_zero = c >= need;
+        if (!take_zero) {
+          need -= c;
+          prefix |= 1u << bit;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) alive[r] = alive[r] && ((((key[r] >> bit) & 1u) == 0u) == take_zero);
+      }
+      need_eq = need;
+      return prefix;
+    };
+    uint32_t need = 0;
+    const uint32_t T = kth(kk, need);
+    uint32_t n_eq = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) n_eq += (uint32_t)__popcll((unsigned long long)__ballot(in[r] && key[r] == T));
+    if (n_eq != need) return false;  // a tie across the boundary: the row ids decide
+    if (QTRACK && q >= 1u && q <= kk) {
+      uint32_t ne;
+      t_q = fminf(t_q, f32_from_sort_key(kth(q, ne)));  // (a distance: ties do not matter)
+    }
+    __threadfence_block();           // every entry is in registers before any slot is rewritten
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool k = in[r] && key[r] <= T;
+      const uint64_t m = __ballot(k);
+      if (k) list[base + (uint32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)))] = mine[r];
+      base += (uint32_t)__popcll((unsigned long long)m);
+    }
+    cnt = base;  // == kk
+    t_run = fminf(t_run, f32_from_sort_key(T));
+    __threadfence_block();
+    return true;
+  }
+
+  // keep the kk best entries, sorted by (distance, id); idof(pos) -> row id  (`fast`: unsorted, see compact_select)
   template <typename IdOf>
   __device__ __forceinline__ void compact(int lane, IdOf idof) {
+    if (fast && cnt > kk && compact_select(lane)) return;
+    compact_rank(lane, idof);
+  }
+  template <typename IdOf>
+  __device__ __forceinline__ void compact_rank(int lane, IdOf idof) {
     __threadfence_block();
     ListEnt mine[R];
     bool val[R];
@@ -540,6 +615,20 @@ struct WaveList {
     }
     cnt = base;
     __threadfence_block();
+  }
+
+  // append() for a caller that made room itself (cnt <= capacity - 64 on entry): no compaction inside
+  __device__ __forceinline__ void append_room(bool ok, float d, uint32_t pos, int lane) {
+    const uint64_t mask = __ballot(ok);
+    if (!mask) return;
+    if (ok) {
+      const uint32_t idx = cnt + (uint32_t)__popcll((unsigned long long)(mask & ((1ull << lane) - 1ull)));
+      ListEnt e;
+      e.d = d;
+      e.pos = pos;
+      list[idx] = e;
+    }
+    cnt += (uint32_t)__popcll((unsigned long long)mask);
   }
 
   // Every lane offers at most one row.  `thr` is the caller's current

@@ -1398,7 +1398,7 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
         tau = min(tau_a, tau_b);
         __syncthreads();  // the keys are dead: the sweep reuses their space
       }
-      constexpr int G = 4;
+      constexpr int G = 8;  // (a single query cut by rows has up to 1024 sources: 10 240 slots at k = 10, two trips)
       for (uint32_t t0 = 0; t0 < n; t0 += G * NT) {
         Cand c[G];
         bool in[G];

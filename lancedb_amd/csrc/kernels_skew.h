@@ -316,7 +316,13 @@ struct PlanArgs {
   // candidate lists cost is selection, and selection work follows the rows admitted.  The price is one
   // extra, un-shared read of ~one partition per query (+13 % L2 fills at C3, HBM is 15 % busy).
   uint32_t best_first;
-  uint32_t n_slices;        // work items per pair (SkewArgs::n_slices)
+  uint32_t n_slices;        // work items per pair (SkewArgs::n_slices); with by_rows: the most a pair is cut into (its slot stride)
+  // by_rows > 0 (the sparse planner only): pairs are cut by ROWS, not by count — a pair of P tile positions becomes ceil(P / T) work
+  // items, T the smallest number of positions per item that leaves at most n_wg * by_rows items (round 6: with eight slices per
+  // pair whatever its length, the eight workgroups on a single query's longest partition — 2.8 x the mean at C3's skew — ran 75 us
+  // items and then took a second one, while the first workgroup was out of work after 57 of the launch's 92 us)
+  uint32_t by_rows;         // target work items per scan workgroup (0: n_slices items per pair)
+  uint32_t n_wg;            // scan workgroups of the launch
   ActiveMask act;           // device-side batch size: pairs of inactive queries make no item, no slot writes
 };
 
@@ -459,19 +465,30 @@ static __global__ __launch_bounds__(1024) void k_plan_fused(PlanArgs a) {
 #define PLAN_SPARSE_MAX_PAIRS 512u
 // (the body runs inside any workgroup of >= PLAN_SPARSE_MAX_PAIRS threads: k_plan_sparse alone, or the last workgroup of
 //  k_select_plan.  FRESH: the probe lists were written by OTHER workgroups of the same launch — read them at L2.)
+// tile positions of the longest unit of a partition of `len` rows: what a pair can be cut into (a slice is a range of positions)
+__host__ __device__ __forceinline__ uint32_t sk_positions(uint32_t len) {
+  const uint32_t n_tiles = (len + SK_TILE - 1) / SK_TILE;
+  return (n_tiles + SK_STREAMS - 1) / SK_STREAMS;
+}
+#define PLAN_BY_ROWS_AUTO 0xFFFFFFFFu
+#define PLAN_T_TRIES 4u  // candidate positions-per-item tried side by side (by_rows)
+#define PLAN_SQ_WORDS 13u
 template <bool FRESH>
 __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_key /*[PLAN_SPARSE_MAX_PAIRS]*/, uint32_t* s_xf /*[9]*/,
-                                                 uint32_t* s_q /*[10]*/,
+                                                 uint32_t* s_q /*[PLAN_SQ_WORDS]*/,
                                                  const uint32_t* lds_probes = nullptr /*[n_pairs] in LDS: skip the global read*/,
-                                                 unsigned long long* stat_rows = nullptr /*+= probed rows of the batch*/) {
+                                                 unsigned long long* stat_rows = nullptr /*+= probed rows of the batch*/,
+                                                 uint32_t* s_nsl = nullptr /*[PLAN_SPARSE_MAX_PAIRS] (by_rows) items of every pair*/) {
   const uint32_t i = threadIdx.x, lane = i & 63u;
   const uint32_t ncls = a.best_first ? 2u : 1u;
+  const bool by_rows = a.by_rows != 0u && s_nsl != nullptr && a.n_slices > 1u;
   if (i < 9) s_xf[i] = a.xcd_first[i];
-  if (i < 10) s_q[i] = 0;  // [0..8] items before each queue boundary, [9] probed rows of the batch
+  // [0..8] items of queue x (then: items before queue x), [9] probed rows, [10] tile positions, [11], [12] items at T0 + k, two per word
+  if (i < PLAN_SQ_WORDS) s_q[i] = 0;
   __syncthreads();
   // (every thread loads unconditionally at clamped indices — its probe, then the five per-partition words side by side:
   //  guarded, each load is a memory round trip of its own and the item records waited for three more at the end)
-  uint32_t key = 0xFFFFFFFFu, p = 0xFFFFFFFFu, len = 0;
+  uint32_t key = 0xFFFFFFFFu, p = 0xFFFFFFFFu, len = 0, xq = 0;
   const bool mine = i < a.n_pairs && a.act.on(i / a.nprobe);
   const uint32_t ic = i < a.n_pairs ? i : a.n_pairs - 1u;
   const uint32_t p_ld = lds_probes ? lds_probes[ic]
@@ -485,35 +502,78 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
     p = p_ld;
     len = p < a.nlist ? len_ld : 0u;
     if (len) {
-      uint32_t x = 0;
-      for (uint32_t y = 1; y < 8; ++y) x += (at >= s_xf[y]) ? 1u : 0u;  // queue of the partition (empty queues are skipped over)
-      const uint32_t qlen = s_xf[x + 1] - s_xf[x], idx = at - s_xf[x];
-      key = ncls * s_xf[x] + ((ncls == 2u && plan_class(a, i) == 0u) ? qlen : 0u) + idx;
+      for (uint32_t y = 1; y < 8; ++y) xq += (at >= s_xf[y]) ? 1u : 0u;  // queue of the partition (empty queues are skipped over)
+      const uint32_t qlen = s_xf[xq + 1] - s_xf[xq], idx = at - s_xf[xq];
+      key = ncls * s_xf[xq] + ((ncls == 2u && plan_class(a, i) == 0u) ? qlen : 0u) + idx;
     }
   }
   if (i < PLAN_SPARSE_MAX_PAIRS) s_key[i] = key;
-  if (stat_rows) {  // probed rows of the batch: wave sums, one LDS atomic per wave
-    uint32_t v = key != 0xFFFFFFFFu ? len : 0u;
+  auto wave_sum = [&](uint32_t v) -> uint32_t {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += (uint32_t)__shfl_xor((int)v, off);
-    if (lane == 0 && v) atomicAdd(&s_q[9], v);
+    return v;
+  };
+  const bool live = key != 0xFFFFFFFFu;
+  const uint32_t pos = live ? sk_positions(len) : 0u;
+  if (stat_rows || by_rows) {  // probed rows / tile positions of the batch: wave sums, one LDS atomic per wave
+    if (__any(live)) {
+      const uint32_t v = wave_sum(live ? len : 0u), vp = by_rows ? wave_sum(pos) : 0u;
+      if (lane == 0 && v) atomicAdd(&s_q[9], v);
+      if (lane == 0 && vp) atomicAdd(&s_q[10], vp);
+    }
     __syncthreads();
-    if (i == 0 && s_q[9]) atomicAdd(stat_rows, (unsigned long long)s_q[9]);
+    if (stat_rows && i == 0 && s_q[9]) atomicAdd(stat_rows, (unsigned long long)s_q[9]);
   }
-  // queue x starts behind the items whose place is below its first virtual index
+  // work items of this pair
+  uint32_t nsl = live ? a.n_slices : 0u;
+  if (by_rows) {
+    // items per workgroup the launch should not exceed: an item costs its table (10 us) and its streams' tails (a third of a
+    // position) before it scans anything, so a workgroup gets ONE item unless its share is long enough to hide that — two from
+    // 8 positions, three from 12
+    const uint32_t share = s_q[10] / max(a.n_wg, 1u);
+    const uint32_t ipc = a.by_rows != PLAN_BY_ROWS_AUTO ? a.by_rows : min(3u, max(1u, share / 4u));
+    const uint32_t cap = a.n_wg * ipc;
+    const uint32_t t0 = max(1u, (s_q[10] + cap - 1u) / max(cap, 1u));
+    // the items of the launch at T0 .. T0 + 3 positions per item, side by side (a pair gives <= 64 items, a wave <= 4096, the
+    // batch <= 32768: 16-bit fields, two per word)
+    if (__any(live)) {
+      uint32_t c[PLAN_T_TRIES];
 #pragma unroll
-  for (uint32_t x = 0; x < 9; ++x) {
-    const uint64_t m = __ballot(key != 0xFFFFFFFFu && key < ncls * s_xf[x]);
-    if (lane == 0 && m) atomicAdd(&s_q[x], (uint32_t)__popcll((unsigned long long)m));
+      for (uint32_t k = 0; k < PLAN_T_TRIES; ++k) c[k] = min((pos + t0 + k - 1u) / (t0 + k), a.n_slices);
+      const uint32_t w01 = wave_sum(c[0] | (c[1] << 16)), w23 = wave_sum(c[2] | (c[3] << 16));
+      if (lane == 0) {
+        atomicAdd(&s_q[11], w01);
+        atomicAdd(&s_q[12], w23);
+      }
+    }
+    __syncthreads();
+    const uint32_t n_at[PLAN_T_TRIES] = {s_q[11] & 0xFFFFu, s_q[11] >> 16, s_q[12] & 0xFFFFu, s_q[12] >> 16};
+    uint32_t t = t0 + PLAN_T_TRIES - 1u;
+#pragma unroll
+    for (uint32_t k = PLAN_T_TRIES; k-- > 0;)
+      if (n_at[k] <= cap) t = t0 + k;
+    nsl = live ? max(1u, min((pos + t - 1u) / t, a.n_slices)) : 0u;
+    if (i < PLAN_SPARSE_MAX_PAIRS) s_nsl[i] = nsl;
   }
+  if (live) atomicAdd(&s_q[xq], nsl);  // (the keys of queue x lie in [ncls * s_xf[x], ncls * s_xf[x + 1]))
   __syncthreads();
-  if (key != 0xFFFFFFFFu) {
-    uint32_t rank = 0;  // pairs placed before this one
-    for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {  // (s_key beyond n_pairs holds 0xFFFFFFFF: never below a real key)
-      const uint4 kj = *(const uint4*)&s_key[j0];
-      const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w};
+  if (live) {
+    uint32_t before = 0;  // items of the pairs placed before this one
+    if (by_rows) {
+      for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {  // (s_key beyond n_pairs holds 0xFFFFFFFF: never below a real key)
+        const uint4 kj = *(const uint4*)&s_key[j0], nj = *(const uint4*)&s_nsl[j0];
+        const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w}, nv[4] = {nj.x, nj.y, nj.z, nj.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) rank += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? 1u : 0u;
+        for (int e = 0; e < 4; ++e) before += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? nv[e] : 0u;
+      }
+    } else {
+      for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {
+        const uint4 kj = *(const uint4*)&s_key[j0];
+        const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) before += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? 1u : 0u;
+      }
+      before *= a.n_slices;
     }
     SkewItem it;
     it.part = p;
@@ -521,18 +581,22 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
     it.lrow0 = it_lrow0;
     it.grow0 = it_grow0;
     it.code_off = it_code_off;
-    for (uint32_t sl = 0; sl < a.n_slices; ++sl) {
-      it.pair = a.n_slices > 1u ? sk_pack_pair(i, sl, a.n_slices) : i;
-      a.items[(size_t)rank * a.n_slices + sl] = it;
+    for (uint32_t sl = 0; sl < nsl; ++sl) {
+      it.pair = a.n_slices > 1u ? sk_pack_pair(i, sl, nsl) : i;
+      a.items[(size_t)before + sl] = it;
     }
   }
-  if (i < 9) a.q_start[i] = s_q[i] * a.n_slices;
+  if (i < 9) {  // queue x starts behind the items of the queues below it
+    uint32_t acc = 0;
+    for (uint32_t y = 0; y < i; ++y) acc += s_q[y];
+    a.q_start[i] = acc;
+  }
   if (i < 8) a.heads[i * SK_HEAD_STRIDE] = 0;
 }
 static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(PlanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
-  __shared__ uint32_t s_xf[9], s_q[10];
-  plan_sparse_body<false>(a, s_key, s_xf, s_q);
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ uint32_t s_xf[9], s_q[PLAN_SQ_WORDS];
+  plan_sparse_body<false>(a, s_key, s_xf, s_q, nullptr, nullptr, s_nsl);
 }
 
 // ---- latency front, second half: probe selection of every query + the work list, ONE launch ----------------------
@@ -565,8 +629,8 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_and, s_or, s_prefix, s_need, s_less, s_wave_cnt[SELPLAN_NT / 64], s_running, s_best_at, s_eq_all, s_last;
   __shared__ unsigned long long s_best;
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
-  __shared__ uint32_t s_xf[9], s_q[10];
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ uint32_t s_xf[9], s_q[PLAN_SQ_WORDS];
   constexpr int NT = SELPLAN_NT, NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t b = blockIdx.x, nlist = a.nlist, nprobe = a.nprobe;
@@ -745,7 +809,7 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   const unsigned long long sp_t3 = wall_clock64();
 #endif
   if (!alone && !s_last) return;
-  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q, alone ? s_out : (const uint32_t*)nullptr, a.stat_rows);
+  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q, alone ? s_out : (const uint32_t*)nullptr, a.stat_rows, s_nsl);
 #ifdef MI355_DEV_FRONT
   __syncthreads();
   if (tid == 0 && a.stat_rows) {  // (stat_rows = &DevCtl::rows_scanned, the first member: the counters follow it)
@@ -802,6 +866,7 @@ struct SkewArgs {
   // IMG kernels: the distance tables of the batch, built by k_lut_images (kernels_lut.h) before this launch —
   // [pair][slab][column block][code][16] f32; a work item copies its image into the LDS table instead of building it
   const float* lut_img;
+  unsigned long long* dev_tl;  // (-DMI355_DEV_TIMELINE builds) [grid][SK_TL_WORDS], else nullptr
 };
 
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -863,6 +928,30 @@ __device__ __forceinline__ void sk_dev_add(uint32_t& acc, uint32_t v) { acc += v
 #else
 #define SK_DEV(...)
 #endif
+// dev builds (-DMI355_DEV_TIMELINE, tests/tools/scan_timeline.py): thread 0 of every workgroup stamps wall_clock64() at its start and,
+// for its first SK_TL_ITEMS items, at the item's start / table ready / its own wave's streams done / every wave done / merge done, plus
+// the item's rows — into SkewArgs::dev_tl [grid][SK_TL_WORDS] (the last launch's timeline; mi355_dev_timeline copies it out)
+#ifdef MI355_DEV_KNOBS
+#define SK_KNOB(...) __VA_ARGS__
+#else
+#define SK_KNOB(...)
+#endif
+#ifndef SK_LAT_SHARE_BEST
+#define SK_LAT_SHARE_BEST 1
+#endif
+#ifndef SK_LAT_QSHARE
+#define SK_LAT_QSHARE 0
+#endif
+#ifndef SK_FAST_SEL
+#define SK_FAST_SEL 1
+#endif
+#define SK_TL_ITEMS 6u
+#define SK_TL_WORDS (2u + 6u * SK_TL_ITEMS)
+#ifdef MI355_DEV_TIMELINE
+#define SK_TL(...) __VA_ARGS__
+#else
+#define SK_TL(...)
+#endif
 // SLABBED: the generalised form for the widths the plain kernel is not instantiated for (SkewShape): table column j of
 // slab s is sub-quantiser s * M + j of the index (an all-zero column past ix.m), the residual in LDS is one slab's,
 // and with n_slabs > 1 a work item walks the slabs: build table s, scan code slab s with every row's accumulator
@@ -872,7 +961,11 @@ __device__ __forceinline__ void sk_dev_add(uint32_t& acc, uint32_t v) { acc += v
 // merges while the other scans.  The second launch-bound figure is waves per SIMD: 4 keeps both at <= 128 VGPRs.
 // IMG: the table is not built here — k_lut_images (kernels_lut.h) built every pair's table of the batch with the codebook in
 // registers, and the item copies its image (4 * M bytes per code row) into LDS: no residual, no codebook stream.
-template <int M, int LR, int NT, bool MULTI, bool OPT = false, bool SLABBED = false, bool TWO = false, bool IMG = false>
+// LAT: the instantiation sliced batches run (a few queries cut into about one work item per CU, ann_scan_skew_lat.hip): every item
+// starts without a bound — all of a query's items run at once — so every wave fills and compacts its list; these kernels compact
+// by selection (WaveList::compact_select) and keep ONE copy of the selection code per call site.  The batch kernels, whose items
+// inherit the query's bound and hardly ever compact, stay as they were (the extra code costs them registers: C3 -2.5 %).
+template <int M, int LR, int NT, bool MULTI, bool OPT = false, bool SLABBED = false, bool TWO = false, bool IMG = false, bool LAT = false>
 __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a) {
   static_assert(!IMG || !MULTI, "table images are scanned in one selection pass");
   static_assert(!TWO || (NT == 512 && M <= 32), "two workgroups per CU: eight waves and a one-slab table each");
@@ -899,7 +992,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   uint32_t* s_thr = s_ovf + 1;                                // [1] block threshold (sort key)
   // long candidate lists (kk > 64): the shared threshold is built from every wave's q-th best,
   // q = ceil(kk / NW) (WaveList QTRACK); the kk <= 64 kernel keeps the per-wave bound alone
-  constexpr bool QSHARE = LR >= 3;
+  constexpr bool QSHARE = LR >= 3 || (LAT && SK_LAT_QSHARE);  // (LAT: every item of a sliced batch starts without a bound — the shared one is what ends the filling)
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
   SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
   PassFloor* s_floor = (PassFloor*)(s_rec + 2);                          // [1] (MULTI)
@@ -989,6 +1082,8 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   }
 
   SK_DEV(uint32_t dv_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
+  SK_TL(uint32_t tl_n = 0; unsigned long long* tl = a.dev_tl ? a.dev_tl + (size_t)blockIdx.x * SK_TL_WORDS : nullptr;
+        if (tid == 0 && tl) { tl[0] = wall_clock64(); tl[1] = xcc_id(); })
   for (uint32_t slot = 0;; slot ^= 1u) {
     // the record is wave-uniform: keep it in SGPRs
     const SkewItem* rec = s_rec + slot;
@@ -1007,6 +1102,8 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     const uint32_t b = pair / a.nprobe;
     const uint32_t n_tiles = (len + SK_TILE - 1) / SK_TILE;
     Cand* out = a.cand + (size_t)oslot * a.kk;
+    SK_TL(unsigned long long* tli = (tid == 0 && tl && tl_n < SK_TL_ITEMS) ? tl + 2 + 6 * tl_n : nullptr;
+          if (tli) { tli[0] = wall_clock64(); tli[5] = ((unsigned long long)len << 32) | pair_f; })
     SK_DEV(const unsigned long long dv_t0 = wall_clock64(); unsigned long long dv_scan = 0, dv_merge = 0; uint32_t dv_adm = 0;
            const unsigned long long dv_c0 = clock64();)  // shader-clock ticks of the item -> dev[5] (with dev[0..2]: the clock the chip holds)
 
@@ -1035,7 +1132,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       if (d < res_n) res[d] = pre_q[u] - pre_c[u];  // dot: pre_c == 0, q - 0 == q exactly
     }
     if (tid == 0) *s_thr = __hip_atomic_load(a.qthr + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
+    if ((QSHARE || LAT) && tid < NW) s_part[tid] = 0xFFFFFFFFu;
     if (OPT && tid == 0) *s_ovf = 0u;
     __syncthreads();
     // distance table of slab `slab` (the whole row's when !SLABBED): columns = sub-quantisers slab * M .. of the index
@@ -1211,6 +1308,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     }
     __syncthreads();
 
+    SK_TL(if (tli) tli[1] = wall_clock64();)
     SK_DEV(const unsigned long long dv_t1 = wall_clock64();
            if (tid == 0) { sk_dev_add(dv_acc[0], (uint32_t)(dv_t1 - dv_t0)); sk_dev_add(dv_acc[3], 1u);
                          })
@@ -1243,7 +1341,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     const bool whole_kk = pass_base + kk_pass >= a.kk;  // this pass completes the item's kk rows
     uint32_t pub_g = 0xFFFFFFFFu;                        // the tightest bound this lane sent to the query's global word
     const uint32_t q_share = (kk_pass + NW - 1) / NW;
-    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass, q_share);
+    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass, q_share, /*fast=*/LAT && SK_FAST_SEL && !OPT SK_KNOB(&& !(a.dbg & 64u)));
     float pub_q = __builtin_huge_valf();
     bool q_sorted = false;  // the one early sort of the list happened
     float thr = f32_from_sort_key(thr0_key);
@@ -1282,7 +1380,43 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
           }
         }
         SK_DEV(dv_adm += (uint32_t)__popcll((unsigned long long)__ballot(ok));)
-        wl.append(ok, d, lrow0 + row, thr, lane, idof);
+        if constexpr (LAT) {
+          // room for this position's rows is made HERE, the one place of a call site where a LAT kernel compacts (a list of
+          // 128 entries takes 64 more while it holds up to 64): the compaction's code — a radix select and, for ties across
+          // its boundary, the ranking form — exists once per call site, not once per append, early sort and stream end
+          static_assert(!LAT || LR * MI355_WAVE >= 2 * MI355_WAVE, "a LAT list holds two appends");
+          if (wl.cnt > (uint32_t)((LR - 1) * MI355_WAVE)) {
+            wl.compact(lane, idof);
+            thr = fminf(thr, wl.t_run);
+#if SK_LAT_SHARE_BEST
+            if constexpr (!QSHARE) {
+              // the waves' BEST rows (see the block merge below): as soon as kk waves have compacted once, the largest of their
+              // bests bounds kk rows of the item — an order of magnitude below a wave's own kk-th best.  Any snapshot of
+              // s_part is valid: a wave's entry only falls, and the wave keeps a row at or below every value it published.
+              if (kk_pass <= (uint32_t)NW) {
+                uint32_t mk = 0xFFFFFFFFu;
+                if ((uint32_t)lane < wl.cnt) mk = f32_sort_key(wl.list[lane].d);
+#pragma unroll
+                for (int off = 1; off < MI355_WAVE; off <<= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, off));
+                if (lane == 0) __hip_atomic_store(s_part + wid, mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t vp = lane < NW ? __hip_atomic_load(s_part + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xFFFFFFFFu;
+                if ((uint32_t)__popcll((unsigned long long)__ballot(vp != 0xFFFFFFFFu)) >= kk_pass) {
+                  uint32_t v = vp != 0xFFFFFFFFu ? vp : 0u;
+#pragma unroll
+                  for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+                  v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                  if (lane == 0 && atomicMin(s_thr, v) > v && whole_kk) atomicMin(a.qthr + b, v);
+                  thr = fminf(thr, f32_from_sort_key(v));
+                }
+              }
+            }
+#endif
+            ok = ok && d <= thr;
+          }
+          wl.append_room(ok, d, lrow0 + row, lane);
+        } else {
+          wl.append(ok, d, lrow0 + row, thr, lane, idof);
+        }
         if (wl.t_run < published) {  // a compaction tightened this wave's kk-th best: share it
           published = wl.t_run;
           if (lane == 0) atomicMin(s_thr, f32_sort_key(published));
@@ -1290,7 +1424,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         if constexpr (QSHARE) {
           // the first time the wave holds a tile's worth of rows (and at least q), sort them once to
           // learn its q-th best; later compactions (list overflow) keep tightening it
-          if (!q_sorted && wl.cnt >= q_share && wl.cnt >= MI355_WAVE) {
+          if (!LAT && !q_sorted && wl.cnt >= q_share && wl.cnt >= MI355_WAVE) {
             q_sorted = true;
             wl.compact(lane, idof);
             thr = fminf(thr, wl.t_run);
@@ -1326,6 +1460,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     const float fd_scale = ix.metric == MI355_METRIC_COSINE ? 0.5f : 1.0f;
     const float fd_bias = ix.metric == MI355_METRIC_DOT ? -(float)(ix.m - 1) : -0.0f;
     [[maybe_unused]] auto consume2 = [&](const sk_f32x2& acc2, uint32_t sa, uint32_t sb, uint32_t tp) {
+#ifdef MI355_DEV_KNOBS
+      if (a.dbg & 32u) return;  // dev: no selection at all (what the streams alone cost)
+#endif
       const uint32_t bk = __hip_atomic_load(s_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (bk != 0xFFFFFFFFu) {
         const float t = f32_from_sort_key(bk);
@@ -1333,8 +1470,13 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       }
       const float d0 = __fmaf_rn(acc2.x, fd_scale, fd_bias), d1 = __fmaf_rn(acc2.y, fd_scale, fd_bias);
       if (!__any(d0 <= thr || d1 <= thr)) return;
-      consume(acc2.x, sa, tp);
-      consume(acc2.y, sb, tp);
+      if constexpr (LAT) {
+#pragma nounroll
+        for (uint32_t h = 0; h < 2u; ++h) consume(h ? acc2.y : acc2.x, h ? sb : sa, tp);  // (ONE copy of the selection code per call site)
+      } else {
+        consume(acc2.x, sa, tp);
+        consume(acc2.y, sb, tp);
+      }
     };
 
 #ifdef SK_DUAL
@@ -1535,9 +1677,10 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
 #endif
 
     __builtin_amdgcn_s_setprio(0);
+    SK_TL(if (tli) tli[2] = wall_clock64();)
     SK_DEV(const unsigned long long dv_pw = wall_clock64();)  // this wave's streams are done
     // ---- block result: exact kk_pass best of all waves' lists, written sorted ----
-    if (wl.cnt > kk_pass) wl.compact(lane, idof);
+    if (!LAT && wl.cnt > kk_pass) wl.compact(lane, idof);  // (LAT: the block below shrinks long lists — once, for the workgroup)
     if (lane == 0) s_cnt[wid] = wl.cnt;
     auto next_item_fallback = [&]() {  // thread 0: the prefetch ran off the end of its queue (rare, synchronous)
       if (!nxt_valid) {
@@ -1567,6 +1710,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       if (g != 0xFFFFFFFFu) atomicMin(s_thr, g);
     }
     __syncthreads();
+    SK_TL(if (tli) tli[3] = wall_clock64();)
     SK_DEV(const unsigned long long dv_p1 = wall_clock64(); dv_scan += dv_p1 - dv_p0;  // every wave is done
            )
     if constexpr (OPT) {
@@ -1627,7 +1771,34 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         if constexpr (QSHARE) {
           if (lane == 0 && wl.t_q < pub_q) __hip_atomic_store(s_part + wid, f32_sort_key(wl.t_q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        // LAT: every wave's BEST row.  Waves that hold a row hold one at or below their own best, so the LARGEST of kk waves' bests
+        // bounds kk rows — with 16 waves and k = 10 about the 16th best row of the item, where a
+        // wave's own kk-th best (published above) is the 10th best of a sixteenth of it.  The lists then enter the ranking below
+        // with a dozen rows in all instead of 160.
+        if constexpr (LAT && !QSHARE) {
+          uint32_t mk = 0xFFFFFFFFu;
+          if ((uint32_t)lane < wl.cnt) mk = f32_sort_key(wl.list[lane].d);  // (compacted: cnt <= kk_pass <= 64)
+#pragma unroll
+          for (int off = 1; off < MI355_WAVE; off <<= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, off));
+          if (lane == 0) s_part[wid] = mk;  // (reset to "no row" at the item's start)
+        }
         __syncthreads();
+        if constexpr (LAT && !QSHARE) {
+          const uint32_t vp = lane < NW ? s_part[lane] : 0xFFFFFFFFu;
+          const uint32_t n_have = (uint32_t)__popcll((unsigned long long)__ballot(vp != 0xFFFFFFFFu));
+          if (n_have >= kk_pass) {  // (wave-uniform, the same in every wave)
+            // the kk_pass-th smallest of the waves' bests would do; their maximum is one reduction
+            uint32_t v = vp != 0xFFFFFFFFu ? vp : 0u;
+#pragma unroll
+            for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            if (tid == 0) {
+              atomicMin(s_thr, v);
+              if (whole_kk) atomicMin(a.qthr + b, v);
+            }
+            __syncthreads();
+          }
+        }
         if constexpr (QSHARE) {
           if (tid < MI355_WAVE) {  // wave 0: the maximum of the waves' q-th bests bounds NW * q >= kk rows
             uint32_t v = lane < NW ? s_part[lane] : 0u;
@@ -1641,7 +1812,10 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
           __syncthreads();
         }
         const uint32_t tk = *s_thr;
-        if (tk != 0xFFFFFFFFu) wl.prune(f32_from_sort_key(tk), lane);
+        if (tk != 0xFFFFFFFFu) {
+          if (wl.fast) wl.filter(f32_from_sort_key(tk), lane);  // (a list compacted by selection is not sorted)
+          else wl.prune(f32_from_sort_key(tk), lane);
+        }
         if (lane == 0) s_cnt[wid] = wl.cnt;
         __syncthreads();
       }
@@ -1737,7 +1911,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     }
     __syncthreads();  // the floor is published; the lists and the block threshold are rebuilt
     if (tid == 0) *s_thr = thr0_key;
-    if (QSHARE && tid < NW) s_part[tid] = 0xFFFFFFFFu;
+    if ((QSHARE || LAT) && tid < NW) s_part[tid] = 0xFFFFFFFFu;
     __syncthreads();
     }  // passes
     if (MULTI && !tail_done) {  // the tail work of an item whose last pass was not known in advance
@@ -1756,6 +1930,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       __syncthreads();
       if (s_rec[slot ^ 1u].pair != SK_NONE) prefetch_res(s_rec[slot ^ 1u]);
     }
+    SK_TL(if (tli) { tli[4] = wall_clock64(); ++tl_n; tl[1] = xcc_id() | ((unsigned long long)tl_n << 8); })
     SK_DEV(if (tid == 0 && !OPT) { sk_dev_add(dv_acc[5], (uint32_t)(clock64() - dv_c0)); }
            if (tid == 0) { sk_dev_add(dv_acc[1], (uint32_t)dv_scan); sk_dev_add(dv_acc[2], (uint32_t)dv_merge); }
            (void)dv_adm;)

@@ -243,4 +243,4 @@ def test_every_entry_point_has_the_exception_barrier():
             if d != "mi355_abi_version":
                 assert re.search(r'extern "C" (?:int32_t|uint32_t) ' + d + r"\([^{;]*\) try \{", src), (f, d)
         seen.update(defs)
-    assert seen - {"mi355_dev_counters"} == set(_abi.EXPORTED_SYMBOLS)  # (dev_counters: developer builds only, not in the header)
+    assert seen - {"mi355_dev_counters", "mi355_dev_timeline"} == set(_abi.EXPORTED_SYMBOLS)  # (dev_*: developer builds only, not in the header)

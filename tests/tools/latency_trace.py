@@ -13,6 +13,7 @@ from lancedb_amd import _abi  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000  # 100000000 4096: the C3 shape
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # queries per call
 dim, m = 768, 96
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
@@ -35,11 +36,11 @@ q = (cen[torch.randint(0, nlist, (512,), generator=g, device=dev)] + 0.5 * torch
 kw = dict(k=10, nprobe_min=64, nprobe_max=64)
 ix.configure(profile=0, graph=False, coalesce=False)
 for i in range(10):
-    ix.search(q[i:i + 1], **kw)
+    ix.search(q[i:i + B], **kw)
 lat = []
 for i in range(300):
     t0 = time.perf_counter()
-    ix.search(q[i:i + 1], **kw)
+    ix.search(q[i:i + B], **kw)
     lat.append(time.perf_counter() - t0)
 lat = np.sort(np.array(lat)) * 1e6
-print(f"single query, host I/O: p50 {lat[150]:.1f} us  p99 {lat[296]:.1f} us  mean {lat.mean():.1f} us", flush=True)
+print(f"{B} queries per call, host I/O: p50 {lat[150]:.1f} us  p99 {lat[296]:.1f} us  mean {lat.mean():.1f} us", flush=True)

@@ -36,7 +36,7 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_
     LAUNCH_SK(2, 1024, false, false)
     HIP_TRY(hipGetLastError());
     return MI355_OK;
-  }
+  } else {  // (else: a LAT launcher instantiates nothing below)
 #ifndef SK_NO_PAIRED_WG
   // Tables of 32 columns (m <= 32: 128- to 512-d vectors at the reference's dim / 16) are 64 KiB, so TWO eight-wave
   // workgroups share a CU: a work item of so few columns spends a third of its time building its table and merging,
@@ -71,8 +71,9 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_
   else if (kk <= SCAN_PASS_ROWS) LAUNCH_SK(5, 512, false, false)
   else LAUNCH_SK(5, 512, true, false)
   }
-#undef LAUNCH_SK
-#undef LAUNCH_SK_
   HIP_TRY(hipGetLastError());
   return MI355_OK;
+  }  // !LAT
+#undef LAUNCH_SK
+#undef LAUNCH_SK_
 }

@@ -436,7 +436,9 @@ struct ListEnt {
 // NW * q >= kk, then kk rows lie at or below max_w t_q (k_scan_skew publishes it as the shared
 // admission threshold: far tighter than any single wave's kk-th best when the winners are spread
 // over the waves).
-template <int R, bool QTRACK = false>  // capacity = 64 * R entries
+// FAST: compactions select instead of ranking and leave the kk best rows UNSORTED (compact_select); a compile-time property — as a
+// run-time flag both forms were instantiated in every kernel and the scan's selection lambdas stopped being inlined
+template <int R, bool QTRACK = false, bool FAST = false>  // capacity = 64 * R entries
 struct WaveList {
   ListEnt* list;  // LDS
   uint32_t cnt;   // wave-uniform
@@ -445,16 +447,15 @@ struct WaveList {
   uint32_t q;     // (QTRACK) rank tracked by t_q
   float t_q;      // (QTRACK) distance of the q-th best row seen so far (+inf until q rows were compacted)
 
-  bool fast;      // compactions may leave the kk best rows UNSORTED (compact_select); callers then use filter(), not prune()
+  static constexpr bool fast = FAST;  // callers of a FAST list use filter(), not prune()
 
-  __device__ __forceinline__ void init(ListEnt* lds, uint32_t kk_, uint32_t q_ = 0, bool fast_ = false) {
+  __device__ __forceinline__ void init(ListEnt* lds, uint32_t kk_, uint32_t q_ = 0) {
     list = lds;
     cnt = 0;
     kk = kk_;
     t_run = __builtin_huge_valf();
     q = q_;
     t_q = __builtin_huge_valf();
-    fast = fast_;
   }
 
   // The kk best entries by a radix select over the lanes' registers: 32 rounds of ballots find the kk-th smallest distance key T,
@@ -527,7 +528,9 @@ struct WaveList {
   // keep the kk best entries, sorted by (distance, id); idof(pos) -> row id  (`fast`: unsorted, see compact_select)
   template <typename IdOf>
   __device__ __forceinline__ void compact(int lane, IdOf idof) {
-    if (fast && cnt > kk && compact_select(lane)) return;
+    if constexpr (FAST) {
+      if (cnt > kk && compact_select(lane)) return;
+    }
     compact_rank(lane, idof);
   }
   template <typename IdOf>

@@ -1352,6 +1352,73 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
       auto key_of = [&](const Cand& c) -> uint32_t {  // 0xFFFFFFFF: not a candidate; -0 orders as +0, like the compare
         return (c.pos != CAND_EMPTY_POS && c.d == c.d) ? f32_sort_key(c.d) : 0xFFFFFFFFu;
       };
+      // A query whose filled slots fit one row per thread (the items of a sliced batch share their bounds: a single query
+      // leaves a few dozen rows in ~240 of its 1024 sources): every thread fetches ONE filled slot — found by a binary search
+      // over the prefix of the counts — and the rows are ranked against each other at once.  No sweep over the empty slots, no
+      // radix passes, no second fetch of the winners: 12.5 -> ~7 us for a single query at C3.
+      if (n_filled <= NT && a.n_src <= NT) {  // block-uniform
+        {
+          const uint32_t c = (uint32_t)tid < a.n_src ? s_pre[tid] : 0u;
+          uint32_t inc = c;
+#pragma unroll
+          for (int off = 1; off < MI355_WAVE; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+          }
+          if (lane == MI355_WAVE - 1) s_wt[wid] = inc;
+          __syncthreads();
+          uint32_t base = 0;
+          for (int w = 0; w < wid; ++w) base += s_wt[w];
+          if ((uint32_t)tid < a.n_src) s_pfx[tid] = base + inc - c;
+          if (tid == 0) s_pfx[a.n_src] = n_filled;
+        }
+        __syncthreads();
+        Cand mine;
+        mine.d = 0.f;
+        mine.pos = CAND_EMPTY_POS;
+        mine.id = 0;
+        uint32_t my_t = 0;
+        bool valid = false;
+        if ((uint32_t)tid < n_filled) {
+          uint32_t lo = 0, hi = a.n_src;  // the last source whose prefix is <= tid holds filled slot tid
+          while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pfx[mid] <= (uint32_t)tid) lo = mid; else hi = mid;
+          }
+          const uint32_t r = (uint32_t)tid - s_pfx[lo];
+          mine = src[(size_t)lo * a.src_stride + r];
+          my_t = lo * a.kk_in + r;
+          valid = key_of(mine) != 0xFFFFFFFFu;
+          f_d[tid] = valid ? mine.d + 0.0f : __builtin_nanf("");  // (a NaN is below nothing and nothing is below it)
+          f_id[tid] = mine.id;
+        }
+        {
+          const uint64_t mv = __ballot(valid);
+          if (lane == 0 && mv) atomicAdd(&st[3], (uint32_t)__popcll((unsigned long long)mv));
+        }
+        __syncthreads();
+        if (valid) {
+          const float d = mine.d + 0.0f;
+          uint32_t rank = 0;
+          for (uint32_t j0 = 0; j0 < n_filled; j0 += 4) {  // broadcast reads, four distances at a time
+            const float4 dj = *(const float4*)&f_d[j0];
+            const float dv[4] = {dj.x, dj.y, dj.z, dj.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (j0 + e >= n_filled) break;
+              bool lt = dv[e] < d;
+              if (dv[e] == d) {
+                const uint64_t idj = f_id[j0 + e];
+                lt = idj < mine.id || (idj == mine.id && j0 + e < (uint32_t)tid);
+              }
+              rank += lt ? 1u : 0u;
+            }
+          }
+          if (rank < a.k_out) emit_row(rank, mine.d, by_slot ? my_t : mine.pos, mine.id);
+        }
+        if (tid == 0) a.out_cnt[b] = min(st[3], a.k_out);
+        return;
+      }
       uint32_t tau = 0xFFFFFFFFu;
       if (n_filled > MERGE_SHORT_CAP) {
         // Two samples of NT distinct filled slots, the smaller k_out-th key wins.  (A) the first rows of every source:

@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     if (OPT && tid == 0) *s_ovf = 0u;
     __syncthreads();
     // distance table of slab `slab` (the whole row's when !SLABBED): columns = sub-quantisers slab * M .. of the index
-    auto build_lut = [&](uint32_t slab) {
+    auto build_lut = [&](uint32_t slab) __attribute__((always_inline)) {
       const uint32_t dsub = ix.dsub;
       const bool dotm = ix.metric == MI355_METRIC_DOT;
       const uint32_t jbase = SLABBED ? slab * (uint32_t)M : 0u;
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       }
 #endif
     };
-    auto load_lut_image = [&](uint32_t slab) {
+    auto load_lut_image = [&](uint32_t slab) __attribute__((always_inline)) {
       if (SK_IMG_PREFETCH && slab == 0u) {  // (requested before the loop / during the previous item's merge; IMG kernels are single-pass)
         store_image(img_pf);
       } else {
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         store_image(v);
       }
     };
-    auto make_lut = [&](uint32_t slab) {
+    auto make_lut = [&](uint32_t slab) __attribute__((always_inline)) {
       if constexpr (IMG) load_lut_image(slab);
       else build_lut(slab);
     };
@@ -1337,11 +1337,11 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       fl_id = s_floor->id;
     }
     SK_DEV(const unsigned long long dv_p0 = wall_clock64();)
-    WaveList<LR, QSHARE> wl;
+    WaveList<LR, QSHARE, LAT && SK_FAST_SEL && !OPT> wl;
     const bool whole_kk = pass_base + kk_pass >= a.kk;  // this pass completes the item's kk rows
     uint32_t pub_g = 0xFFFFFFFFu;                        // the tightest bound this lane sent to the query's global word
     const uint32_t q_share = (kk_pass + NW - 1) / NW;
-    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass, q_share, /*fast=*/LAT && SK_FAST_SEL && !OPT SK_KNOB(&& !(a.dbg & 64u)));
+    wl.init(lists + (size_t)wid * LR * MI355_WAVE, kk_pass, q_share);
     float pub_q = __builtin_huge_valf();
     bool q_sorted = false;  // the one early sort of the list happened
     float thr = f32_from_sort_key(thr0_key);
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
 
     // a finished row: tile position tp of stream w, this lane's row
     float published = __builtin_huge_valf();
-    auto consume = [&](float acc, uint32_t w, uint32_t tp) {
+    auto consume = [&](float acc, uint32_t w, uint32_t tp) __attribute__((always_inline)) {
       const uint32_t row = (w + SK_STREAMS * tp) * SK_TILE + lane;  // w = stream index
       const float d = finalize_dist(acc, ix.metric, ix.m);
       bool ok = row < len && (ranged ? in_range(d, a.range) : d == d);
@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
     // form of finalize_dist is the same single rounding: x * 1 - 0, x * 0.5 - 0, x * 1 - (m - 1)).
     const float fd_scale = ix.metric == MI355_METRIC_COSINE ? 0.5f : 1.0f;
     const float fd_bias = ix.metric == MI355_METRIC_DOT ? -(float)(ix.m - 1) : -0.0f;
-    [[maybe_unused]] auto consume2 = [&](const sk_f32x2& acc2, uint32_t sa, uint32_t sb, uint32_t tp) {
+    [[maybe_unused]] auto consume2 = [&](const sk_f32x2& acc2, uint32_t sa, uint32_t sb, uint32_t tp) __attribute__((always_inline)) {
 #ifdef MI355_DEV_KNOBS
       if (a.dbg & 32u) return;  // dev: no selection at all (what the streams alone cost)
 #endif

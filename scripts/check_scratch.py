@@ -32,6 +32,11 @@ def unit_report(src):
             return src, None, r.stdout[-2000:]
         s = open(out).read()
     rows = []
+    # a device function that was NOT inlined (round 6: the scan's selection lambda, called through s_swappc with every captured
+    # variable in scratch, after its body had grown past the inliner's threshold — twice the code, and wrong results)
+    calls = len(re.findall(r"\bs_swappc_b64\b", s))
+    if calls:
+        rows.append((f"<{calls} s_swappc_b64 calls: a device function or lambda is not inlined>", 1 << 20, 0))
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, flags=re.S):
         name, body = m.group(1), m.group(2)
         priv = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))

@@ -226,8 +226,9 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
     if (pairs && pairs < 3ull * ix->n_cus) {
       // (round 6) batches the sparse planner lays out are cut by rows, not by count: equal work items whatever the partition
       // lengths are, one per CU for a single query; a pair's candidate slots are strided by the most slices a pair may get
-      const bool sparse = pairs <= PLAN_SPARSE_MAX_PAIRS && dev_knob("MI355_PLAN_SPARSE", 1) && dev_knob("MI355_LAT_BY_ROWS", 1) &&
-                          !(ix->lut_img_ok && !ix->lut_inline_cfg);  // (the table-image kernels walk a fixed number of items per pair)
+      // (such a batch builds its tables in the work items even where batch-level table images exist — below: two more launches
+      //  cost a single query more than they save, and the image kernels walk a fixed number of items per pair)
+      const bool sparse = pairs <= PLAN_SPARSE_MAX_PAIRS && dev_knob("MI355_PLAN_SPARSE", 1) && dev_knob("MI355_LAT_BY_ROWS", 1);
       if (sparse) {
         sk_by_rows = dev_knob("MI355_LAT_IPC", 0);
         if (!sk_by_rows) sk_by_rows = PLAN_BY_ROWS_AUTO;
@@ -257,7 +258,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
   // for, and not for a maximum_nprobes second pass (device-side batch size: its slots are mostly inactive).  The images
   // get their own budget (4 * M bytes per code row and pair: 48 KiB at m = 48, 16 GiB in all); if they cannot be allocated the work
   // items build their tables as before.
-  bool lut_img = skew && ix->lut_img_ok && !ix->lut_inline_cfg && pl.kk <= 128u && !pl.act.n && dev_knob("MI355_LUT_IMAGES", 1);
+  bool lut_img = skew && ix->lut_img_ok && !ix->lut_inline_cfg && pl.kk <= 128u && !pl.act.n && !sk_by_rows && dev_knob("MI355_LUT_IMAGES", 1);
   if (lut_img) {
     const size_t per_q_img = (size_t)nprobe * (lut_image_bytes_per_pair(ix) + lut_residual_bytes_per_pair(ix));
     // (16 GiB: a C5 batch — 2048 queries x 64 probes x 96 KiB — must stay ONE chunk, or its deferred re-rank falls back to
@@ -371,8 +372,9 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       if (pl.host_q) memcpy(qarg->v, pl.host_q, sizeof(float) * ix->dim);
       int lpc = 4;
       while (lpc < 16 && (uint64_t)ix->nlist * lpc < 2ull * 64 * ix->n_cus) lpc *= 2;
+      if (const uint32_t f = dev_knob("MI355_LAT_LPC", 0)) lpc = (int)f;
       auto go = [&](auto kern, size_t lds, uint32_t cpw) -> int {
-        if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 48u * 1024) HIP_TRY(ensure_dyn_lds((const void*)kern, lds));
         hipLaunchKernelGGL(kern, dim3((ix->nlist + cpw - 1) / cpw + 1u), dim3(64), lds, st, *qarg, pl.host_q ? 1u : 0u, q, n, ix->dim, view.centroids, ix->nlist,
                            ix->w_qp.as<float>(), ix->w_qq.as<float>(), ix->w_coarse.as<float>(), pl.arm_in_front ? d_ctl : (DevCtl*)nullptr,
                            pl.arm_ticks, pl.arm_reset, ix->metric == MI355_METRIC_COSINE ? 1u : 0u);
@@ -398,7 +400,9 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       sp.coarse_out = nullptr;
       sp.ticket = ix->heads.as<uint32_t>() + 8 * SK_HEAD_STRIDE;
       sp.plan = pa;
-      hipLaunchKernelGGL(k_select_plan, dim3(n), dim3(SELPLAN_NT), ((size_t)ix->nlist + nprobe) * 4u, st, sp);
+      const size_t sp_lds = ((size_t)ix->nlist + nprobe) * 4u;
+      if (sp_lds > 40u * 1024) HIP_TRY(ensure_dyn_lds((const void*)k_select_plan, sp_lds));
+      hipLaunchKernelGGL(k_select_plan, dim3(n), dim3(SELPLAN_NT), sp_lds, st, sp);
       HIP_TRY(hipGetLastError());
     } else {
     const size_t small_lds = ((size_t)n * (((size_t)ix->dim + 3) & ~(size_t)3) + n) * sizeof(float);
@@ -425,7 +429,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       if (lpc > 1) {
         const size_t lds = coarse_split_lds(n, ix->dim, lpc);
         auto go = [&](auto kern) -> int {
-          if (lds > 48u * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          if (lds > 48u * 1024) HIP_TRY(ensure_dyn_lds((const void*)kern, lds));
           hipLaunchKernelGGL(kern, dim3((ix->nlist * lpc + 63) / 64), dim3(64), lds, st, q, n, ix->dim, ix->metric, view.centroids,
                              view.cnorm, ix->nlist, ix->w_qp.as<float>(), ix->w_qq.as<float>(), ix->w_coarse.as<float>());
           return MI355_OK;
@@ -434,7 +438,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
         if (rc != MI355_OK) return rc;
       } else {
       if (small_lds > 48u * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+        HIP_TRY(ensure_dyn_lds((const void*)k_coarse_small, small_lds));
       hipLaunchKernelGGL(k_coarse_small, dim3((ix->nlist + 63) / 64), dim3(64), small_lds, st, q, n, ix->dim, ix->metric,
                          view.centroids, view.cnorm, ix->nlist, ix->w_qp.as<float>(), ix->w_qq.as<float>(),
                          ix->w_coarse.as<float>());

@@ -113,6 +113,22 @@ int32_t need_device(int32_t device);
 void shard_plan_host(const uint64_t* po, uint32_t nlist, uint32_t shards, std::vector<uint32_t>& owner,
                      const float* weight = nullptr);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize), once per kernel, device and size.  The call costs the host tens of microseconds;
+// made on every search it pushed the submission of the launches behind it past the END of a short scan (round 6: behind a 43 us scan
+// at the reference's default index shape the merge kernel "ran" 59 us — waiting to be submitted).
+static inline hipError_t ensure_dyn_lds(const void* kern, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> g(mu);
+  size_t& have = granted[{kern, dev}];
+  if (have >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+
 // Build-time dev knobs (-DMI355_DEV_KNOBS, scripts/build_variants.sh only): environment
 // overrides for kernel tuning experiments.  The product build reads no environment.
 #ifdef MI355_DEV_KNOBS

@@ -26,8 +26,7 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_
     if (table_at_lds_zero.load(std::memory_order_relaxed) < 0)                                  \
       return fail(MI355_ERR_NOT_SUPPORTED, "scan kernel was built with static LDS in front of its table " \
                   "(the gather address assumes the table at LDS address 0)");                   \
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                (int)lds));                                                     \
+    HIP_TRY(ensure_dyn_lds((const void*)kern, lds));                                            \
     hipLaunchKernelGGL(kern, dim3(GRID), dim3(NT), lds, st, sa);                                \
   }
 #define LAUNCH_SK(LR, NT, MULTI, OPT) LAUNCH_SK_(LR, NT, MULTI, OPT, false, n_blocks)

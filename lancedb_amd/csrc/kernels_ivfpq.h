@@ -1389,27 +1389,41 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
           mine = src[(size_t)lo * a.src_stride + r];
           my_t = lo * a.kk_in + r;
           valid = key_of(mine) != 0xFFFFFFFFu;
-          f_d[tid] = valid ? mine.d + 0.0f : __builtin_nanf("");  // (a NaN is below nothing and nothing is below it)
-          f_id[tid] = mine.id;
         }
+        // every wave keeps its own k_out best rows (a radix select on ballots, one key per lane): at most 16 * k_out rows are
+        // ranked against each other — ranking all filled rows is quadratic on ONE CU (800 rows: 30 us, round 6)
+        const uint32_t mykey = valid ? f32_sort_key(mine.d) : 0xFFFFFFFFu;
+        uint32_t t_w = 0xFFFFFFFFu;
+        if (a.k_out <= (uint32_t)MI355_WAVE) t_w = wave_kth_smallest_key(mykey, a.k_out);  // (fewer valid rows: 0xFFFFFFFF, keeps all)
+        const bool keep = valid && mykey <= t_w;
+        uint32_t my_i = 0;
         {
-          const uint64_t mv = __ballot(valid);
+          const uint64_t mv = __ballot(valid), mk = __ballot(keep);
           if (lane == 0 && mv) atomicAdd(&st[3], (uint32_t)__popcll((unsigned long long)mv));
+          uint32_t base = 0;
+          if (lane == 0 && mk) base = atomicAdd(&st[2], (uint32_t)__popcll((unsigned long long)mk));
+          base = __shfl(base, 0);
+          my_i = base + (uint32_t)__popcll((unsigned long long)(mk & ((1ull << lane) - 1ull)));
+        }
+        if (keep) {
+          f_d[my_i] = mine.d + 0.0f;
+          f_id[my_i] = mine.id;
         }
         __syncthreads();
-        if (valid) {
+        const uint32_t n_surv = st[2];
+        if (keep) {
           const float d = mine.d + 0.0f;
           uint32_t rank = 0;
-          for (uint32_t j0 = 0; j0 < n_filled; j0 += 4) {  // broadcast reads, four distances at a time
+          for (uint32_t j0 = 0; j0 < n_surv; j0 += 4) {  // broadcast reads, four distances at a time
             const float4 dj = *(const float4*)&f_d[j0];
             const float dv[4] = {dj.x, dj.y, dj.z, dj.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              if (j0 + e >= n_filled) break;
+              if (j0 + e >= n_surv) break;
               bool lt = dv[e] < d;
               if (dv[e] == d) {
                 const uint64_t idj = f_id[j0 + e];
-                lt = idj < mine.id || (idj == mine.id && j0 + e < (uint32_t)tid);
+                lt = idj < mine.id || (idj == mine.id && j0 + e < my_i);
               }
               rank += lt ? 1u : 0u;
             }
@@ -1417,6 +1431,9 @@ __global__ __launch_bounds__(64 * NW) void k_merge_cands(MergeArgs a) {
           if (rank < a.k_out) emit_row(rank, mine.d, by_slot ? my_t : mine.pos, mine.id);
         }
         if (tid == 0) a.out_cnt[b] = min(st[3], a.k_out);
+#ifdef MI355_DEV_COUNTERS  // dev[5]: 7e8 + filled slots = this path
+        if (tid == 0 && a.ctl) atomicAdd(const_cast<uint32_t*>(&a.ctl->dev[5]), 700000000u + n_filled);
+#endif
         return;
       }
       uint32_t tau = 0xFFFFFFFFu;

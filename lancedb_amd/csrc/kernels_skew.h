@@ -608,7 +608,7 @@ static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(Pl
 // probe list exactly like k_select_probes (ties at the threshold by ascending partition id, the nearest partition at
 // rank 0), and the last workgroup to finish lays out the scan's work list (plan_sparse_body).
 #define SELPLAN_NT 1024
-#define SELPLAN_MAX_NLIST 8192u
+#define SELPLAN_MAX_NLIST 16384u  // (the reference's default rows / 8192 partitions: 12 207 at 100 M rows)
 struct SelectPlanArgs {
   const float* raw;        // [nq, nlist] dot chains of k_coarse_lat
   const float* qq;         // [nq] |q|^2 chains
@@ -1028,8 +1028,12 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   // IMG: the item's table image instead — quads of four columns, thread e reads quad e, e + NT, ... (coalesced 16-B loads,
   // all of a thread's loads in flight at once); requested where the residual operands are: for the first item before the
   // loop, for every later one while the previous item's lists are merged (SK_IMG_PREFETCH=0: at the item's own start)
+  // (round 6, late: with the request in flight across the previous item's merge a search returned rows with wrong distances once in
+  //  ~15 searches of 520 x 14 pairs at m = 96 / 192 — never at m = 48, never with in-item tables, never with the request at the item's own
+  //  start: 0 of 300 searches.  The prefetched registers always EQUALLED a fresh fetch (a verifying build), so the cause is not the
+  //  image data; it was not found.  The prefetch was worth nothing by itself (NOTES 11.2): it is off.)
 #ifndef SK_IMG_PREFETCH
-#define SK_IMG_PREFETCH 1
+#define SK_IMG_PREFETCH 0
 #endif
 #ifndef SK_IMG_NT_LOAD
 #define SK_IMG_NT_LOAD 1  // (the image is read once: it should not push the partition codes other queries reuse out of L2; scan -1.5 %)
@@ -1072,7 +1076,10 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   // at the start of item i thread 0 loads the record of item i + 1 from the index it popped at the start of item i - 1 —
   // long since arrived — and pops the index of item i + 2.  (pa, pa_q0, pa_n, pa_q): the older pop, its queue's bounds
   // and id when it was issued.
-  constexpr bool POP2 = IMG;
+#ifndef SK_POP2
+#define SK_POP2 1
+#endif
+  constexpr bool POP2 = IMG && SK_POP2;
   uint32_t pa = SK_NONE, pa_q0 = 0, pa_n = 0, pa_q = 0;
   if (POP2 && tid == 0 && s_rec[0].pair != SK_NONE && q_tried < 8) {
     pa_q = q_cur;
@@ -1762,6 +1769,44 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       uint32_t tot0 = 0;
 #pragma unroll
       for (int w2 = 0; w2 < NW; ++w2) tot0 += s_cnt[w2];
+      // LAT, first: the bound of the waves' BEST rows needs no compaction — a wave's best is one minimum over its list, whatever
+      // order and length (a single-position item arrives here with 128 rows per wave and no bound at all: compacting the 16 lists
+      // first was most of a 9 us merge phase at the reference's default shape).  When kk waves hold a row, cut every list at the
+      // largest of their bests and count again; lists that stay long take the general route below.
+      if constexpr (LAT && !QSHARE) {
+        if (tot0 > kk_pass + 2u * MI355_WAVE && kk_pass <= (uint32_t)NW) {  // workgroup-uniform
+          uint32_t mk = 0xFFFFFFFFu;
+#pragma unroll
+          for (int r = 0; r < LR; ++r) {
+            const uint32_t slot = (uint32_t)(r * MI355_WAVE + lane);
+            if (slot < wl.cnt) mk = min(mk, f32_sort_key(wl.list[slot].d));
+          }
+#pragma unroll
+          for (int off = 1; off < MI355_WAVE; off <<= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, off));
+          if (lane == 0) s_part[wid] = mk;
+          __syncthreads();
+          const uint32_t vp = lane < NW ? s_part[lane] : 0xFFFFFFFFu;
+          const bool bounded = (uint32_t)__popcll((unsigned long long)__ballot(vp != 0xFFFFFFFFu)) >= kk_pass;  // (the same in every wave)
+          if (bounded) {
+            uint32_t v = vp != 0xFFFFFFFFu ? vp : 0u;
+#pragma unroll
+            for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            if (tid == 0) {
+              atomicMin(s_thr, v);
+              if (whole_kk) atomicMin(a.qthr + b, v);
+            }
+            wl.filter(f32_from_sort_key(v), lane);
+            if (lane == 0) s_cnt[wid] = wl.cnt;
+          }
+          __syncthreads();
+          if (bounded) {
+            tot0 = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) tot0 += s_cnt[w2];
+          }
+        }
+      }
       if (tot0 > kk_pass + 2u * MI355_WAVE) {  // workgroup-uniform
         wl.compact(lane, idof);
         if (wl.t_run < published) {

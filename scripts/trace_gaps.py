@@ -21,18 +21,21 @@ for f in files:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
 rows.sort()
-# searches: runs that start with `first`
+# searches: runs that start with `first`; "gap": a new search starts behind every idle gap of more than 12 us
 searches, cur = [], None
+prev_end = None
 for s, e, n in rows:
-    if first in n:
+    start = (first in n) if first != "gap" else (prev_end is None or s - prev_end > 12000)
+    if start:
         if cur:
             searches.append(cur)
         cur = []
     if cur is not None:
         cur.append((s, e, n))
+    prev_end = e
 if cur:
     searches.append(cur)
-searches = [x for x in searches if len(x) == len(searches[len(searches) // 2])][-200:]
+searches = [x for x in searches[len(searches) // 3:] if len(x) == len(searches[2 * len(searches) // 3])][-200:]
 print(f"{len(searches)} searches of {len(searches[0])} kernels")
 names = [n for _, _, n in searches[0]]
 dur = np.array([[e - s for s, e, _ in x] for x in searches]) / 1e3

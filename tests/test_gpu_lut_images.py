@@ -45,7 +45,9 @@ def test_images_equal_inline_builds_and_the_oracle(oracle, m, dim, metric):
     s["part_offsets"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     g = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
     o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], metric=metric)
-    q = (s["centroids"][rng.integers(0, nlist, size=37)] + rng.normal(0, 0.5, size=(37, dim))).astype(np.float32)
+    # (520 queries: batches of up to 512 (query, partition) pairs that cannot fill the chip are cut by rows and build their tables
+    #  in the work items — round 6, tests/test_gpu_latency_mode.py; with one probe these 520 pairs are cut in two slices: image + slices)
+    q = (s["centroids"][rng.integers(0, nlist, size=520)] + rng.normal(0, 0.5, size=(520, dim))).astype(np.float32)
     for nprobe, k in ((1, 10), (5, 1), (14, 10), (14, 64), (14, 100), (14, 128)):
         kw = dict(k=k, nprobe_min=nprobe, nprobe_max=nprobe)
         g.configure(lut_inline=False)
@@ -63,9 +65,10 @@ def test_images_equal_inline_builds_and_the_oracle(oracle, m, dim, metric):
 
 
 def test_images_with_slices_refine_filter_ranges_and_second_pass(oracle):
-    """The default 768-d shape end to end: single queries cut into slices of tile positions (every slice of a pair copies
-    the SAME image), refine, prefilter, distance ranges, a NaN query, and maximum_nprobes (the second pass runs behind a
-    device-side batch size and builds its tables in the items)."""
+    """The default 768-d shape end to end: single queries and small batches (cut by rows; they build their tables in the work
+    items — round 6), batches cut into a fixed number of slices (every slice of a pair copies the SAME image), refine, prefilter,
+    distance ranges, a NaN query, and maximum_nprobes (the second pass runs behind a device-side batch size and builds its tables
+    in the items)."""
     m, dim, n, nlist = 48, 768, 120_000, 16
     rng = np.random.default_rng(5)
     s = train.synthetic_index(n, dim, nlist, m, seed=11, skew=1.0, empty_parts=2)
@@ -74,12 +77,13 @@ def test_images_with_slices_refine_filter_ranges_and_second_pass(oracle):
     o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"], raw_vectors=raw)
     g.configure(graph=False, coalesce=False)
     qb = (s["centroids"][rng.integers(0, nlist, size=200)] + rng.normal(0, 0.5, size=(200, dim))).astype(np.float32)
-    for nq, nprobe in ((1, 8), (1, 16), (3, 12), (8, 5), (200, 6)):
+    for nq, nprobe in ((1, 8), (1, 16), (3, 12), (8, 5), (100, 6), (200, 6)):
         q = qb[:nq]
         for kw in (dict(k=10), dict(k=100), dict(k=10, refine_factor=10)):
             kw = dict(nprobe_min=nprobe, nprobe_max=nprobe, **kw)
             _same(g.search(q, **kw), o.search(q, **kw))
-            assert g.stats()["lut_images"] == 1
+            # up to 512 pairs: cut by rows, tables built in the items; 600 pairs: two slices per pair + images; 1200: whole partitions
+            assert g.stats()["lut_images"] == (1 if nq * nprobe > 512 else 0)
     exp = o.search(qb, k=10, nprobe_min=6, nprobe_max=6)
     lo, hi = float(exp[1][0, 2]), float(exp[1][0, 8])
     kw = dict(k=10, nprobe_min=6, nprobe_max=6, lower_bound=lo, upper_bound=hi)
@@ -106,7 +110,7 @@ def test_images_on_a_sharded_handle_and_external_probes(oracle):
     m, dim, n, nlist = 48, 768, 60_000, 24
     rng = np.random.default_rng(9)
     s = train.synthetic_index(n, dim, nlist, m, seed=21, skew=0.7)
-    q = (s["centroids"][rng.integers(0, nlist, size=64)] + rng.normal(0, 0.5, size=(64, dim))).astype(np.float32)
+    q = (s["centroids"][rng.integers(0, nlist, size=80)] + rng.normal(0, 0.5, size=(80, dim))).astype(np.float32)  # (640 pairs: images)
     o = oracle.OracleIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
     full = lancedb_amd.IvfPqIndex(s["centroids"], s["codebook"], s["part_offsets"], s["codes"], s["row_ids"])
     exp = o.search(q, k=10, nprobe_min=8, nprobe_max=8)
@@ -121,7 +125,7 @@ def test_images_on_a_sharded_handle_and_external_probes(oracle):
         b = sh.search(q, k=10, nprobe_min=8, nprobe_max=8)
         _equal(a, b)
         parts.append(a)
-    for b in range(64):  # the k-way merge of the shards' lists in the (distance, rowid) order = the unsharded result
+    for b in range(len(q)):  # the k-way merge of the shards' lists in the (distance, rowid) order = the unsharded result
         rows = [(float(p.distances[b, j]), int(p.rowids[b, j])) for p in parts for j in range(int(p.counts[b]))]
         rows.sort()
         top = rows[:10]

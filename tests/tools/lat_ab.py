@@ -18,7 +18,8 @@ from lancedb_amd import _abi  # noqa: E402
 n = int(sys.argv[1])
 nlist = int(sys.argv[2])
 settings = sys.argv[3:] or [""]
-dim, m = 768, 96
+dim, m = 768, int(os.environ.get("LAT_M", "96"))  # LAT_M=48 LAT_NPROBE=20 with nlist = rows / 8192: the reference's default index shape
+nprobe = int(os.environ.get("LAT_NPROBE", "64"))
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(1)
@@ -37,7 +38,7 @@ torch.cuda.synchronize()
 ix = lancedb_amd.IvfPqIndex(cen, cb, po, codes, None, codes_layout=_abi.CODES_PART_TRANSPOSED)
 del codes
 q = (cen[torch.randint(0, nlist, (512,), generator=g, device=dev)] + 0.5 * torch.randn((512, dim), generator=g, device=dev)).cpu().numpy()
-kw = dict(k=10, nprobe_min=64, nprobe_max=64)
+kw = dict(k=10, nprobe_min=nprobe, nprobe_max=nprobe)
 ix.configure(profile=0, graph=False, coalesce=False)
 touched = set()
 for rep in range(2):  # every setting twice, interleaved: the box drifts

@@ -3,10 +3,11 @@ per-kernel device times of the latency path next to the wall-clock p50 / p99."""
 import sys
 import time
 
+import os
+
 import numpy as np
 import torch
 
-import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import lancedb_amd  # noqa: E402
 from lancedb_amd import _abi  # noqa: E402
@@ -14,7 +15,7 @@ from lancedb_amd import _abi  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000  # 100000000 4096: the C3 shape
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # queries per call
-dim, m = 768, 96
+dim, m = 768, int(os.environ.get("LAT_M", "96"))  # LAT_M=48 LAT_NPROBE=20, nlist = rows / 8192: the reference's default shape
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(1)
@@ -33,7 +34,8 @@ torch.cuda.synchronize()
 ix = lancedb_amd.IvfPqIndex(cen, cb, po, codes, None, codes_layout=_abi.CODES_PART_TRANSPOSED)
 del codes
 q = (cen[torch.randint(0, nlist, (512,), generator=g, device=dev)] + 0.5 * torch.randn((512, dim), generator=g, device=dev)).cpu().numpy()
-kw = dict(k=10, nprobe_min=64, nprobe_max=64)
+nprobe = int(os.environ.get("LAT_NPROBE", "64"))
+kw = dict(k=10, nprobe_min=nprobe, nprobe_max=nprobe)
 ix.configure(profile=0, graph=False, coalesce=False)
 for i in range(10):
     ix.search(q[i:i + B], **kw)

@@ -402,6 +402,38 @@ def default_shape_leg(a, torch, np, dev, n_rows=100_000_000, dim=768, parity_que
                "both_paths_return_the_same_bits": ti["rowid_checksum"] == ii["rowid_checksum"] and ti["distance_checksum"] == ii["distance_checksum"],
                "roofline_qps_at_8tbs": HBM_PEAK_GBS * 1e9 / (ti["roofline"]["algorithmic_bytes_per_launch"] / B)}
         res[f"nprobe{nprobe}"] = ent
+    # ---- what ONE caller sees on this index (rust/lancedb/src/query.rs:1011-1021: a VectorQuery is one vector): host-I/O single
+    # queries and batches of 8 at nprobes 20.  Round 6: batches too small to fill the chip take the latency front (nlist <= 16384),
+    # are cut by rows and build their tables in the work items (LAT kernels) — 228 -> 112 us for a single query.
+    try:
+        hq = qpool[0].cpu().numpy()
+        kw = dict(k=k, nprobe_min=20, nprobe_max=20)
+        ix.configure(profile=0, graph=False, coalesce=False)
+        lat_out = {}
+        for nq_call in (1, 8):
+            for i in range(8):
+                ix.search(hq[i:i + nq_call], **kw)
+            lat = []
+            for i in range(200):
+                t0 = time.perf_counter()
+                r1 = ix.search(hq[i:i + nq_call], **kw)
+                lat.append(time.perf_counter() - t0)
+            lat = np.sort(np.array(lat)) * 1e6
+            lat_out[f"batch{nq_call}_us"] = {"p50": float(lat[100]), "p99": float(lat[197]), "mean": float(lat.mean())}
+        ix.configure(profile=1, graph=False, coalesce=False)
+        r1 = ix.search(hq[7:8], **kw)
+        st1 = ix.stats()
+        lat_out["single_query_stage_us"] = {s2: st1["us_" + s2] for s2 in ("coarse", "select", "scan", "merge")}
+        # the same eight queries as one batch of the throughput path: ids and distances must be the same bits
+        rb = ix.search(qpool[0][:8].contiguous(), _abi.make_params(k=k, nprobe_min=20, nprobe_max=20))
+        torch.cuda.synchronize()
+        r8 = ix.search(hq[0:8], **kw)
+        lat_out["batch8_equals_throughput_path"] = bool((np.asarray(r8.rowids).astype(np.uint64) == rb.rowids.cpu().numpy().astype(np.uint64)).all() and
+                                                        (np.asarray(r8.distances) == rb.distances.cpu().numpy()).all())
+        res["latency_nprobe20"] = lat_out
+        ix.configure(profile=0, graph=False, coalesce=True)
+    except Exception as e:  # noqa: BLE001  (a leg never takes the line down)
+        res["latency_nprobe20"] = {"error": repr(e)}
     # ---- CPU-oracle parity sample (nprobes 20) on a host copy of the partitions the sample probes
     if a.cpu_seconds > 0 and parity_queries:
         from oracle import oracle as orc
@@ -735,6 +767,8 @@ def summary_of(result):
                                   "x_in_item": v(d, "speedup_over_in_item_tables"), "same_bits": v(d, "both_paths_return_the_same_bits")}
     if "default_shape" in sec:
         s["dflt_parity_ids"] = v(sec, "default_shape", "cpu_baseline", "parity", "rowids_bit_exact")
+        s["dflt_lat_p50_us"] = v(sec, "default_shape", "latency_nprobe20", "batch1_us", "p50")
+        s["dflt_lat8_p50_us"] = v(sec, "default_shape", "latency_nprobe20", "batch8_us", "p50")
     cc = sec.get("concurrent_callers_c3", {})
     s["callers_qps"] = {k2.replace("_threads", ""): round(v2["queries_per_s"]) for k2, v2 in cc.items()}
     for key, line in sec.items():

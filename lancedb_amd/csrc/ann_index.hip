@@ -529,7 +529,8 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       }
       if (lut_img)
         ST_TRY(launch_scan_skew_img(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
-      else if (n_slices > 1 && !ix->sk_slabbed && pl.kk <= 64u && dev_knob("MI355_LAT_KERNEL", 1))
+      else if (n_slices > 1 && !ix->sk_slabbed && dev_knob("MI355_LAT_KERNEL", 1) &&
+               (pl.kk <= 16u || (pl.kk <= 128u && sk_scan_lds(ix->sk_M, ix->sk_res_floats, 16, 3) <= 160u * 1024)))
         ST_TRY(launch_scan_skew_lat(ka, ix->sk_M, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));
       else
         ST_TRY(launch_scan_skew(ka, ix->sk_M, ix->sk_slabbed, n_blocks, (uint64_t)n * nprobe * n_slices, pl.kk, st));

@@ -31,8 +31,11 @@ static int32_t launch_scan_skew_m(const SkewArgs& sa, uint32_t n_blocks, uint64_
   }
 #define LAUNCH_SK(LR, NT, MULTI, OPT) LAUNCH_SK_(LR, NT, MULTI, OPT, false, n_blocks)
   if constexpr (LAT) {  // (the driver asks for these with k * refine_factor <= 64 only, ann_index.hip)
-    if (kk > 64) return fail(MI355_ERR_NOT_SUPPORTED, "the sliced scan kernels select k * refine_factor <= 64");
-    LAUNCH_SK(2, 1024, false, false)
+    // kk <= 16: lists of 128 rows (the waves' BEST rows bound the item); up to 128: lists of 192 and the waves' q-th bests
+    if (kk > 128 || (kk > 16 && lds_of(16, 3) > 160u * 1024))
+      return fail(MI355_ERR_NOT_SUPPORTED, "no sliced scan kernel for k * refine_factor = %u at this residual length", kk);
+    if (kk <= 16) LAUNCH_SK(2, 1024, false, false)
+    else LAUNCH_SK(3, 1024, false, false)
     HIP_TRY(hipGetLastError());
     return MI355_OK;
   } else {  // (else: a LAT launcher instantiates nothing below)

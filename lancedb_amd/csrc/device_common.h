@@ -463,7 +463,7 @@ struct WaveList {
   // compaction below reads the list entry by entry, one dependent LDS broadcast per entry: ~8 us for a full list of 128 rows.
   // A single query's work items all start without a bound, so every wave fills its list at once and compacted it twice per
   // item: 20 of a 43 us scan phase, round 6.)  Exact unless MORE rows than needed tie with the kk-th distance — then the row ids
-  // decide and the caller falls back to the ranking form: returns false, nothing changed.  Needs cnt > kk.
+  // decide and the caller falls back to the ranking form: returns false, nothing changed.
   __device__ __forceinline__ bool compact_select(int lane) {
     __threadfence_block();
     ListEnt mine[R];
@@ -500,13 +500,20 @@ struct WaveList {
       need_eq = need;
       return prefix;
     };
+    if (cnt <= kk) {  // nothing to drop: only the q-th best is news (the list keeps its order)
+      if (QTRACK && q > 1u && q <= cnt) {
+        uint32_t ne;
+        t_q = fminf(t_q, f32_from_sort_key(kth(q, ne)));
+      }
+      return true;
+    }
     uint32_t need = 0;
     const uint32_t T = kth(kk, need);
     uint32_t n_eq = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) n_eq += (uint32_t)__popcll((unsigned long long)__ballot(in[r] && key[r] == T));
     if (n_eq != need) return false;  // a tie across the boundary: the row ids decide
-    if (QTRACK && q >= 1u && q <= kk) {
+    if (QTRACK && q > 1u && q <= kk) {  // (q = 1: the callers take the minimum of the list themselves — no second select)
       uint32_t ne;
       t_q = fminf(t_q, f32_from_sort_key(kth(q, ne)));  // (a distance: ties do not matter)
     }
@@ -529,7 +536,7 @@ struct WaveList {
   template <typename IdOf>
   __device__ __forceinline__ void compact(int lane, IdOf idof) {
     if constexpr (FAST) {
-      if (cnt > kk && compact_select(lane)) return;
+      if (compact_select(lane)) return;
     }
     compact_rank(lane, idof);
   }

@@ -992,7 +992,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   uint32_t* s_thr = s_ovf + 1;                                // [1] block threshold (sort key)
   // long candidate lists (kk > 64): the shared threshold is built from every wave's q-th best,
   // q = ceil(kk / NW) (WaveList QTRACK); the kk <= 64 kernel keeps the per-wave bound alone
-  constexpr bool QSHARE = LR >= 3 || (LAT && SK_LAT_QSHARE);  // (LAT: every item of a sliced batch starts without a bound — the shared one is what ends the filling)
+  constexpr bool QSHARE = (LR >= 3 && !LAT) || (LAT && SK_LAT_QSHARE);  // (LAT: every item of a sliced batch starts without a bound — the shared one is what ends the filling)
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
   SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
   PassFloor* s_floor = (PassFloor*)(s_rec + 2);                          // [1] (MULTI)
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       fl_id = s_floor->id;
     }
     SK_DEV(const unsigned long long dv_p0 = wall_clock64();)
-    WaveList<LR, QSHARE, LAT && SK_FAST_SEL && !OPT> wl;
+    WaveList<LR, QSHARE || LAT, LAT && SK_FAST_SEL && !OPT> wl;  // (LAT: the q-th best of a compaction feeds the lean bound below)
     const bool whole_kk = pass_base + kk_pass >= a.kk;  // this pass completes the item's kk rows
     uint32_t pub_g = 0xFFFFFFFFu;                        // the tightest bound this lane sent to the query's global word
     const uint32_t q_share = (kk_pass + NW - 1) / NW;
@@ -1400,14 +1400,20 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
               // the waves' BEST rows (see the block merge below): as soon as kk waves have compacted once, the largest of their
               // bests bounds kk rows of the item — an order of magnitude below a wave's own kk-th best.  Any snapshot of
               // s_part is valid: a wave's entry only falls, and the wave keeps a row at or below every value it published.
-              if (kk_pass <= (uint32_t)NW) {
+              // (k <= 16: q = 1, a wave's best is one minimum over its compacted list; beyond: its q-th best, q = ceil(kk / 16), which
+              //  the compaction's second radix select left in t_q — waves that hold q rows each bound n * q rows by their largest)
+              {
                 uint32_t mk = 0xFFFFFFFFu;
-                if ((uint32_t)lane < wl.cnt) mk = f32_sort_key(wl.list[lane].d);
+                if (q_share == 1u) {
+                  if ((uint32_t)lane < wl.cnt) mk = f32_sort_key(wl.list[lane].d);
 #pragma unroll
-                for (int off = 1; off < MI355_WAVE; off <<= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, off));
+                  for (int off = 1; off < MI355_WAVE; off <<= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, off));
+                } else if (wl.t_q < __builtin_huge_valf()) {
+                  mk = f32_sort_key(wl.t_q);
+                }
                 if (lane == 0) __hip_atomic_store(s_part + wid, mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t vp = lane < NW ? __hip_atomic_load(s_part + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xFFFFFFFFu;
-                if ((uint32_t)__popcll((unsigned long long)__ballot(vp != 0xFFFFFFFFu)) >= kk_pass) {
+                if ((uint32_t)__popcll((unsigned long long)__ballot(vp != 0xFFFFFFFFu)) * q_share >= kk_pass) {
                   uint32_t v = vp != 0xFFFFFFFFu ? vp : 0u;
 #pragma unroll
                   for (int off = 1; off < NW; off <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
@@ -1774,7 +1780,7 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       // first was most of a 9 us merge phase at the reference's default shape).  When kk waves hold a row, cut every list at the
       // largest of their bests and count again; lists that stay long take the general route below.
       if constexpr (LAT && !QSHARE) {
-        if (tot0 > kk_pass + 2u * MI355_WAVE && kk_pass <= (uint32_t)NW) {  // workgroup-uniform
+        if (tot0 > kk_pass + 2u * MI355_WAVE && q_share == 1u) {  // workgroup-uniform (kk <= 16)
           uint32_t mk = 0xFFFFFFFFu;
 #pragma unroll
           for (int r = 0; r < LR; ++r) {
@@ -1822,16 +1828,20 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
         // with a dozen rows in all instead of 160.
         if constexpr (LAT && !QSHARE) {
           uint32_t mk = 0xFFFFFFFFu;
-          if ((uint32_t)lane < wl.cnt) mk = f32_sort_key(wl.list[lane].d);  // (compacted: cnt <= kk_pass <= 64)
+          if (q_share == 1u) {
+            if ((uint32_t)lane < wl.cnt) mk = f32_sort_key(wl.list[lane].d);  // (compacted: cnt <= kk_pass <= 16)
 #pragma unroll
-          for (int off = 1; off < MI355_WAVE; off <<= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, off));
+            for (int off = 1; off < MI355_WAVE; off <<= 1) mk = min(mk, (uint32_t)__shfl_xor((int)mk, off));
+          } else if (wl.t_q < __builtin_huge_valf()) {
+            mk = f32_sort_key(wl.t_q);  // (the wave's q-th best, q = ceil(kk / 16): left by the compaction above)
+          }
           if (lane == 0) s_part[wid] = mk;  // (reset to "no row" at the item's start)
         }
         __syncthreads();
         if constexpr (LAT && !QSHARE) {
           const uint32_t vp = lane < NW ? s_part[lane] : 0xFFFFFFFFu;
           const uint32_t n_have = (uint32_t)__popcll((unsigned long long)__ballot(vp != 0xFFFFFFFFu));
-          if (n_have >= kk_pass) {  // (wave-uniform, the same in every wave)
+          if (n_have * q_share >= kk_pass) {  // (wave-uniform, the same in every wave)
             // the kk_pass-th smallest of the waves' bests would do; their maximum is one reduction
             uint32_t v = vp != 0xFFFFFFFFu ? vp : 0u;
 #pragma unroll
@@ -1861,6 +1871,28 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
           if (wl.fast) wl.filter(f32_from_sort_key(tk), lane);  // (a list compacted by selection is not sorted)
           else wl.prune(f32_from_sort_key(tk), lane);
         }
+        if (lane == 0) s_cnt[wid] = wl.cnt;
+        __syncthreads();
+      }
+    }
+    // LAT, k beyond a few dozen: the bounds above leave ~2.5 kk rows (16 waves x their q-th bests), and the ranking below is
+    // quadratic — 50 us of merge per item at k = 100 on single-position items (the reference's default shape).  The EXACT kk-th
+    // smallest key of all lists (four histogram passes over the lists where they lie; the dead table's first KiB holds the
+    // histogram) cuts them to kk rows plus ties first.
+    if constexpr (LAT && !QSHARE) {
+      uint32_t tot1 = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) tot1 += s_cnt[w2];
+      if (tot1 > 2u * kk_pass + 32u) {  // workgroup-uniform
+        uint32_t* hist = (uint32_t*)smem;
+        const uint32_t T = block_kth_smallest_key<NT>(
+            [&](uint32_t i) -> uint32_t {
+              const uint32_t w2 = i / (uint32_t)(LR * MI355_WAVE), sl = i % (uint32_t)(LR * MI355_WAVE);
+              return sl < s_cnt[w2] ? f32_sort_key(lists[i].d) : 0xFFFFFFFFu;
+            },
+            (uint32_t)(NW * LR * MI355_WAVE), kk_pass, hist, hist + 256);
+        wl.filter(f32_from_sort_key(T), lane);
+        __syncthreads();  // (every thread read the old counts)
         if (lane == 0) s_cnt[wid] = wl.cnt;
         __syncthreads();
       }

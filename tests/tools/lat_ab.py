@@ -38,7 +38,7 @@ torch.cuda.synchronize()
 ix = lancedb_amd.IvfPqIndex(cen, cb, po, codes, None, codes_layout=_abi.CODES_PART_TRANSPOSED)
 del codes
 q = (cen[torch.randint(0, nlist, (512,), generator=g, device=dev)] + 0.5 * torch.randn((512, dim), generator=g, device=dev)).cpu().numpy()
-kw = dict(k=10, nprobe_min=nprobe, nprobe_max=nprobe)
+kw = dict(k=int(os.environ.get("LAT_K", "10")), nprobe_min=nprobe, nprobe_max=nprobe)
 ix.configure(profile=0, graph=False, coalesce=False)
 touched = set()
 for rep in range(2):  # every setting twice, interleaved: the box drifts

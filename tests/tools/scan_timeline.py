@@ -18,7 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 settings = sys.argv[4:] or [""]
-dim, m = 768, 96
+dim, m = 768, int(os.environ.get("LAT_M", "96"))  # (LAT_M / LAT_NPROBE / LAT_K: like lat_ab.py)
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(1)
@@ -37,7 +37,8 @@ torch.cuda.synchronize()
 ix = lancedb_amd.IvfPqIndex(cen, cb, po, codes, None, codes_layout=_abi.CODES_PART_TRANSPOSED)
 del codes
 q = (cen[torch.randint(0, nlist, (512,), generator=g, device=dev)] + 0.5 * torch.randn((512, dim), generator=g, device=dev)).cpu().numpy()
-kw = dict(k=10, nprobe_min=64, nprobe_max=64)
+nprobe = int(os.environ.get("LAT_NPROBE", "64"))
+kw = dict(k=int(os.environ.get("LAT_K", "10")), nprobe_min=nprobe, nprobe_max=nprobe)
 ix.configure(profile=0, graph=False, coalesce=False)
 L = _lib.lib()
 L.mi355_dev_timeline.restype = C.c_int32

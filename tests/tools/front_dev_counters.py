@@ -13,6 +13,7 @@ from lancedb_amd import _abi, _lib  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # queries per call (the planning workgroup of a batch is the LAST one to finish its selection)
 dim, m = 768, 96
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
@@ -36,12 +37,12 @@ kw = dict(k=10, nprobe_min=64, nprobe_max=64)
 ix.configure(profile=0, graph=False, coalesce=False)
 L = _lib.lib()
 for i in range(10):
-    ix.search(q[i:i + 1], **kw)
+    ix.search(q[i:i + B], **kw)
 c = (C.c_uint32 * 8)()
 L.mi355_dev_counters(ix._h, c, C.c_int32(1))
 N = 200
 for i in range(N):
-    ix.search(q[i:i + 1], **kw)
+    ix.search(q[i:i + B], **kw)
 L.mi355_dev_counters(ix._h, c, C.c_int32(0))
 t = 0.01
 s = max(c[3], 1)

@@ -400,6 +400,7 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
       sp.coarse_out = nullptr;
       sp.ticket = ix->heads.as<uint32_t>() + 8 * SK_HEAD_STRIDE;
       sp.plan = pa;
+      sp.select_only = 0;
       const size_t sp_lds = ((size_t)ix->nlist + nprobe) * 4u;
       if (sp_lds > 40u * 1024) HIP_TRY(ensure_dyn_lds((const void*)k_select_plan, sp_lds));
       hipLaunchKernelGGL(k_select_plan, dim3(n), dim3(SELPLAN_NT), sp_lds, st, sp);
@@ -455,9 +456,27 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
                          ix->w_coarse.as<float>(), act);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
+    if (skew && ix->nlist <= SELPLAN_MAX_NLIST && nprobe <= ix->nlist && dev_knob("MI355_SELECT_WIDE", 1)) {
+      // (round 6) the latency front's selection, one 1024-thread workgroup per query, for batches too: finished scores in, no plan
+      SelectPlanArgs sp{};
+      sp.raw = ix->w_coarse.as<float>();
+      sp.metric = ix->metric;
+      sp.nlist = ix->nlist;
+      sp.nprobe = nprobe;
+      sp.plen = view.plen;
+      sp.probes = ix->w_probes.as<uint32_t>();
+      sp.stat_rows = d_stat;
+      sp.qthr = ix->qthr.as<uint32_t>();
+      sp.plan.act = act;
+      sp.select_only = 1;
+      const size_t sp_lds = ((size_t)ix->nlist + nprobe) * 4u;
+      if (sp_lds > 40u * 1024) HIP_TRY(ensure_dyn_lds((const void*)k_select_plan, sp_lds));
+      hipLaunchKernelGGL(k_select_plan, dim3(n), dim3(SELPLAN_NT), sp_lds, st, sp);
+    } else {
     hipLaunchKernelGGL(k_select_probes, dim3(n), dim3(256), 0, st, ix->w_coarse.as<float>(),
                        ix->nlist, nprobe, view.plen, ix->w_probes.as<uint32_t>(), d_stat, act,
                        skew ? ix->qthr.as<uint32_t>() : (uint32_t*)nullptr);
+    }
     HIP_TRY(hipGetLastError());
     }
     }  // !lat_front

@@ -622,6 +622,11 @@ struct SelectPlanArgs {
   float* coarse_out;       // [nq, nlist] finished scores (what k_coarse_small would have written), or nullptr
   uint32_t* ticket;        // one word, zero between launches
   PlanArgs plan;
+  // select_only (round 6: batches of any size, nlist <= SELPLAN_MAX_NLIST): `raw` holds FINISHED scores (k_coarse_mfma), the workgroup
+  // selects its query's probes — the same set, the nearest partition at rank 0 — adds the probed rows to the statistics, and nobody
+  // plans: a 1024-thread workgroup that radix-selects over the key bits that DIFFER with its keys in LDS takes ~8 us per query where
+  // k_select_probes' four byte passes over global memory took 22 (176 -> ~50 us per 2048 queries at 12 207 partitions).
+  uint32_t select_only;
 };
 static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
@@ -635,6 +640,7 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t b = blockIdx.x, nlist = a.nlist, nprobe = a.nprobe;
   uint32_t* out = a.probes + (size_t)b * nprobe;
+  if (a.select_only && !a.plan.act.on(b)) return;  // (an inactive slot of a device-side batch size: like k_select_probes)
 #ifdef MI355_DEV_FRONT  // dev: query 0's stage times -> DevCtl::dev[4..7] (keys / radix windows / emit + ticket / plan)
   const unsigned long long sp_t0 = wall_clock64();
 #endif
@@ -652,7 +658,7 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   __syncthreads();
   {
     const float* src = a.raw + (size_t)b * nlist;
-    const float qq = a.metric == MI355_METRIC_DOT ? 0.f : a.qq[b];
+    const float qq = (a.select_only || a.metric == MI355_METRIC_DOT) ? 0.f : a.qq[b];
     uint32_t k_and = 0xFFFFFFFFu, k_or = 0;
     constexpr int KPT = (int)(SELPLAN_MAX_NLIST / SELPLAN_NT);  // scores per thread: all loaded before the first is used
     float s_acc[KPT], s_cn[KPT];
@@ -660,13 +666,13 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
     for (int i = 0; i < KPT; ++i) {
       const uint32_t pc = min((uint32_t)tid + (uint32_t)i * NT, nlist - 1u);
       s_acc[i] = src[pc];
-      s_cn[i] = a.cnorm[pc];
+      s_cn[i] = a.select_only ? 0.f : a.cnorm[pc];
     }
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const uint32_t p = (uint32_t)tid + (uint32_t)i * NT;
       if (p < nlist) {
-        const float v = a.metric == MI355_METRIC_DOT ? 1.0f - s_acc[i] : __fmaf_rn(-2.0f, s_acc[i], qq + s_cn[i]);
+        const float v = a.select_only ? s_acc[i] : a.metric == MI355_METRIC_DOT ? 1.0f - s_acc[i] : __fmaf_rn(-2.0f, s_acc[i], qq + s_cn[i]);
         if (a.coarse_out) a.coarse_out[(size_t)b * nlist + p] = v;
         const uint32_t key = f32_sort_key(v);
         s_keys[p] = key;
@@ -794,6 +800,14 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
     __syncthreads();
   }
   for (uint32_t i = tid; i < nprobe; i += NT) out[i] = s_out[i];
+  if (a.select_only) {  // the query's probed rows -> statistics; no work list from here
+    unsigned long long rows = 0;
+    for (uint32_t i = tid; i < nprobe; i += NT) rows += a.plen[s_out[i]];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) rows += (unsigned long long)__shfl_xor((long long)rows, off);
+    if (lane == 0 && rows && a.stat_rows) atomicAdd(a.stat_rows, rows);
+    return;
+  }
   const bool alone = gridDim.x == 1u;  // a single query: this workgroup plans from its own LDS copy, no ticket, no fence
   if (!alone) {
     __threadfence();  // this query's probe list is at L2 before the ticket is taken

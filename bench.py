@@ -469,6 +469,9 @@ def latency_and_concurrency(a, np, ix, qpool):
     ix.search(hq[7:8], **kw)
     st = ix.stats()
     out["single_query_stage_us"] = {s2: st["us_" + s2] for s2 in ("coarse", "select", "scan", "merge")}
+    out["single_query_stage_us_note"] = ("intervals between HIP events recorded around the four launches: every marker adds ~5 us of queue time, so the "
+                                         "stages sum to MORE than the eager p50 beside them; the kernel trace of the same searches (rocprofv3 --kernel-trace, "
+                                         "committed: profiles/r06_o_kernel_trace_latency_paths_final_tree.txt) is 10.1 + 16.5 + 59.7 + 9.0 = 95.5 us back to back")
     # (concurrent callers: secondary.concurrent_callers_c3 — C++ threads; Python threads measured the interpreter lock)
     ix.configure(profile=0, graph=False, coalesce=True)  # the defaults of a freshly opened handle
     return out

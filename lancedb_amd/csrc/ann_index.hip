@@ -456,8 +456,10 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
                          ix->w_coarse.as<float>(), act);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(es.ev[1], st));
-    if (skew && ix->nlist <= SELPLAN_MAX_NLIST && nprobe <= ix->nlist && dev_knob("MI355_SELECT_WIDE", 1)) {
-      // (round 6) the latency front's selection, one 1024-thread workgroup per query, for batches too: finished scores in, no plan
+    if (skew && ix->nlist > 8192u && ix->nlist <= SELPLAN_MAX_NLIST && nprobe <= ix->nlist && dev_knob("MI355_SELECT_WIDE", 1)) {
+      // (round 6) the latency front's selection, one 1024-thread workgroup per query, for batches too: finished scores in, no plan.
+      // From 8192 partitions: at 12 207 it takes 128 us per 2048 queries where k_select_probes takes 177; at 4096 it is the
+      // slower one (85 against 72 us: eight 256-thread workgroups per CU hide their own latencies better than two of 1024)
       SelectPlanArgs sp{};
       sp.raw = ix->w_coarse.as<float>();
       sp.metric = ix->metric;

@@ -226,7 +226,8 @@ typedef struct mi355_stats {
   uint64_t partitions_probed;  /* sum over queries */
   uint64_t vectors_scanned;    /* sum over (query, partition) pairs */
   uint64_t code_bytes_scanned; /* algorithmic bytes: m*nbits/8 per vector per query */
-  uint64_t work_items;         /* scan work items launched */
+  uint64_t work_items;         /* scan work items launched; for batches cut by rows on the device (up to 512 (query, partition) pairs
+                                  that cannot fill the chip) the candidate-slot groups laid out for them: an upper bound of the items */
   float us_coarse;             /* per-stage device time; 0 unless profiling on */
   float us_select;
   float us_plan;               /* between probe selection and the scan kernel: work list + table images */

@@ -41,6 +41,7 @@ q = (cen[torch.randint(0, nlist, (512,), generator=g, device=dev)] + 0.5 * torch
 kw = dict(k=int(os.environ.get("LAT_K", "10")), nprobe_min=nprobe, nprobe_max=nprobe)
 ix.configure(profile=0, graph=False, coalesce=False)
 touched = set()
+NB = int(os.environ.get("LAT_B", "8"))  # queries of the batch timed beside the single query
 for rep in range(2):  # every setting twice, interleaved: the box drifts
     for s in settings:
         for k in touched:
@@ -61,6 +62,6 @@ for rep in range(2):  # every setting twice, interleaved: the box drifts
         lat = np.sort(np.array(lat)) * 1e6
         t0 = time.perf_counter()
         for i in range(50):
-            r8 = ix.search(q[8 * i:8 * i + 8], **kw)
+            r8 = ix.search(q[NB * i % 448:NB * i % 448 + NB], **kw)
         b8 = (time.perf_counter() - t0) / 50 * 1e6
-        print(f"[{s or 'default':40s}] p50 {lat[150]:6.1f} us  p99 {lat[296]:6.1f} us  batch of 8: {b8:6.1f} us  ids {chk:012x}", flush=True)
+        print(f"[{s or 'default':40s}] p50 {lat[150]:6.1f} us  p99 {lat[296]:6.1f} us  batch of {NB}: {b8:6.1f} us  ids {chk:012x}", flush=True)

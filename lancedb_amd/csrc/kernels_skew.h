@@ -1008,7 +1008,11 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   // q = ceil(kk / NW) (WaveList QTRACK); the kk <= 64 kernel keeps the per-wave bound alone
   constexpr bool QSHARE = (LR >= 3 && !LAT) || (LAT && SK_LAT_QSHARE);  // (LAT: every item of a sliced batch starts without a bound — the shared one is what ends the filling)
   uint32_t* s_q = s_thr + 1;                                  // [9] queue bounds
-  SkewItem* s_rec = (SkewItem*)(((size_t)(s_q + 9) + 31) & ~(size_t)31);  // [2] current / next item
+  // (an OFFSET from the LDS base, not a pointer rounded through size_t: that cast lost the address space and every access to the
+  //  records became a FLAT instruction — counted in vmcnt AND lgkmcnt, free to complete out of order with the global loads around
+  //  it; 14 of them in a kernel, found while looking for the image-prefetch failures of NOTES 11.11 — which this did not cure)
+  const uint32_t rec_off = ((uint32_t)((const unsigned char*)(s_q + 9) - smem) + 31u) & ~31u;  // (smem is 16-B aligned at LDS address 0)
+  SkewItem* s_rec = (SkewItem*)(smem + rec_off);  // [2] current / next item
   PassFloor* s_floor = (PassFloor*)(s_rec + 2);                          // [1] (MULTI)
   // the gather address is (code << 9) | column bytes: the table must start at LDS address 0, i.e. the kernel must own
   // no static __shared__ in front of its dynamic block — a compile-time property the launcher checks on the host
@@ -1328,6 +1332,34 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       nxt_valid = true;
     }
     __syncthreads();
+#ifdef SK_IMG_VERIFY2  // dev: the LDS table against the image in memory (non-slabbed IMG kernels): dev[6] after the store, dev[7] after the scan
+    [[maybe_unused]] auto verify_table = [&](uint32_t which) {
+      if constexpr (IMG && !SLABBED) {
+        sk_f32x4 v2[IMG_PER];
+        fetch_image(pair, 0u, v2);
+        uint32_t nbad = 0;
+#pragma unroll
+        for (int u = 0; u < IMG_PER; ++u) {
+          const uint32_t e = (uint32_t)tid + (uint32_t)u * NT;
+          if (IMG_NQ % NT == 0 || e < IMG_NQ) {
+            const uint32_t c = (e >> 2) & 255u, j = (e >> 10) * 16u + (e & 3u) * 4u;
+            uint32_t at, dup;
+            sk_lut_slots(c, j + 3u, (uint32_t)M, at, dup);
+            const sk_f32x4 t = *(const sk_f32x4*)(lut + at - 3u);
+            nbad += (__float_as_uint(t.x) != __float_as_uint(v2[u].x) || __float_as_uint(t.y) != __float_as_uint(v2[u].y) ||
+                     __float_as_uint(t.z) != __float_as_uint(v2[u].z) || __float_as_uint(t.w) != __float_as_uint(v2[u].w)) ? 1u : 0u;
+            if (dup != SK_NONE) {
+              const sk_f32x4 t2 = *(const sk_f32x4*)(lut + dup - 3u);
+              nbad += (__float_as_uint(t2.x) != __float_as_uint(v2[u].x) || __float_as_uint(t2.w) != __float_as_uint(v2[u].w)) ? 1u : 0u;
+            }
+          }
+        }
+        if (nbad) atomicAdd(&a.ctl->dev[which], nbad);
+      }
+    };
+    verify_table(6);
+    __syncthreads();
+#endif
 
     SK_TL(if (tli) tli[1] = wall_clock64();)
     SK_DEV(const unsigned long long dv_t1 = wall_clock64();
@@ -1705,6 +1737,11 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
 
     __builtin_amdgcn_s_setprio(0);
     SK_TL(if (tli) tli[2] = wall_clock64();)
+#ifdef SK_IMG_VERIFY2
+    __syncthreads();
+    verify_table(7);
+    __syncthreads();
+#endif
     SK_DEV(const unsigned long long dv_pw = wall_clock64();)  // this wave's streams are done
     // ---- block result: exact kk_pass best of all waves' lists, written sorted ----
     if (!LAT && wl.cnt > kk_pass) wl.compact(lane, idof);  // (LAT: the block below shrinks long lists — once, for the workgroup)

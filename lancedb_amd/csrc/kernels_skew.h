@@ -1047,9 +1047,9 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
   // all of a thread's loads in flight at once); requested where the residual operands are: for the first item before the
   // loop, for every later one while the previous item's lists are merged (SK_IMG_PREFETCH=0: at the item's own start)
   // (round 6, late: with the request in flight across the previous item's merge a search returned rows with wrong distances once in
-  //  ~15 searches of 520 x 14 pairs at m = 96 / 192 — never at m = 48, never with in-item tables, never with the request at the item's own
-  //  start: 0 of 300 searches.  The prefetched registers always EQUALLED a fresh fetch (a verifying build), so the cause is not the
-  //  image data; it was not found.  The prefetch was worth nothing by itself (NOTES 11.2): it is off.)
+  //  ~15 searches of 520 x 14 pairs at m = 96 / 192.  The cause was NOT the prefetch — a barrier inside a branch that was not
+  //  workgroup-uniform in the block merge, see `tk0` below; the prefetch only widened its window — and with it fixed a prefetching
+  //  build is clean (0 of 600 searches).  The prefetch measured worth nothing by itself (NOTES 11.2) and stays off.)
 #ifndef SK_IMG_PREFETCH
 #define SK_IMG_PREFETCH 0
 #endif
@@ -1805,12 +1805,18 @@ __global__ __launch_bounds__(NT, TWO ? 4 : NT / 256) void k_scan_skew(SkewArgs a
       // The lists were filled under the bounds known when their rows arrived; the bound the workgroup holds now — its
       // own or one of the query's other work items' — cuts them before they are ranked.  (A single query's 512 slices
       // run at the same time without any bound: each would rank, and hand the final merge, its own kk best rows.)
-      const uint32_t tk0 = *s_thr;  // workgroup-uniform: nothing writes it between the barrier above and this read
+      // The barrier behind this read is UNCONDITIONAL.  Until late in round 6 it sat inside `if (tk0 != no bound)`: with no bound
+      // yet — a query's first item on a partition so short that no list filled: 2048 rows are exactly 128 per wave — a fast wave went
+      // on to the block below, compacted its list and published its kk-th best to s_thr BEFORE a slow wave had read tk0; the slow wave
+      // then saw a bound, took the branch and waited at a barrier the others never reached: from there the waves of the workgroup
+      // were one barrier apart (a wave could start the next item while others still merged this one).  Wrong distances once in ~15
+      // searches of 520 x 14 pairs with the table-image prefetch widening the window (NOTES 11.11), never caught without it.
+      const uint32_t tk0 = *s_thr;
       if (tk0 != 0xFFFFFFFFu) {
         wl.filter(f32_from_sort_key(tk0), lane);
         if (lane == 0) s_cnt[wid] = wl.cnt;
-        __syncthreads();
       }
+      __syncthreads();
     }
     // Exact (distance, rowid) ranks of the lists' rows, one row per WAVE at a time, the 64 lanes
     // comparing it with 64 rows of the concatenated lists per step: every step is an independent

@@ -810,7 +810,10 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   }
   const bool alone = gridDim.x == 1u;  // a single query: this workgroup plans from its own LDS copy, no ticket, no fence
   if (!alone) {
-    __threadfence();  // this query's probe list is at L2 before the ticket is taken
+    // this query's probe list is at L2 before the ticket is taken: a RELEASE only (every wave waits for its own stores and writes the
+    // L2 back) — the full fence also invalidated this XCD's L2 in every wave, and the planner behind it reads the probes with
+    // agent-scope loads anyway (emit + ticket 6.1 -> 4.3 us per call of a batch, tests/tools/front_dev_counters.py)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) {
       const uint32_t t = atomicAdd(a.ticket, 1u);

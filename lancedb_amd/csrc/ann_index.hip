@@ -71,7 +71,7 @@ extern "C" int32_t mi355_last_stats(mi355_index* ix, mi355_stats* out) try {
   return MI355_OK;
 } MI355_ABI_GUARD("mi355_last_stats")
 
-#if defined(MI355_DEV_COUNTERS) || defined(MI355_DEV_FRONT) || defined(SK_IMG_VERIFY2)
+#if defined(MI355_DEV_COUNTERS) || defined(MI355_DEV_FRONT) || defined(MI355_DEV_PLAN)
 // dev builds only (never in the product library): the scan's phase ticks and selection counters (or the front kernels' stage ticks)
 extern "C" int32_t mi355_dev_counters(mi355_index* ix, uint32_t* out8, int32_t reset) try {
   HIP_TRY(hipSetDevice(ix->device));

@@ -472,18 +472,26 @@ __host__ __device__ __forceinline__ uint32_t sk_positions(uint32_t len) {
 }
 #define PLAN_BY_ROWS_AUTO 0xFFFFFFFFu
 #define PLAN_T_TRIES 4u  // candidate positions-per-item tried side by side (by_rows)
-#define PLAN_SQ_WORDS 13u
+#define PLAN_SQ_BINS 13u   // s_q[13 ..]: 16 bins x {pairs, items, cursor}
+#define PLAN_SQ_WORDS (PLAN_SQ_BINS + 48u)
 template <bool FRESH>
 __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_key /*[PLAN_SPARSE_MAX_PAIRS]*/, uint32_t* s_xf /*[9]*/,
                                                  uint32_t* s_q /*[PLAN_SQ_WORDS]*/,
                                                  const uint32_t* lds_probes = nullptr /*[n_pairs] in LDS: skip the global read*/,
                                                  unsigned long long* stat_rows = nullptr /*+= probed rows of the batch*/,
-                                                 uint32_t* s_nsl = nullptr /*[PLAN_SPARSE_MAX_PAIRS] (by_rows) items of every pair*/) {
+                                                 uint2* s_list = nullptr /*[PLAN_SPARSE_MAX_PAIRS] the pairs grouped by bin: {key, items << 16 | pair}*/) {
   const uint32_t i = threadIdx.x, lane = i & 63u;
   const uint32_t ncls = a.best_first ? 2u : 1u;
-  const bool by_rows = a.by_rows != 0u && s_nsl != nullptr && a.n_slices > 1u;
+  const bool by_rows = a.by_rows != 0u && a.n_slices > 1u;
+#ifdef MI355_DEV_PLAN
+  const unsigned long long pl_t0 = wall_clock64();
+  unsigned long long pl_t1 = 0, pl_t2 = 0, pl_t3 = 0;
+#define PL_STAMP(x) x = wall_clock64()
+#else
+#define PL_STAMP(x)
+#endif
   if (i < 9) s_xf[i] = a.xcd_first[i];
-  // [0..8] items of queue x (then: items before queue x), [9] probed rows, [10] tile positions, [11], [12] items at T0 + k, two per word
+  // [9] probed rows, [10] tile positions, [11], [12] items at T0 + k, two per word, [13 ..] the bins ([0..8]: unused)
   if (i < PLAN_SQ_WORDS) s_q[i] = 0;
   __syncthreads();
   // (every thread loads unconditionally at clamped indices — its probe, then the five per-partition words side by side:
@@ -524,6 +532,7 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
     __syncthreads();
     if (stat_rows && i == 0 && s_q[9]) atomicAdd(stat_rows, (unsigned long long)s_q[9]);
   }
+  PL_STAMP(pl_t1);
   // work items of this pair
   uint32_t nsl = live ? a.n_slices : 0u;
   if (by_rows) {
@@ -553,28 +562,43 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
     for (uint32_t k = PLAN_T_TRIES; k-- > 0;)
       if (n_at[k] <= cap) t = t0 + k;
     nsl = live ? max(1u, min((pos + t - 1u) / t, a.n_slices)) : 0u;
-    if (i < PLAN_SPARSE_MAX_PAIRS) s_nsl[i] = nsl;
   }
-  if (live) atomicAdd(&s_q[xq], nsl);  // (the keys of queue x lie in [ncls * s_xf[x], ncls * s_xf[x + 1]))
-  __syncthreads();
+  // The place of a pair's items: behind the items of the BINS below its own — (queue, class), class 1 (the nearest partitions) first, the
+  // order of `key` — and behind the pairs of its own bin with a smaller key.  Counting over all pairs instead (every thread sweeping
+  // 512 keys in LDS) was 13 of the 24 us a batch of 8 spent planning: the sweep is LDS-bandwidth-bound however it is split.
+  uint32_t* s_bcnt = s_q + PLAN_SQ_BINS;         // [16] pairs per bin
+  uint32_t* s_bitems = s_bcnt + 16;              // [16] items per bin
+  uint32_t* s_bcur = s_bitems + 16;              // [16] scatter cursors
+  const uint32_t bin = xq * 2u + ((ncls == 2u && plan_class(a, i) == 0u) ? 1u : 0u);
   if (live) {
-    uint32_t before = 0;  // items of the pairs placed before this one
-    if (by_rows) {
-      for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {  // (s_key beyond n_pairs holds 0xFFFFFFFF: never below a real key)
-        const uint4 kj = *(const uint4*)&s_key[j0], nj = *(const uint4*)&s_nsl[j0];
-        const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w}, nv[4] = {nj.x, nj.y, nj.z, nj.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) before += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? nv[e] : 0u;
-      }
-    } else {
-      for (uint32_t j0 = 0; j0 < a.n_pairs; j0 += 4) {
-        const uint4 kj = *(const uint4*)&s_key[j0];
-        const uint32_t kv[4] = {kj.x, kj.y, kj.z, kj.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) before += (kv[e] < key || (kv[e] == key && j0 + e < i)) ? 1u : 0u;
-      }
-      before *= a.n_slices;
+    atomicAdd(&s_bcnt[bin], 1u);
+    atomicAdd(&s_bitems[bin], nsl);
+  }
+  __syncthreads();
+  uint32_t off_pairs = 0, off_items = 0;
+  if (live) {
+    for (uint32_t y = 0; y < bin; ++y) {
+      off_pairs += s_bcnt[y];
+      off_items += s_bitems[y];
     }
+    s_list[off_pairs + atomicAdd(&s_bcur[bin], 1u)] = make_uint2(key, (nsl << 16) | i);  // (nsl <= 64, i < 512)
+  }
+  __syncthreads();
+  PL_STAMP(pl_t2);
+  uint32_t before = off_items;
+  if (live) {
+    // (the bin's members in a row, key and items side by side: a list of pair indices made every step two DEPENDENT LDS reads — 10 us
+    //  for the 63 members of a batch of 8's bins)
+    const uint32_t n_b = s_bcnt[bin];
+    const uint2* mem = s_list + off_pairs;
+#pragma unroll 4
+    for (uint32_t t = 0; t < n_b; ++t) {
+      const uint2 mj = mem[t];
+      before += (mj.x < key || (mj.x == key && (mj.y & 0xFFFFu) < i)) ? (mj.y >> 16) : 0u;
+    }
+  }
+  if (live) {
+    PL_STAMP(pl_t3);
     SkewItem it;
     it.part = p;
     it.len = len;
@@ -588,15 +612,25 @@ __device__ __forceinline__ void plan_sparse_body(const PlanArgs& a, uint32_t* s_
   }
   if (i < 9) {  // queue x starts behind the items of the queues below it
     uint32_t acc = 0;
-    for (uint32_t y = 0; y < i; ++y) acc += s_q[y];
+    for (uint32_t y = 0; y < 2u * i; ++y) acc += s_bitems[y];
     a.q_start[i] = acc;
   }
   if (i < 8) a.heads[i * SK_HEAD_STRIDE] = 0;
+#ifdef MI355_DEV_PLAN  // dev[0..3] += loads + totals / T + histogram / rank loop / emit (thread 0's stamps; stat_rows = &DevCtl::rows_scanned)
+  if (i == 0 && stat_rows) {
+    uint32_t* dev = (uint32_t*)stat_rows + 8;
+    atomicAdd(dev + 0, (uint32_t)(pl_t1 - pl_t0));
+    atomicAdd(dev + 1, (uint32_t)(pl_t2 - pl_t1));
+    atomicAdd(dev + 2, (uint32_t)(pl_t3 - pl_t2));
+    atomicAdd(dev + 3, (uint32_t)(wall_clock64() - pl_t3));
+  }
+#endif
 }
 static __global__ __launch_bounds__(PLAN_SPARSE_MAX_PAIRS) void k_plan_sparse(PlanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ __attribute__((aligned(16))) uint2 s_list[PLAN_SPARSE_MAX_PAIRS];
   __shared__ uint32_t s_xf[9], s_q[PLAN_SQ_WORDS];
-  plan_sparse_body<false>(a, s_key, s_xf, s_q, nullptr, nullptr, s_nsl);
+  plan_sparse_body<false>(a, s_key, s_xf, s_q, nullptr, nullptr, s_list);
 }
 
 // ---- latency front, second half: probe selection of every query + the work list, ONE launch ----------------------
@@ -634,7 +668,8 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   __shared__ uint32_t hist[256];
   __shared__ uint32_t s_and, s_or, s_prefix, s_need, s_less, s_wave_cnt[SELPLAN_NT / 64], s_running, s_best_at, s_eq_all, s_last;
   __shared__ unsigned long long s_best;
-  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS], s_nsl[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[PLAN_SPARSE_MAX_PAIRS];
+  __shared__ __attribute__((aligned(16))) uint2 s_list[PLAN_SPARSE_MAX_PAIRS];
   __shared__ uint32_t s_xf[9], s_q[PLAN_SQ_WORDS];
   constexpr int NT = SELPLAN_NT, NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -826,7 +861,7 @@ static __global__ __launch_bounds__(SELPLAN_NT) void k_select_plan(SelectPlanArg
   const unsigned long long sp_t3 = wall_clock64();
 #endif
   if (!alone && !s_last) return;
-  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q, alone ? s_out : (const uint32_t*)nullptr, a.stat_rows, s_nsl);
+  plan_sparse_body<true>(a.plan, s_key, s_xf, s_q, alone ? s_out : (const uint32_t*)nullptr, a.stat_rows, s_list);
 #ifdef MI355_DEV_FRONT
   __syncthreads();
   if (tid == 0 && a.stat_rows) {  // (stat_rows = &DevCtl::rows_scanned, the first member: the counters follow it)

@@ -48,3 +48,4 @@ t = 0.01
 s = max(c[3], 1)
 print(f"k_coarse_lat, per sampled block ({c[3]} samples): query->LDS {c[0] * t / s:.2f} us, row loads + staging {c[1] * t / s:.2f} us, chains {c[2] * t / s:.2f} us")
 print(f"k_select_plan, per call: keys {c[4] * t / N:.2f} us, radix windows {c[5] * t / N:.2f} us, emit + ticket {c[6] * t / N:.2f} us, plan {c[7] * t / N:.2f} us")
+print(f"(a -DMI355_DEV_PLAN build instead: plan_sparse_body per call: loads + totals {c[0] * t / N:.2f} us, T + histogram {c[1] * t / N:.2f} us, rank loop {c[2] * t / N:.2f} us, emit {c[3] * t / N:.2f} us)")

@@ -34,6 +34,15 @@ pmc c3_lds $LDS -- $C3 --steps 2
 pmc dflt_fetch FETCH_SIZE -- $DS
 pmc dflt_write WRITE_SIZE -- $DS
 pmc dflt_lds $LDS -- $DS
+# the latency paths: kernel traces of single queries / batches of 8 on the C3 index and on the reference's default shape (profiles/r06_o_*)
+for cfg in "96 64 4096 1" "96 64 4096 8" "48 20 12207 1" "48 20 12207 8"; do
+  set -- $cfg
+  echo "=== m=$1 nprobe=$2 nlist=$3 batch=$4" >> $R/$O/latency_gaps.txt
+  rm -rf /tmp/tr_lat
+  LAT_M=$1 LAT_NPROBE=$2 timeout 400 rocprofv3 --kernel-trace -d /tmp/tr_lat -o t --output-format csv -- python -u $R/tests/tools/latency_trace.py 100000000 $3 $4 2>&1 | grep "per call" >> $R/$O/latency_gaps.txt
+  python $R/scripts/trace_gaps.py /tmp/tr_lat k_coarse_lat >> $R/$O/latency_gaps.txt 2>&1
+done
+rm -rf /tmp/tr_lat
 cd $R
 for n in c3 dflt flat; do f=$(find $O/$n -name "*kernel_stats.csv" | head -1); echo "== $n $f"; head -9 "$f" | cut -c1-230; done
 grep "^nprobe" $O/dflt.log | head -3

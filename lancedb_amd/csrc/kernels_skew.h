@@ -297,9 +297,9 @@ struct PlanArgs {
   const uint32_t* order;    // [nlist] static partition order
   const uint32_t* opos;     // [nlist] its inverse: position of partition p in `order`
   const uint32_t* xcd_first;  // [9] index into order where queue x starts
-  uint32_t* cnt;            // [2 * nlist] (zeroed by k_plan_scan for the next batch); second half: class "nearest"
-  uint32_t* off;            // [2 * nlist]
-  uint32_t* fill;           // [2 * nlist]
+  uint32_t* cnt;            // [2 * nlist] indexed by plan_vkey (zeroed by k_plan_scan for the next batch)
+  uint32_t* off;            // [2 * nlist] (same index)
+  uint32_t* fill;           // [2 * nlist] (same index)
   uint32_t* q_start;        // [9]
   uint32_t* heads;          // [8 * SK_HEAD_STRIDE]
   SkewItem* items;          // [n_pairs]
@@ -330,6 +330,19 @@ struct PlanArgs {
 __device__ __forceinline__ uint32_t plan_class(const PlanArgs& a, uint32_t i) {
   return (a.best_first && (i % a.nprobe) == 0u) ? 1u : 0u;
 }
+// cnt / off / fill are indexed by a (partition, class)'s place in the VIRTUAL sequence the work list is laid out in: queue by
+// queue, [class-1 counts of the queue's partitions (best_first only)] [class-0 counts of the same partitions], partitions in
+// the index's static `order`.  (Rounds 4-6 indexed them by partition + class * nlist and k_plan_scan walked the sequence
+// through `order`: two dependent, uncoalesced loads and three scattered stores per counter from ONE workgroup — bound by the
+// CU's one-line-per-clock address path, 80 us at the reference's default 12 207 partitions.)
+__device__ __forceinline__ uint32_t plan_vkey(const PlanArgs& a, uint32_t p, uint32_t cls) {
+  const uint32_t pos = a.opos[p];
+  if (!a.best_first) return pos;
+  uint32_t x = 0;
+  for (uint32_t y = 1; y < 8; ++y) x += (pos >= a.xcd_first[y]) ? 1u : 0u;  // queue of p (empty queues are skipped over)
+  const uint32_t x0 = a.xcd_first[x], len = a.xcd_first[x + 1] - x0, idx = pos - x0;
+  return 2u * x0 + (cls ? idx : len + idx);
+}
 
 __device__ __forceinline__ void plan_count_pair(const PlanArgs& a, uint32_t i) {
   if (!a.act.on(i / a.nprobe)) return;
@@ -337,84 +350,85 @@ __device__ __forceinline__ void plan_count_pair(const PlanArgs& a, uint32_t i) {
   // ids outside the index (mi355_search_probes), empty and not-owned partitions make no work item; a
   // pair's candidate slots hold cand_cnt[i] rows: 0 until (and unless) its item ran
   for (uint32_t sl = 0; sl < a.n_slices; ++sl) a.cand_cnt[(size_t)i * a.n_slices + sl] = 0u;
-  if (p < a.nlist && a.plen[p]) atomicAdd(&a.cnt[p + plan_class(a, i) * a.nlist], a.n_slices);
+  if (p < a.nlist && a.plen[p]) atomicAdd(&a.cnt[plan_vkey(a, p, plan_class(a, i))], a.n_slices);
 }
 static __global__ void k_plan_count(PlanArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < a.n_pairs) plan_count_pair(a, i);
 }
 
-// one 1024-thread block: exclusive scan of the item counts in queue order.  The virtual sequence is,
-// queue by queue, [class-1 counts of the queue's partitions (best_first only)] [class-0 counts of the
-// same partitions], partitions in the index's static `order`.
-__device__ __forceinline__ void plan_scan_block(const PlanArgs& a, uint32_t* s_part /*[1024]*/, uint32_t* s_xf /*[9]*/) {
+// one 1024-thread block: exclusive scan of the item counts in the virtual sequence (= index order of cnt / off / fill), in
+// chunks of PLAN_CHUNK counters staged through LDS: coalesced loads, every thread scans its eight consecutive counters, the
+// chunk's offsets leave coalesced again (a chunk is one memory round trip + one block scan: ~3 us).
+#define PLAN_CHUNK 8192u
+#define PLAN_CHUNK_WORDS (PLAN_CHUNK + PLAN_CHUNK / 8u)  // (a thread's eight counters start 9 words apart: no bank conflicts)
+__device__ __forceinline__ void plan_scan_block(const PlanArgs& a, uint32_t* s_part /*[1024]*/, uint32_t* s_xf /*[9]*/,
+                                                uint32_t* s_c /*[PLAN_CHUNK_WORDS]*/) {
   const uint32_t tid = threadIdx.x;
   const uint32_t ncls = a.best_first ? 2u : 1u;
   const uint32_t nv = ncls * a.nlist;
   if (tid < 9) s_xf[tid] = a.xcd_first[tid];
   __syncthreads();
-  // virtual index -> key into cnt / off / fill (partition + class * nlist)
-  auto key_of = [&](uint32_t v) -> uint32_t {
-    uint32_t x = 0;
-    for (uint32_t y = 1; y < 8; ++y) x += (v >= ncls * s_xf[y]) ? 1u : 0u;  // queue of v (empty queues are skipped over)
-    const uint32_t len = s_xf[x + 1] - s_xf[x], r = v - ncls * s_xf[x];
-    const uint32_t cls = (ncls == 2u && r < len) ? 1u : 0u, idx = r < len ? r : r - len;
-    return a.order[s_xf[x] + idx] + cls * a.nlist;
-  };
-  const uint32_t per = (nv + 1023u) / 1024u;
-  const uint32_t i0 = tid * per, i1 = sk_min_u32(nv, i0 + per);
-  // (eight counts in flight per thread, loaded unconditionally at clamped indices: one dependent L2 round trip per count —
-  //  24 per thread and pass at the reference's default 12 207 partitions — made this single workgroup a 97 us kernel)
-  constexpr uint32_t PFN = 8;
-  uint32_t sum = 0;
-  for (uint32_t i = i0; i < i1; i += PFN) {
-    uint32_t c[PFN];
+  auto slot = [](uint32_t i) -> uint32_t { return i + (i >> 3); };
+  uint32_t carry = 0;
+  for (uint32_t b = 0; b < nv; b += PLAN_CHUNK) {
+    uint32_t c[8];
 #pragma unroll
-    for (uint32_t u = 0; u < PFN; ++u) c[u] = a.cnt[key_of(sk_min_u32(i + u, i1 - 1u))];
-#pragma unroll
-    for (uint32_t u = 0; u < PFN; ++u) sum += (i + u < i1) ? c[u] : 0u;
-  }
-  s_part[tid] = sum;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t v = tid >= d ? s_part[tid - d] : 0u;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = s_part[tid] - sum;
-  for (uint32_t i = i0; i < i1; i += PFN) {
-    uint32_t kk[PFN], c[PFN];
-#pragma unroll
-    for (uint32_t u = 0; u < PFN; ++u) {
-      kk[u] = key_of(sk_min_u32(i + u, i1 - 1u));
-      c[u] = a.cnt[kk[u]];
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t v = b + u * 1024u + tid;
+      c[u] = v < nv ? a.cnt[v] : 0u;
     }
 #pragma unroll
-    for (uint32_t u = 0; u < PFN; ++u) {
-      if (i + u < i1) {
-        a.off[kk[u]] = run;
-        a.fill[kk[u]] = 0;
-        a.cnt[kk[u]] = 0;
-        // queue boundaries: the first virtual index of each queue records its offset
-        for (uint32_t x = 0; x < 8; ++x)
-          if (ncls * s_xf[x] == i + u) a.q_start[x] = run;
-        run += c[u];
+    for (uint32_t u = 0; u < 8; ++u) s_c[slot(u * 1024u + tid)] = c[u];
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      c[u] = s_c[slot(tid * 8u + u)];
+      sum += c[u];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+      uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+      __syncthreads();
+      s_part[tid] += v;
+      __syncthreads();
+    }
+    uint32_t run = carry + s_part[tid] - sum;
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      s_c[slot(tid * 8u + u)] = run;
+      run += c[u];
+    }
+    const uint32_t total = s_part[1023];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t v = b + u * 1024u + tid;
+      if (v < nv) {
+        a.off[v] = s_c[slot(u * 1024u + tid)];
+        a.fill[v] = 0;
+        a.cnt[v] = 0;
       }
     }
+    // queue boundaries: the first virtual index of each queue records its offset
+    if (tid < 8) {
+      const uint32_t v = ncls * s_xf[tid];
+      if (v >= b && v < b + PLAN_CHUNK && v < nv) a.q_start[tid] = s_c[slot(v - b)];
+    }
+    carry += total;
+    __syncthreads();
   }
-  if (tid == 1023) {
-    const uint32_t total = s_part[1023];
-    a.q_start[8] = total;
-    for (uint32_t x = 0; x < 8; ++x)
-      if (s_xf[x] >= a.nlist) a.q_start[x] = total;
-  }
+  if (tid < 8 && s_xf[tid] >= a.nlist) a.q_start[tid] = carry;
+  if (tid == 8) a.q_start[8] = carry;
   if (tid < 8) a.heads[tid * SK_HEAD_STRIDE] = 0;
 }
 static __global__ __launch_bounds__(1024) void k_plan_scan(PlanArgs a) {
   __shared__ uint32_t s_part[1024];
   __shared__ uint32_t s_xf[9];
-  plan_scan_block(a, s_part, s_xf);
+  __shared__ uint32_t s_c[PLAN_CHUNK_WORDS];
+  plan_scan_block(a, s_part, s_xf, s_c);
 }
 
 __device__ __forceinline__ void plan_fill_pair(const PlanArgs& a, uint32_t i) {
@@ -429,7 +443,7 @@ __device__ __forceinline__ void plan_fill_pair(const PlanArgs& a, uint32_t i) {
   it.lrow0 = a.lrow0[p];
   it.grow0 = a.grow0[p];
   it.code_off = a.code_off[p];
-  const uint32_t key = p + plan_class(a, i) * a.nlist;
+  const uint32_t key = plan_vkey(a, p, plan_class(a, i));
   const uint32_t at = a.off[key] + atomicAdd(&a.fill[key], a.n_slices);
   for (uint32_t sl = 0; sl < a.n_slices; ++sl) {
     it.pair = a.n_slices > 1u ? sk_pack_pair(i, sl, a.n_slices) : i;
@@ -448,10 +462,11 @@ static __global__ void k_plan_fill(PlanArgs a) {
 static __global__ __launch_bounds__(1024) void k_plan_fused(PlanArgs a) {
   __shared__ uint32_t s_part[1024];
   __shared__ uint32_t s_xf[9];
+  __shared__ uint32_t s_c[PLAN_CHUNK_WORDS];
   for (uint32_t i = threadIdx.x; i < a.n_pairs; i += 1024u) plan_count_pair(a, i);
   __threadfence();
   __syncthreads();
-  plan_scan_block(a, s_part, s_xf);
+  plan_scan_block(a, s_part, s_xf, s_c);
   __threadfence();
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < a.n_pairs; i += 1024u) plan_fill_pair(a, i);

@@ -711,10 +711,22 @@ static __global__ __launch_bounds__(256) void k_select_probes(
     hist[tid] = 0;
     __syncthreads();
     uint32_t prefix = s_prefix;
+    // (runs of one bin are counted in a register and added once: coarse distances share their top key byte, and at
+    //  nlist 65536 the first pass was 65536 same-address LDS atomics per query — serialised)
+    uint32_t cur = 0, run = 0;
     for (uint32_t p = tid; p < nlist; p += 256) {
       uint32_t key = f32_sort_key(src[p]);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * byte)) & 255u], 1u);
+      if ((key & mask) == prefix) {
+        const uint32_t bin = (key >> (8 * byte)) & 255u;
+        if (bin != cur && run) {
+          atomicAdd(&hist[cur], run);
+          run = 0;
+        }
+        cur = bin;
+        ++run;
+      }
     }
+    if (run) atomicAdd(&hist[cur], run);
     __syncthreads();
     {
       // the bin holding the need-th smallest key: inclusive scan of the 256 counts over the 256 threads (a

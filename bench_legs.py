@@ -375,7 +375,7 @@ def default_shape_leg(a, torch, np, dev, n_rows=100_000_000, dim=768, parity_que
     outb = out_buffers(torch, dev, B, k)
     ix.set_stream(torch.cuda.current_stream().cuda_stream)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    steps = max(4, a.steps // 2)
+    steps = max(20, a.steps * 2)  # (a step is 4-10 ms here: five of them left the leg +-4 % from run to run)
     res = {"config": {"n_rows": n, "dim": dim, "nlist": nlist, "m": m, "batch_queries": B, "k": k, "partition_rows_median": int(np.median(s["lens"])),
                       "partition_rows_max": int(s["lens"].max()), "table_image_bytes_per_pair": 256 * m * 4,
                       "codebook_bytes_per_in_item_build": 256 * dim * 4}}

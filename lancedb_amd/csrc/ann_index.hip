@@ -449,6 +449,12 @@ int32_t run_ivfpq(mi355_index* ix, const float* d_q, uint32_t nq, const SearchPl
                          dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
                          view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
                          ix->w_coarse.as<float>());
+    else if ((ix->dim & 3u) == 0 && (uint64_t)((ix->nlist + CM2_T - 1) / CM2_T) * ((n + CM2_T - 1) / CM2_T) >= 2u * (uint64_t)ix->n_cus &&
+             dev_knob("MI355_COARSE_BLOCKED", 1))
+      hipLaunchKernelGGL(k_coarse_mfma2, dim3((ix->nlist + CM2_T - 1) / CM2_T, (n + CM2_T - 1) / CM2_T),
+                         dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,
+                         view.centroids, view.cnorm, ix->nlist, ix->dim, ix->metric,
+                         ix->w_coarse.as<float>(), act);
     else
       hipLaunchKernelGGL(k_coarse_mfma, dim3((ix->nlist + CM_T - 1) / CM_T, (n + CM_T - 1) / CM_T),
                          dim3(256), 0, st, ix->w_qp.as<float>(), ix->w_qq.as<float>(), n,

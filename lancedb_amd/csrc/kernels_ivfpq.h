@@ -191,6 +191,7 @@ static __global__ __launch_bounds__(256) void k_coarse_tile(
 #define CM_T 64
 #define CM_K 32
 typedef __attribute__((ext_vector_type(16))) float cm_f32x16;
+typedef __attribute__((ext_vector_type(4))) float cm_f32x4;
 static __global__ __launch_bounds__(256) void k_coarse_mfma(
     const float* __restrict__ qp, const float* __restrict__ qq, uint32_t nq,
     const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist, uint32_t dim,
@@ -275,6 +276,99 @@ static __global__ __launch_bounds__(256) void k_coarse_mfma(
     else
       v = __fmaf_rn(-2.0f, acc[reg], qq[qi] + cnv);
     out[(size_t)qi * nlist + ci] = v;
+  }
+}
+
+// The same kernel register-blocked 2 x 2: a wave owns a 64 x 64 block (four 32 x 32 MFMA tiles), the workgroup 128 queries x
+// 128 centroids.  Every output element still accumulates its products k-ascending in ONE accumulator, so the bits are
+// k_coarse_mfma's; per MFMA the LDS reads, the staging stores and the barriers are halved (the 64 x 64 kernel ran at 0.57-0.66
+// of the f32 matrix peak).  Used when the launch still has two workgroups per CU (batches of ~1024 queries and up).
+#define CM2_T 128
+static __global__ __launch_bounds__(256) void k_coarse_mfma2(
+    const float* __restrict__ qp, const float* __restrict__ qq, uint32_t nq,
+    const float* __restrict__ cen, const float* __restrict__ cn, uint32_t nlist, uint32_t dim,
+    uint32_t metric, float* __restrict__ out /*[nq, nlist]*/, ActiveMask act = ActiveMask()) {
+  __shared__ float sa[CM2_T][CM_K + 1];
+  __shared__ float sb[CM2_T][CM_K + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const uint32_t q0 = blockIdx.y * CM2_T, c0 = blockIdx.x * CM2_T;
+  if (!act.on(q0)) return;  // a query tile past the device-side batch size
+  cm_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fi = lane & 31, fk = lane >> 5;
+  // staging: 128 rows x 32 k per operand = 1024 16-B pieces, 4 per thread per operand (dim % 4 == 0: the launch site checks)
+  cm_f32x4 ra[4], rb[4];
+  auto fetch = [&](uint32_t k0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      const int r = idx >> 3, k4 = (idx & 7) * 4;
+      const uint32_t k = k0 + k4;
+      cm_f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = va;
+      if (k < dim) {
+        if (q0 + r < nq) va = *(const cm_f32x4*)(qp + (size_t)(q0 + r) * dim + k);
+        if (c0 + r < nlist) vb = *(const cm_f32x4*)(cen + (size_t)(c0 + r) * dim + k);
+      }
+      ra[e] = va;
+      rb[e] = vb;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      const int r = idx >> 3, k4 = (idx & 7) * 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sa[r][k4 + t] = ra[e][t];
+        sb[r][k4 + t] = rb[e][t];
+      }
+    }
+  };
+  fetch(0);
+  for (uint32_t k0 = 0; k0 < dim; k0 += CM_K) {
+    stash();
+    __syncthreads();
+    if (k0 + CM_K < dim) fetch(k0 + CM_K);
+#pragma unroll
+    for (int kk = 0; kk < CM_K; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = sa[wr * 64 + i * 32 + fi][kk + fk];
+        b[i] = sb[wc * 64 + i * 32 + fi][kk + fk];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D: col = lane & 31 (centroid), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t ci = c0 + wc * 64 + j * 32 + fi;
+    const float cnv = ci < nlist ? cn[ci] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const uint32_t qi = q0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fk;
+        if (qi >= nq || ci >= nlist) continue;
+        float v;
+        if (metric == MI355_METRIC_DOT)
+          v = 1.0f - acc[i][j][reg];
+        else
+          v = __fmaf_rn(-2.0f, acc[i][j][reg], qq[qi] + cnv);
+        out[(size_t)qi * nlist + ci] = v;
+      }
   }
 }
 

@@ -627,3 +627,17 @@ def test_flat_takes_the_cheaper_exact_path_per_call_and_both_return_the_same(ora
     from lancedb_amd._lib import lib
     both = _abi.FLAT_FORCE_FILTER | _abi.FLAT_FORCE_SWEEP  # the two pins exclude each other
     assert lib().mi355_flat_configure(f._h, C.c_uint32(0), C.c_uint32(0), C.c_uint32(both)) == _abi.ERR_INVALID_INPUT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_blocked_coarse_kernel_partial_tiles(oracle, metric):
+    """Batches whose coarse stage launches at least two 128 x 128 tiles per CU run the register-blocked f32 MFMA kernel
+    (k_coarse_mfma2, csrc/kernels_ivfpq.h): nlist and the batch are not multiples of 128, dim is a multiple of 4 but not
+    of the 32-deep k stage.  A wrong coarse score changes a probe list, and with it ids or distances: everything `==`."""
+    nlist, dim, m, nq, nprobe = 33001, 100, 25, 300, 6
+    s = train.synthetic_index(150_000, dim, nlist, m, seed=91, skew=0.8, empty_parts=500)
+    rng = np.random.default_rng(17)
+    q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.4, size=(nq, dim))).astype(np.float32)
+    g, o = _both(oracle, s, metric=metric)
+    _assert_same(g.search(q, k=10, nprobe_min=nprobe, nprobe_max=nprobe), o.search(q, k=10, nprobe_min=nprobe, nprobe_max=nprobe))

@@ -554,6 +554,12 @@ int32_t coarse_topn_device(mi355_index* ix, const float* d_q, uint32_t nq, uint3
   const float* cn = ix->cnorm.as<float>() + cent_lo;
   for (uint32_t y0 = 0; y0 < nq; y0 += 65535u * CM_T) {  // grid.y limit
     const uint32_t ny = std::min(nq - y0, 65535u * CM_T);
+    // (the register-blocked kernel when the launch has two 128 x 128 tiles per CU: same bits, see kernels_ivfpq.h)
+    if ((ix->dim & 3u) == 0 && (uint64_t)((n_slice + CM2_T - 1) / CM2_T) * ((ny + CM2_T - 1) / CM2_T) >= 2u * (uint64_t)ix->n_cus)
+      hipLaunchKernelGGL(k_coarse_mfma2, dim3((n_slice + CM2_T - 1) / CM2_T, (ny + CM2_T - 1) / CM2_T), dim3(256), 0, st,
+                         ix->w_qp.as<float>() + (size_t)y0 * ix->dim, ix->w_qq.as<float>() + y0, ny, cen, cn, n_slice,
+                         ix->dim, ix->metric, ix->w_coarse.as<float>() + (size_t)y0 * n_slice);
+    else
     hipLaunchKernelGGL(k_coarse_mfma, dim3((n_slice + CM_T - 1) / CM_T, (ny + CM_T - 1) / CM_T), dim3(256), 0, st,
                        ix->w_qp.as<float>() + (size_t)y0 * ix->dim, ix->w_qq.as<float>() + y0, ny, cen, cn, n_slice,
                        ix->dim, ix->metric, ix->w_coarse.as<float>() + (size_t)y0 * n_slice);

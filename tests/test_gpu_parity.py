@@ -641,3 +641,20 @@ def test_blocked_coarse_kernel_partial_tiles(oracle, metric):
     q = (s["centroids"][rng.integers(0, nlist, size=nq)] + rng.normal(0, 0.4, size=(nq, dim))).astype(np.float32)
     g, o = _both(oracle, s, metric=metric)
     _assert_same(g.search(q, k=10, nprobe_min=nprobe, nprobe_max=nprobe), o.search(q, k=10, nprobe_min=nprobe, nprobe_max=nprobe))
+
+
+def test_blocked_coarse_kernel_in_the_coarse_slice_path(oracle):
+    """mi355_coarse_topn (the sharded coarse stage of SURVEY.md §8e) over a centroid slice large enough for the register-blocked
+    kernel (two 128 x 128 tiles per CU), slice bounds and batch not multiples of 128: scores and ids `==` the oracle's."""
+    nlist, dim, m, nq, n_sel, lo, hi = 40000, 64, 16, 600, 9, 1237, 1237 + 17003
+    s = train.synthetic_index(60_000, dim, nlist, m, seed=92, skew=0.5, empty_parts=100)
+    rng = np.random.default_rng(18)
+    q = (s["centroids"][rng.integers(lo, hi, size=nq)] + rng.normal(0, 0.4, size=(nq, dim))).astype(np.float32)
+    g, o = _both(oracle, s)
+    ids, dist, cnt = g.coarse_topn(q, n_sel, lo, hi)
+    assert (np.asarray(cnt) == n_sel).all()
+    for i in range(0, nq, 7):
+        co = np.asarray(o.coarse(q[i]))[lo:hi]
+        order = np.lexsort((np.arange(lo, hi), co))[:n_sel]
+        got = sorted(zip(np.asarray(dist[i]).tolist(), np.asarray(ids[i]).astype(np.int64).tolist()))
+        assert got == sorted(zip(co[order].tolist(), (order + lo).tolist())), i
